@@ -1,0 +1,152 @@
+/*
+ * x266hip.h -- C ABI of libx266hip.so: the MI355X (gfx950) implementation of
+ * x266's block-transform / motion-cost hot path.
+ *
+ * Plain C, plain pointers and sizes; no HIP, torch or C++ types cross this
+ * boundary (a stream is passed as an opaque `void *` that holds a hipStream_t).
+ * Reference paths below are relative to the upstream x266 tree.
+ *
+ * Three groups of entry points:
+ *
+ *  1. The six BDPI symbols the Bluespec testbenches import
+ *     (src/mkDct32.bsv:409-411, src/mkSatd.bsv:204-206) and that upstream
+ *     defines in src_tb/dct32.c:178-246 and src_tb/satd.c:124-152.  Signatures,
+ *     packing, call order and statefulness are identical, so this library can
+ *     replace src_tb/{dct32,satd}.c on the bsc link line that names every src_tb C file
+ *     link line (build/Makefile:65-67); the golden values the DUT is compared
+ *     with are then computed by the GPU kernels.
+ *
+ *  2. Batch entry points (no upstream counterpart -- upstream is one block at
+ *     a time).  Conventions follow src/x266.cpp: `x` prefix, context first,
+ *     caller-allocated buffers, int 0 / negative return (x266.cpp:494-513).
+ *     Block layout is the reference's: row-major int16, blocks contiguous
+ *     (32x32 = 2048 B per DCT block, 8x8 = 128 B per SATD block).
+ *
+ *  3. Small host utilities (word packing, device memory helpers) so that a
+ *     pure-C host can drive the device-pointer API without HIP headers.
+ *
+ * The library NEVER falls back to a CPU implementation: without a usable
+ * gfx950 device every compute entry point fails (negative return; the BDPI
+ * shims print to stderr and abort()).
+ */
+#ifndef X266HIP_H
+#define X266HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* return codes (x266.cpp style: 0 ok, negative failure)                     */
+/* ------------------------------------------------------------------------ */
+#define X266HIP_OK        0
+#define X266HIP_EINVAL   (-1)   /* bad argument (NULL pointer with n > 0, ...)  */
+#define X266HIP_EDEVICE  (-2)   /* no gfx950 device / HIP runtime error         */
+#define X266HIP_ENOMEM   (-3)   /* device or host allocation failed             */
+
+typedef struct x266hip_ctx x266hip_ctx;     /* opaque, one per (thread, device) */
+
+/* ------------------------------------------------------------------------ */
+/* context (cf. xCodecInit / xCodecFree, src/x266.cpp:494-524)               */
+/* ------------------------------------------------------------------------ */
+/* Creates a context on HIP device `device_id`, uploads the MFMA operand images
+ * of the coefficient matrix (g_t32, src_tb/dct32.c:30-64).  Fails with
+ * X266HIP_EDEVICE when the device is not a gfx950 part. */
+int  xHipCodecInit(x266hip_ctx **ctx, int device_id);
+void xHipCodecFree(x266hip_ctx *ctx);
+/* Last error text of this context (never NULL; "" when none). */
+const char *xHipLastError(const x266hip_ctx *ctx);
+/* Device facts for reports: name, CU count, max engine clock (MHz), HBM bytes. */
+int  xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap,
+                    int *cu_count, int *clock_mhz, size_t *hbm_bytes);
+/* Kernel variant selection for A/B measurement ("dct32_variant", "satd_variant",
+ * "waves_per_cu" ...).  Unknown keys return X266HIP_EINVAL. */
+int  xHipSetOption(x266hip_ctx *ctx, const char *key, int value);
+int  xHipGetOption(const x266hip_ctx *ctx, const char *key, int *value);
+
+/* ------------------------------------------------------------------------ */
+/* batch API, device pointers (inputs already resident in HBM)               */
+/* `stream` holds a hipStream_t (NULL = the default stream).  Asynchronous:  */
+/* returns after enqueueing; use xHipStreamSync or the caller's own stream   */
+/* API to wait.  d_in / d_out must be 16-byte aligned and must not overlap.   */
+/* ------------------------------------------------------------------------ */
+/* 2-D forward 32x32 DCT-II, shifts 4 then 11, truncating int16 stores:
+ * bit-exact with partialButterfly32 x2 as called by dct32_genNew
+ * (src_tb/dct32.c:66-170,180-198).  out[v*32+u], v = vertical frequency. */
+int xDct32FwdBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out,
+                      size_t n_blocks, void *stream);
+/* 2-D inverse (no upstream counterpart; HEVC/VVC inverse for 8-bit video:
+ * column pass shift 7, row pass shift 12, int16 clipping after each pass). */
+int xDct32InvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out,
+                      size_t n_blocks, void *stream);
+/* 8x8 Hadamard SATD of n residual blocks: bit-exact with satd8x8
+ * (src_tb/satd.c:31-118), including its int16 wraparound.  d_out[n] uint32. */
+int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out,
+                     size_t n_blocks, void *stream);
+/* Synthetic residual stream with the reference's stimulus distribution
+ * ((rand()&0xFF)-(rand()&0xFF), src_tb/dct32.c:191-193) from a counter-based
+ * SplitMix64: sample i = lo8(r) - lo8(r>>8), r = mix(seed+(first_index+i+1)*phi). */
+int xFillResidualDev(x266hip_ctx *ctx, int16_t *d_dst, size_t n_samples,
+                     uint64_t seed, uint64_t first_index, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* batch API, host pointers (caller-owned host buffers; staged through        */
+/* internal device buffers in chunks, H2D / kernel / D2H overlapped).         */
+/* Synchronous: results are in `out` on return.                               */
+/* ------------------------------------------------------------------------ */
+int xDct32FwdBatch(x266hip_ctx *ctx, const int16_t *in, int16_t *out, size_t n_blocks);
+int xDct32InvBatch(x266hip_ctx *ctx, const int16_t *in, int16_t *out, size_t n_blocks);
+int xSatd8x8Batch(x266hip_ctx *ctx, const int16_t *diff, uint32_t *out, size_t n_blocks);
+
+/* ------------------------------------------------------------------------ */
+/* device memory / stream helpers for hosts without HIP headers               */
+/* ------------------------------------------------------------------------ */
+int xHipMalloc(x266hip_ctx *ctx, void **d_ptr, size_t bytes);
+int xHipFree(x266hip_ctx *ctx, void *d_ptr);
+int xHipMemcpyH2D(x266hip_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int xHipMemcpyD2H(x266hip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+int xHipStreamSync(x266hip_ctx *ctx, void *stream);
+/* Times `reps` back-to-back launches of one kernel with HIP events recorded on
+ * `stream` itself; returns the mean milliseconds per launch in *ms_per_launch.
+ * op: 0 = dct32 fwd, 1 = dct32 inv, 2 = satd8x8 (buffers as in the Dev calls). */
+int xHipTimeKernel(x266hip_ctx *ctx, int op, const void *d_in, void *d_out,
+                   size_t n_blocks, int reps, void *stream, double *ms_per_launch);
+
+/* ------------------------------------------------------------------------ */
+/* host-only utilities (no device needed)                                     */
+/* ------------------------------------------------------------------------ */
+/* BDPI packing of two input rows, Vector#(2,Vector#(32,Bit#(16))):
+ * res[w] = (x[2w+1] << 16) + x[2w], row `first_row` then `first_row+1`
+ * (src_tb/dct32.c:205-220). */
+void     xDct32PackDiffRows(const int16_t *mat, int first_row, unsigned int res[32]);
+/* BDPI packing of 4 vertically adjacent coefficients, column-major walk:
+ * idx -> col = idx>>5, row = idx&31 (src_tb/dct32.c:223-246). */
+uint64_t xDct32PackDctWord(const int16_t *dct, int idx);
+const char *xHipVersion(void);
+
+/* ------------------------------------------------------------------------ */
+/* BDPI drop-in surface (stateful, non-reentrant, single-threaded -- exactly  */
+/* like upstream; device from env X266HIP_DEVICE, default 0)                  */
+/* ------------------------------------------------------------------------ */
+/* const int16_t g_t32[32][32]        -- src_tb/dct32.c:30 (exported global)  */
+#ifndef X266HIP_DEFINING_TABLE   /* the defining TU generates it at compile time */
+extern const int16_t g_t32[32][32];
+#endif
+/* draws a new 32x32 stimulus block with rand() and transforms it on the GPU  */
+void               dct32_genNew(void);                    /* src_tb/dct32.c:178 */
+/* two input rows per call, 16 calls per block                                */
+void               dct32_getDiff(unsigned int res[]);     /* src_tb/dct32.c:205 */
+/* four coefficients per call, column-major, 256 calls per block              */
+unsigned long long dct32_getDct(void);                    /* src_tb/dct32.c:223 */
+void               satd8x8_genNew(void);                  /* src_tb/satd.c:124  */
+/* one row (8 x int16 = 4 words) per call                                     */
+void               satd8x8_getDiff(unsigned int res[]);   /* src_tb/satd.c:143  */
+unsigned int       satd8x8_getSatd(void);                 /* src_tb/satd.c:149  */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X266HIP_H */

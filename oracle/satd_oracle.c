@@ -1,0 +1,74 @@
+/*
+ * satd_oracle.c -- CPU restatement of the reference's 8x8 Hadamard SATD.
+ *
+ * TEST INFRASTRUCTURE ONLY (see x266_oracle.h).  Parity: PINNED against
+ * oracle/_ref (src_tb/satd.c compiled in place) and tests/golden vectors.
+ *
+ * Reference: satd8x8(), src_tb/satd.c:31-118 -- three radix-2 butterfly
+ * stages with pairing distance 4, 2, 1 along rows (:38-70), the same along
+ * columns (:73-103), every intermediate stored to int16 (wraps), sum of
+ * absolute values in int32 (:105-111), result (sum + 2) >> 2 (:113).
+ * RTL twin: satd_1d / mkSatd8, src/mkSatd.bsv:44-80, 121-159.
+ */
+#include "x266_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+
+/* One in-place 8-point Hadamard over elements v[0], v[s], ..., v[7*s], with the
+ * reference's stage order (distance 4, then 2, then 1) and int16 wraparound. */
+static void hadamard8_i16(int16_t *v, int s)
+{
+    for (int dist = 4; dist >= 1; dist >>= 1) {
+        int16_t t[8];
+        for (int i = 0; i < 8; i++) {
+            /* element i pairs with i^dist; the lower index gets the sum */
+            const int lo = i & ~dist, hi = i | dist;
+            const int a = v[lo * s], b = v[hi * s];
+            t[i] = (int16_t)((i & dist) ? a - b : a + b);
+        }
+        for (int i = 0; i < 8; i++) v[i * s] = t[i];
+    }
+}
+
+uint32_t orc_satd8x8(const int16_t diff[64])
+{
+    int16_t m[64];
+    for (int i = 0; i < 64; i++) m[i] = diff[i];
+    for (int r = 0; r < 8; r++) hadamard8_i16(m + 8 * r, 1);   /* horizontal */
+    for (int c = 0; c < 8; c++) hadamard8_i16(m + c, 8);       /* vertical   */
+    int32_t sum = 0;
+    for (int i = 0; i < 64; i++) sum += abs((int)m[i]);
+    return (uint32_t)((sum + 2) >> 2);
+}
+
+void orc_satd8x8_batch(const int16_t *diff, uint32_t *out, size_t n_blocks)
+{
+    for (size_t b = 0; b < n_blocks; b++) out[b] = orc_satd8x8(diff + 64 * b);
+}
+
+typedef struct { const int16_t *in; uint32_t *out; size_t n; } satd_job_t;
+
+static void *satd_worker(void *p)
+{
+    satd_job_t *j = (satd_job_t *)p;
+    orc_satd8x8_batch(j->in, j->out, j->n);
+    return NULL;
+}
+
+void orc_satd8x8_batch_mt(const int16_t *diff, uint32_t *out, size_t n, int threads)
+{
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
+    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    satd_job_t *job = (satd_job_t *)malloc(sizeof(satd_job_t) * threads);
+    size_t done = 0;
+    for (int t = 0; t < threads; t++) {
+        size_t cnt = n / threads + ((size_t)t < n % threads ? 1 : 0);
+        job[t].in = diff + done * 64; job[t].out = out + done; job[t].n = cnt;
+        done += cnt;
+        pthread_create(&tid[t], NULL, satd_worker, &job[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    free(tid); free(job);
+}

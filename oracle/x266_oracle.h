@@ -1,0 +1,74 @@
+/*
+ * x266_oracle.h -- CPU restatement of the x266 DCT32 / SATD hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported CPU baseline.  The
+ * shipped path (libx266hip.so) never links or calls it.
+ *
+ * Every function cites the reference lines it restates (paths relative to
+ * /root/reference).  Parity status is stated per function:
+ *   PINNED    -- checked bit-for-bit against the real reference objects
+ *                (oracle/_ref, built from /root/reference/src_tb/{dct32,satd}.c)
+ *                and against tests/golden/ vectors generated from them.
+ *   UNPINNED  -- the reference holds no implementation; semantics are this
+ *                repository's own definition (documented in DESIGN.md).
+ */
+#ifndef X266_ORACLE_H
+#define X266_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- coefficient table (src_tb/dct32.c:30-64) ---------------------- PINNED */
+/* Row k = frequency, column n = sample.  Regenerated from the 32 magnitudes of
+ * the first column by cosine index folding, not pasted. */
+const int16_t *orc_dct32_table(void);            /* 32*32 int16, row-major   */
+
+/* ---- 1-D pass with transposed store (src_tb/dct32.c:66-170) -------- PINNED */
+/* dst[k*line + j] = (int16)((sum_n g[k][n]*src[32*j+n] + (1<<(shift-1))) >> shift)
+ * computed with the reference's even/odd partial-butterfly decomposition. */
+void orc_dct32_pass(const int16_t *src, int16_t *dst, int shift, int line);
+/* Same contract, computed as the dense 32-tap contraction (cross-check). */
+void orc_dct32_pass_dense(const int16_t *src, int16_t *dst, int shift, int line);
+
+/* ---- 2-D forward transform (src_tb/dct32.c:178-198) ---------------- PINNED */
+/* n blocks of 32x32 int16 row-major, blocks contiguous; shifts 4 then 11.
+ * out[v*32+u]: v = vertical frequency, u = horizontal frequency. */
+void orc_dct32_fwd(const int16_t *in, int16_t *out, size_t n_blocks);
+void orc_dct32_fwd_mt(const int16_t *in, int16_t *out, size_t n_blocks, int threads);
+
+/* ---- 2-D inverse transform ---------------------------------------- UNPINNED */
+/* HEVC/VVC-style inverse of the above for 8-bit video: column pass shift 7,
+ * row pass shift 12, each output clipped to int16. */
+void orc_dct32_inv(const int16_t *in, int16_t *out, size_t n_blocks);
+void orc_dct32_inv_mt(const int16_t *in, int16_t *out, size_t n_blocks, int threads);
+
+/* ---- 8x8 Hadamard SATD (src_tb/satd.c:31-118) ---------------------- PINNED */
+uint32_t orc_satd8x8(const int16_t diff[64]);
+void orc_satd8x8_batch(const int16_t *diff, uint32_t *out, size_t n_blocks);
+void orc_satd8x8_batch_mt(const int16_t *diff, uint32_t *out, size_t n_blocks, int threads);
+
+/* ---- BDPI word packing (src_tb/dct32.c:205-246, satd.c:143-147) ---- PINNED */
+void     orc_pack_diff_rows(const int16_t *mat, int first_row, uint32_t res[32]);
+uint64_t orc_pack_dct_word(const int16_t *dct, int idx);
+
+/* ---- synthetic residual stream (distribution of dct32.c:191-193) ---------- */
+/* Counter-based SplitMix64: sample i of stream `seed` = a - b with a,b the two
+ * low bytes of mix(seed + (i+1)*0x9E3779B97F4A7C15).  Same generator as the
+ * device-side xFillResidual kernel. */
+void orc_fill_residual(int16_t *dst, size_t n_samples, uint64_t seed, uint64_t first_index);
+
+/* ---- helpers --------------------------------------------------------------- */
+uint64_t orc_checksum64(const void *data, size_t n_bytes);  /* FNV-1a over 8-byte words, order dependent */
+uint64_t orc_sum_u16(const int16_t *data, size_t n);        /* order independent: sum of (uint16) values */
+int      orc_hw_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

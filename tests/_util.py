@@ -1,0 +1,212 @@
+"""Shared helpers for the test-suite: ctypes loaders for the oracle (checker),
+the optional real-reference build (oracle/_ref) and small numpy utilities.
+
+Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may touch
+anything under oracle/ -- it is the checker, never the product.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+_P = ctypes.c_void_p
+_SZ = ctypes.c_size_t
+
+
+def _build_oracle():
+    so = os.path.join(ORACLE_DIR, "liborc.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "--no-print-directory", so])
+    return so
+
+
+class Oracle:
+    """ctypes view of oracle/liborc.so (this repo's C restatement)."""
+
+    def __init__(self):
+        self.lib = ctypes.CDLL(_build_oracle())
+        L = self.lib
+        L.orc_dct32_table.restype = ctypes.POINTER(ctypes.c_int16)
+        L.orc_satd8x8.restype = ctypes.c_uint32
+        L.orc_pack_dct_word.restype = ctypes.c_uint64
+        L.orc_checksum64.restype = ctypes.c_uint64
+        L.orc_sum_u16.restype = ctypes.c_uint64
+        L.orc_hw_threads.restype = ctypes.c_int
+
+    def table(self):
+        return np.ctypeslib.as_array(self.lib.orc_dct32_table(), (32, 32)).copy()
+
+    def dct32_fwd(self, x, threads=1):
+        x = np.ascontiguousarray(x, np.int16).reshape(-1, 1024)
+        out = np.empty_like(x)
+        self.lib.orc_dct32_fwd_mt(_P(x.ctypes.data), _P(out.ctypes.data), _SZ(x.shape[0]), threads)
+        return out
+
+    def dct32_inv(self, z, threads=1):
+        z = np.ascontiguousarray(z, np.int16).reshape(-1, 1024)
+        out = np.empty_like(z)
+        self.lib.orc_dct32_inv_mt(_P(z.ctypes.data), _P(out.ctypes.data), _SZ(z.shape[0]), threads)
+        return out
+
+    def dct32_pass(self, src, shift, line=32, dense=False):
+        src = np.ascontiguousarray(src, np.int16)
+        dst = np.empty(32 * line, np.int16)
+        fn = self.lib.orc_dct32_pass_dense if dense else self.lib.orc_dct32_pass
+        fn(_P(src.ctypes.data), _P(dst.ctypes.data), shift, line)
+        return dst
+
+    def satd8x8(self, d, threads=1):
+        d = np.ascontiguousarray(d, np.int16).reshape(-1, 64)
+        out = np.empty(d.shape[0], np.uint32)
+        self.lib.orc_satd8x8_batch_mt(_P(d.ctypes.data), _P(out.ctypes.data), _SZ(d.shape[0]), threads)
+        return out
+
+    def fill_residual(self, n_samples, seed, first_index=0):
+        out = np.empty(n_samples, np.int16)
+        self.lib.orc_fill_residual(_P(out.ctypes.data), _SZ(n_samples), ctypes.c_uint64(seed),
+                                   ctypes.c_uint64(first_index))
+        return out
+
+    def pack_diff_rows(self, mat, first_row):
+        mat = np.ascontiguousarray(mat, np.int16)
+        res = np.empty(32, np.uint32)
+        self.lib.orc_pack_diff_rows(_P(mat.ctypes.data), first_row, _P(res.ctypes.data))
+        return res
+
+    def pack_dct_word(self, dct, idx):
+        dct = np.ascontiguousarray(dct, np.int16)
+        return int(self.lib.orc_pack_dct_word(_P(dct.ctypes.data), idx))
+
+    def checksum64(self, a):
+        a = np.ascontiguousarray(a)
+        return int(self.lib.orc_checksum64(_P(a.ctypes.data), _SZ(a.nbytes)))
+
+    def hw_threads(self):
+        return int(self.lib.orc_hw_threads())
+
+
+def ref_path():
+    return os.path.join(ORACLE_DIR, "_ref", "libx266ref.so")
+
+
+class Reference:
+    """ctypes view of oracle/_ref/libx266ref.so -- the REAL reference golden
+    models (src_tb/dct32.c, satd.c) compiled from /root/reference in place.
+    Present only where `make -C oracle ref` has run (not in git)."""
+
+    def __init__(self):
+        self.lib = ctypes.CDLL(ref_path())
+        L = self.lib
+        L.ref_dct32_table.restype = ctypes.POINTER(ctypes.c_int16)
+        L.ref_dct32_last_input.restype = ctypes.POINTER(ctypes.c_int16)
+        L.ref_dct32_last_output.restype = ctypes.POINTER(ctypes.c_int16)
+        L.ref_satd8x8_last_input.restype = ctypes.POINTER(ctypes.c_int16)
+        L.dct32_getDct.restype = ctypes.c_uint64
+        L.satd8x8_getSatd.restype = ctypes.c_uint32
+
+    def table(self):
+        return np.ctypeslib.as_array(self.lib.ref_dct32_table(), (32, 32)).copy()
+
+    def dct32_fwd(self, x):
+        x = np.ascontiguousarray(x, np.int16).reshape(-1, 1024)
+        out = np.empty_like(x)
+        self.lib.ref_dct32_fwd(_P(x.ctypes.data), _P(out.ctypes.data), ctypes.c_ulong(x.shape[0]))
+        return out
+
+    def dct32_pass(self, src, shift, line=32):
+        src = np.ascontiguousarray(src, np.int16)
+        dst = np.empty(32 * line, np.int16)
+        self.lib.ref_dct32_pass(_P(src.ctypes.data), _P(dst.ctypes.data), shift, line)
+        return dst
+
+    def satd8x8(self, d):
+        d = np.ascontiguousarray(d, np.int16).reshape(-1, 64)
+        out = np.empty(d.shape[0], np.uint32)
+        self.lib.ref_satd8x8_batch(_P(d.ctypes.data), _P(out.ctypes.data), ctypes.c_ulong(d.shape[0]))
+        return out
+
+
+# --------------------------------------------------------------------------
+# numpy twin of the counter-based SplitMix64 stream (oracle/prng_oracle.c and
+# the device kernel x266_fill_residual); used to make full-range test data.
+# --------------------------------------------------------------------------
+def splitmix64(seed, first_index, count):
+    with np.errstate(over="ignore"):
+        idx = np.arange(first_index + 1, first_index + 1 + count, dtype=np.uint64)
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def residual_np(n_samples, seed, first_index=0):
+    r = splitmix64(seed, first_index, n_samples)
+    return ((r & np.uint64(0xFF)).astype(np.int32) - ((r >> np.uint64(8)) & np.uint64(0xFF)).astype(np.int32)).astype(np.int16)
+
+
+def fullrange_np(n_samples, seed, first_index=0):
+    r = splitmix64(seed, first_index, n_samples)
+    return (r >> np.uint64(16)).astype(np.uint16).view(np.int16)
+
+
+def extremes_np(n_samples, seed, first_index=0):
+    r = splitmix64(seed, first_index, n_samples)
+    return np.where((r >> np.uint64(40)) & np.uint64(1), np.int16(32767), np.int16(-32768)).astype(np.int16)
+
+
+def dct_edge_blocks():
+    """Input-independent corner cases for the 32x32 transform."""
+    blocks, names = [], []
+
+    def add(name, b):
+        names.append(name)
+        blocks.append(np.asarray(b, np.int16).reshape(1024))
+
+    add("zeros", np.zeros(1024))
+    add("all_255", np.full(1024, 255))
+    add("all_m256", np.full(1024, -256))
+    add("all_32767", np.full(1024, 32767))
+    add("all_m32768", np.full(1024, -32768))
+    alt = np.where(np.arange(1024) % 2 == 0, 32767, -32768)
+    add("alt_cols_extreme", alt)
+    rows = np.where((np.arange(1024) // 32) % 2 == 0, 32767, -32768)
+    add("alt_rows_extreme", rows)
+    chk = np.where(((np.arange(1024) // 32) + np.arange(1024)) % 2 == 0, 255, -255)
+    add("checker_255", chk)
+    for pos in (0, 31, 32 * 31, 1023, 32 * 7 + 19):
+        imp = np.zeros(1024)
+        imp[pos] = 255
+        add("impulse_%d" % pos, imp)
+    ramp = (np.arange(1024) % 32) * 16 - 248
+    add("h_ramp", ramp)
+    vramp = (np.arange(1024) // 32) * 16 - 248
+    add("v_ramp", vramp)
+    asym = (np.arange(1024) % 32) * 7 - (np.arange(1024) // 32) * 3   # transpose-detecting
+    add("asymmetric", asym)
+    return np.stack(blocks), names
+
+
+def satd_edge_blocks():
+    blocks, names = [], []
+
+    def add(name, b):
+        names.append(name)
+        blocks.append(np.asarray(b, np.int16).reshape(64))
+
+    add("zeros", np.zeros(64))                     # -> 0
+    add("all_255", np.full(64, 255))               # -> 4080
+    add("all_m256", np.full(64, -256))             # -> 4096
+    add("all_32767", np.full(64, 32767))           # -> 16 (int16 wrap)
+    add("alt_extreme", np.where(np.arange(64) % 2 == 0, 32767, -32768))   # -> 16
+    add("all_m32768", np.full(64, -32768))
+    for pos in (0, 7, 56, 63, 27):
+        imp = np.zeros(64)
+        imp[pos] = -255
+        add("impulse_%d" % pos, imp)
+    add("asymmetric", (np.arange(64) % 8) * 5 - (np.arange(64) // 8) * 11)
+    return np.stack(blocks), names

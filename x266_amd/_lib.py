@@ -1,0 +1,213 @@
+"""ctypes view of libx266hip.so (include/x266hip.h).  No compute lives here."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_P = ctypes.c_void_p
+_SZ = ctypes.c_size_t
+_U64 = ctypes.c_uint64
+
+OP_DCT32_FWD, OP_DCT32_INV, OP_SATD8X8 = 0, 1, 2
+
+
+class X266Error(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libx266hip.so")
+
+
+def build_library(force=False):
+    """Compile the HIP kernels + C ABI for gfx950 in-tree (hipcc cross-compiles
+    without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "--no-print-directory"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return lib_path()
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise X266Error("libx266hip.so is not built (run `make -C x266_amd/csrc`); "
+                        "there is no Python/CPU fallback for the kernels")
+    L = ctypes.CDLL(path)
+    L.xHipVersion.restype = ctypes.c_char_p
+    L.xHipLastError.restype = ctypes.c_char_p
+    L.xHipLastError.argtypes = [_P]
+    L.xHipCodecInit.argtypes = [ctypes.POINTER(_P), ctypes.c_int]
+    L.xHipCodecFree.argtypes = [_P]
+    L.xHipCodecFree.restype = None
+    L.xHipDeviceInfo.argtypes = [_P, ctypes.c_char_p, _SZ, ctypes.POINTER(ctypes.c_int),
+                                 ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_SZ)]
+    L.xHipSetOption.argtypes = [_P, ctypes.c_char_p, ctypes.c_int]
+    L.xHipGetOption.argtypes = [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    for name in ("xDct32FwdBatchDev", "xDct32InvBatchDev", "xSatd8x8BatchDev"):
+        getattr(L, name).argtypes = [_P, _P, _P, _SZ, _P]
+    L.xFillResidualDev.argtypes = [_P, _P, _SZ, _U64, _U64, _P]
+    for name in ("xDct32FwdBatch", "xDct32InvBatch", "xSatd8x8Batch"):
+        getattr(L, name).argtypes = [_P, _P, _P, _SZ]
+    L.xHipMalloc.argtypes = [_P, ctypes.POINTER(_P), _SZ]
+    L.xHipFree.argtypes = [_P, _P]
+    L.xHipMemcpyH2D.argtypes = [_P, _P, _P, _SZ]
+    L.xHipMemcpyD2H.argtypes = [_P, _P, _P, _SZ]
+    L.xHipStreamSync.argtypes = [_P, _P]
+    L.xHipTimeKernel.argtypes = [_P, ctypes.c_int, _P, _P, _SZ, ctypes.c_int, _P,
+                                 ctypes.POINTER(ctypes.c_double)]
+    L.xDct32PackDiffRows.argtypes = [_P, ctypes.c_int, _P]
+    L.xDct32PackDiffRows.restype = None
+    L.xDct32PackDctWord.argtypes = [_P, ctypes.c_int]
+    L.xDct32PackDctWord.restype = ctypes.c_uint64
+    L.dct32_getDct.restype = ctypes.c_ulonglong
+    L.satd8x8_getSatd.restype = ctypes.c_uint
+    _lib = L
+    return L
+
+
+def pack_diff_rows(mat, first_row):
+    L = load_library()
+    mat = np.ascontiguousarray(mat, np.int16)
+    res = np.empty(32, np.uint32)
+    L.xDct32PackDiffRows(_P(mat.ctypes.data), first_row, _P(res.ctypes.data))
+    return res
+
+
+def pack_dct_word(dct, idx):
+    L = load_library()
+    dct = np.ascontiguousarray(dct, np.int16)
+    return int(L.xDct32PackDctWord(_P(dct.ctypes.data), idx))
+
+
+class DeviceBuffer:
+    """Device allocation owned through the C ABI (xHipMalloc / xHipFree)."""
+
+    def __init__(self, codec, nbytes):
+        self.codec, self.nbytes = codec, int(nbytes)
+        p = _P()
+        codec._check(codec.L.xHipMalloc(codec.ctx, ctypes.byref(p), self.nbytes), "xHipMalloc")
+        self.ptr = p.value or 0
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.codec._check(self.codec.L.xHipMemcpyH2D(self.codec.ctx, self.ptr, arr.ctypes.data, arr.nbytes),
+                          "xHipMemcpyH2D")
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype)
+        assert out.nbytes <= self.nbytes
+        self.codec._check(self.codec.L.xHipMemcpyD2H(self.codec.ctx, out.ctypes.data, self.ptr, out.nbytes),
+                          "xHipMemcpyD2H")
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.codec.L.xHipFree(self.codec.ctx, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Codec:
+    """Context object mirroring x266hip_ctx (xHipCodecInit / xHipCodecFree)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        ctx = _P()
+        rc = self.L.xHipCodecInit(ctypes.byref(ctx), int(device))
+        if rc != 0 or not ctx.value:
+            raise X266Error("xHipCodecInit(device=%d) failed with %d: no gfx950 device; "
+                            "libx266hip has no CPU path" % (device, rc))
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.xHipCodecFree(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise X266Error("%s failed (%d): %s" % (what, rc, self.L.xHipLastError(self.ctx).decode()))
+
+    # -- info / options ----------------------------------------------------
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        cu, mhz, mem = ctypes.c_int(), ctypes.c_int(), _SZ()
+        self._check(self.L.xHipDeviceInfo(self.ctx, name, 256, ctypes.byref(cu), ctypes.byref(mhz),
+                                          ctypes.byref(mem)), "xHipDeviceInfo")
+        return {"name": name.value.decode(), "cu_count": cu.value, "clock_mhz": mhz.value,
+                "hbm_bytes": mem.value}
+
+    def set_option(self, key, value):
+        self._check(self.L.xHipSetOption(self.ctx, key.encode(), int(value)), "xHipSetOption(%s)" % key)
+
+    def get_option(self, key):
+        v = ctypes.c_int()
+        self._check(self.L.xHipGetOption(self.ctx, key.encode(), ctypes.byref(v)), "xHipGetOption(%s)" % key)
+        return v.value
+
+    # -- host-pointer batch API (numpy in, numpy out) -------------------------
+    def dct32_fwd(self, x):
+        x = np.ascontiguousarray(x, np.int16).reshape(-1, 1024)
+        out = np.empty_like(x)
+        self._check(self.L.xDct32FwdBatch(self.ctx, x.ctypes.data, out.ctypes.data, x.shape[0]), "xDct32FwdBatch")
+        return out
+
+    def dct32_inv(self, z):
+        z = np.ascontiguousarray(z, np.int16).reshape(-1, 1024)
+        out = np.empty_like(z)
+        self._check(self.L.xDct32InvBatch(self.ctx, z.ctypes.data, out.ctypes.data, z.shape[0]), "xDct32InvBatch")
+        return out
+
+    def satd8x8(self, d):
+        d = np.ascontiguousarray(d, np.int16).reshape(-1, 64)
+        out = np.empty(d.shape[0], np.uint32)
+        self._check(self.L.xSatd8x8Batch(self.ctx, d.ctypes.data, out.ctypes.data, d.shape[0]), "xSatd8x8Batch")
+        return out
+
+    # -- device-pointer batch API (raw pointers, e.g. torch .data_ptr()) --------
+    def dct32_fwd_dev(self, d_in, d_out, n_blocks, stream=0):
+        self._check(self.L.xDct32FwdBatchDev(self.ctx, d_in, d_out, n_blocks, stream), "xDct32FwdBatchDev")
+
+    def dct32_inv_dev(self, d_in, d_out, n_blocks, stream=0):
+        self._check(self.L.xDct32InvBatchDev(self.ctx, d_in, d_out, n_blocks, stream), "xDct32InvBatchDev")
+
+    def satd8x8_dev(self, d_in, d_out, n_blocks, stream=0):
+        self._check(self.L.xSatd8x8BatchDev(self.ctx, d_in, d_out, n_blocks, stream), "xSatd8x8BatchDev")
+
+    def fill_residual_dev(self, d_dst, n_samples, seed, first_index=0, stream=0):
+        self._check(self.L.xFillResidualDev(self.ctx, d_dst, n_samples, seed, first_index, stream),
+                    "xFillResidualDev")
+
+    def stream_sync(self, stream=0):
+        self._check(self.L.xHipStreamSync(self.ctx, stream), "xHipStreamSync")
+
+    def time_kernel(self, op, d_in, d_out, n_blocks, reps, stream=0):
+        ms = ctypes.c_double()
+        self._check(self.L.xHipTimeKernel(self.ctx, op, d_in, d_out, n_blocks, reps, stream, ctypes.byref(ms)),
+                    "xHipTimeKernel")
+        return ms.value
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)

@@ -1,0 +1,274 @@
+// dct32_kernels.hip -- batched 32x32 integer DCT-II (forward / inverse) for
+// gfx950 (MI355X, CDNA4).  Hand-written for wave64 + v_mfma_i32_32x32x32_i8.
+//
+// Arithmetic contract (bit-exact): partialButterfly32 called twice with shifts
+// 4 and 11 (src_tb/dct32.c:66-170,180-198):
+//     Y[j][k] = (int16)((sum_n g[k][n] X[j][n] + 8)    >> 4)
+//     Z[v][k] = (int16)((sum_j g[v][j] Y[j][k] + 1024) >> 11)
+// The reference evaluates each sum with an even/odd butterfly; the dense
+// contraction is the same integer, so each 1-D pass is a 32x32x32 integer GEMM
+// against a constant matrix (the RTL already computes it as dense 16-tap MACs,
+// src/mkDct32.bsv:107-129).
+//
+// Mapping:
+//  * one 32x32 block per wavefront per iteration; lane l loads 32 contiguous
+//    bytes: row (l & 31), columns 16*(l >> 5) .. +15.
+//  * int16 data x int8 coefficients on the int8 matrix core: the data is split
+//    into byte planes, x = 256*hi + (lo ^ 0x80) + 128 (hi signed, lo offset to
+//    signed); two chained MFMAs per pass, acc = (mfma(hi) << 8) + c, then
+//    acc = mfma(lo', acc).  The "+128" becomes 128*sum_n g[k][n], folded into
+//    the per-lane constant c together with the rounding term.
+//  * no transpose between the passes: a lane's 16 pass-1 accumulators are 16
+//    rows of one column -- exactly the fragment shape of an MFMA *input*
+//    operand.  They are re-packed to bytes in registers and fed to pass 2,
+//    whose constant operand has its K-slots permuted to the accumulator row
+//    order (the contraction does not care about order).  No LDS, no shuffles,
+//    no barriers; the RTL's BRAM corner-turn (src/mkDct32.bsv:176-210,287-325,
+//    src/mkTranspose.bsv) has no counterpart here.
+//  * the lane<->frequency assignment of the constant operands is chosen so that
+//    each lane finishes with 16 consecutive coefficients of one output row:
+//    two 16-byte stores per lane, same address pattern as the loads.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "x266_device.hpp"
+#include "x266_tables.hpp"
+
+namespace x266 {
+namespace {
+
+// ---- byte-plane helpers ----------------------------------------------------
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {hi_src, lo_src}
+// (indices 0-3 = lo_src, 4-7 = hi_src).
+__device__ __forceinline__ uint32_t bperm(uint32_t hi_src, uint32_t lo_src, uint32_t sel)
+{
+    return __builtin_amdgcn_perm(hi_src, lo_src, sel);
+}
+
+// 8 dwords of int16 pairs -> 4 dwords of low bytes (offset to signed) + 4 of high bytes
+__device__ __forceinline__ void split_planes(const v4i &w0, const v4i &w1, v4i &lo, v4i &hi)
+{
+    const uint32_t w[8] = {(uint32_t)w0[0], (uint32_t)w0[1], (uint32_t)w0[2], (uint32_t)w0[3],
+                           (uint32_t)w1[0], (uint32_t)w1[1], (uint32_t)w1[2], (uint32_t)w1[3]};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        lo[p] = (int)(bperm(w[2 * p + 1], w[2 * p], 0x06040200u) ^ 0x80808080u);
+        hi[p] = (int)bperm(w[2 * p + 1], w[2 * p], 0x07050301u);
+    }
+}
+
+// 16 int32 whose bytes 0/1 hold the wanted low/high byte -> byte planes
+__device__ __forceinline__ void pack_planes(const v16i &s, v4i &lo, v4i &hi)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t t01 = bperm((uint32_t)s[4 * q + 1], (uint32_t)s[4 * q + 0], 0x05010400u);
+        const uint32_t t23 = bperm((uint32_t)s[4 * q + 3], (uint32_t)s[4 * q + 2], 0x05010400u);
+        lo[q] = (int)(bperm(t23, t01, 0x05040100u) ^ 0x80808080u);
+        hi[q] = (int)bperm(t23, t01, 0x07060302u);
+    }
+}
+
+// 16 int32 holding one signed byte value each (byte 0) -> one plane of 4 dwords
+__device__ __forceinline__ v4i pack_bytes(const v16i &s)
+{
+    v4i r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t t01 = bperm((uint32_t)s[4 * q + 1], (uint32_t)s[4 * q + 0], 0x0c0c0400u);
+        const uint32_t t23 = bperm((uint32_t)s[4 * q + 3], (uint32_t)s[4 * q + 2], 0x0c0c0400u);
+        r[q] = (int)bperm(t23, t01, 0x05040100u);
+    }
+    return r;
+}
+
+__device__ __forceinline__ v16i mfma(const v4i &a, const v4i &b, const v16i &c)
+{
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+}
+
+struct LaneConsts {
+    v4i p1, p2, tr;
+    int c1, c2;
+};
+
+__device__ __forceinline__ LaneConsts load_consts(const DctOps *ops, int lane)
+{
+    LaneConsts k;
+    const DctLaneOps *r = &ops->lane[lane];
+    k.p1 = *reinterpret_cast<const v4i *>(r->p1);
+    k.p2 = *reinterpret_cast<const v4i *>(r->p2);
+    k.tr = *reinterpret_cast<const v4i *>(r->tr);
+    k.c1 = r->c1;
+    k.c2 = r->c2;
+    return k;
+}
+
+// ---- forward: one block held as (w0, w1) -> (o0, o1) ------------------------
+__device__ __forceinline__ void fwd_block(const v4i &w0, const v4i &w1, const LaneConsts &k,
+                                          v4i &o0, v4i &o1)
+{
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v4i lo, hi;
+    split_planes(w0, w1, lo, hi);
+
+    // pass 1 (rows): data = A, coefficients = B
+    v16i acc = mfma(hi, k.p1, zero);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)k.c1);
+    acc = mfma(lo, k.p1, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc[r] >> 4;         // bytes 0/1 = int16 result
+    v4i ylo, yhi;
+    pack_planes(acc, ylo, yhi);
+
+    // pass 2 (columns): data = A (pass-1 accumulators re-packed), coefficients = B
+    acc = mfma(yhi, k.p2, zero);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)k.c2);
+    acc = mfma(ylo, k.p2, acc);
+
+    // (acc >> 11) truncated to int16, pairs packed into dwords
+    uint32_t z[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        z[m] = bperm((uint32_t)(acc[2 * m + 1] >> 11), (uint32_t)(acc[2 * m] >> 11), 0x05040100u);
+    o0 = v4i{(int)z[0], (int)z[1], (int)z[2], (int)z[3]};
+    o1 = v4i{(int)z[4], (int)z[5], (int)z[6], (int)z[7]};
+}
+
+// ---- inverse ---------------------------------------------------------------
+// T[u][y] = clip16((sum_v g[v][y] Z[v][u] + 64)   >> 7)      (columns first)
+// R[y][x] = clip16((sum_u g[u][x] T[u][y] + 2048) >> 12)
+// The first contraction runs over the ROW index of the loaded block, which a
+// row-per-lane fragment cannot feed; the block is first transposed on the
+// matrix core (data x permuted identity: Dt[v][c] = Z[v][kappa(c)]), one MFMA
+// per byte plane, whose accumulators are again input-operand shaped.
+__device__ __forceinline__ int clamp16(int v)
+{
+    return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);   // folds to v_med3_i32
+}
+
+__device__ __forceinline__ void inv_block(const v4i &w0, const v4i &w1, const LaneConsts &k,
+                                          const v16i &c2r, v4i &o0, v4i &o1)
+{
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v4i lo, hi;
+    split_planes(w0, w1, lo, hi);
+
+    // transpose both planes (values stay single bytes: no carries between planes)
+    const v16i thi = mfma(hi, k.tr, zero);
+    const v16i tlo = mfma(lo, k.tr, zero);
+    const v4i zhi = pack_bytes(thi);
+    const v4i zlo = pack_bytes(tlo);
+
+    // pass A (columns): data = A, coefficients = B, per-lane constant
+    v16i acc = mfma(zhi, k.p1, zero);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)k.c1);
+    acc = mfma(zlo, k.p1, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = clamp16(acc[r] >> 7);
+    v4i tlo2, thi2;
+    pack_planes(acc, tlo2, thi2);
+
+    // pass B (rows): coefficients = A, data = B, per-register constant
+    acc = mfma(k.p2, thi2, zero);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)c2r[r]);
+    acc = mfma(k.p2, tlo2, acc);
+
+    uint32_t z[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int a = clamp16(acc[2 * m] >> 12), b = clamp16(acc[2 * m + 1] >> 12);
+        z[m] = bperm((uint32_t)b, (uint32_t)a, 0x05040100u);
+    }
+    o0 = v4i{(int)z[0], (int)z[1], (int)z[2], (int)z[3]};
+    o1 = v4i{(int)z[4], (int)z[5], (int)z[6], (int)z[7]};
+}
+
+// ---- kernel ----------------------------------------------------------------
+// Persistent waves, grid-stride over blocks, next block's loads issued before
+// the current block's arithmetic (register double buffer).
+template <bool INVERSE, bool NT>
+__global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ in,
+                                                    int16_t *__restrict__ out, size_t n_blocks,
+                                                    const DctOps *__restrict__ ops)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    if (wave >= n_blocks) return;
+
+    const LaneConsts k = load_consts(ops, lane);
+    v16i c2r;
+    if (INVERSE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c2r[r] = ops->c2r[lane][r];
+    }
+
+    const size_t lane_off = (size_t)(lane & 31) * 64 + (size_t)(lane >> 5) * 32;   // bytes
+    const char *src = reinterpret_cast<const char *>(in) + lane_off;
+    char *dst = reinterpret_cast<char *>(out) + lane_off;
+
+    // The operand images must have landed before the loop: otherwise the
+    // compiler's in-loop wait for them is a vmcnt(0) that also drains every
+    // prefetch it was meant to leave in flight.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt/expcnt untouched
+
+    // Two register sets in ping-pong: the loads of block b + n_waves are in
+    // flight while block b is transformed.
+    size_t b = wave;
+    v4i a0 = load16<NT>(src + b * 2048), a1 = load16<NT>(src + b * 2048 + 16);
+    v4i b0 = a0, b1 = a1, o0, o1;
+    while (true) {
+        size_t nb = b + n_waves;
+        if (nb < n_blocks) {
+            b0 = load16<NT>(src + nb * 2048);
+            b1 = load16<NT>(src + nb * 2048 + 16);
+        }
+        if (INVERSE) inv_block(a0, a1, k, c2r, o0, o1);
+        else         fwd_block(a0, a1, k, o0, o1);
+        store16<NT>(dst + b * 2048, o0);
+        store16<NT>(dst + b * 2048 + 16, o1);
+        if (nb >= n_blocks) break;
+        b = nb;
+        nb = b + n_waves;
+        if (nb < n_blocks) {
+            a0 = load16<NT>(src + nb * 2048);
+            a1 = load16<NT>(src + nb * 2048 + 16);
+        }
+        if (INVERSE) inv_block(b0, b1, k, c2r, o0, o1);
+        else         fwd_block(b0, b1, k, o0, o1);
+        store16<NT>(dst + b * 2048, o0);
+        store16<NT>(dst + b * 2048 + 16, o1);
+        if (nb >= n_blocks) break;
+        b = nb;
+    }
+}
+
+}  // namespace
+
+// ---- launchers ---------------------------------------------------------------
+hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_blocks,
+                        const DctOps *d_ops, const LaunchCfg &cfg, hipStream_t stream)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const size_t waves_wanted = n_blocks;
+    size_t wgs = (waves_wanted + 3) / 4;
+    const size_t cap = (size_t)cfg.cu_count * (size_t)cfg.wgs_per_cu;
+    if (wgs > cap) wgs = cap;
+    dim3 grid((unsigned)wgs), block(256);
+    if (inverse) {
+        if (cfg.nontemporal) hipLaunchKernelGGL((dct32_kernel<true, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops);
+        else                 hipLaunchKernelGGL((dct32_kernel<true, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops);
+    } else {
+        if (cfg.nontemporal) hipLaunchKernelGGL((dct32_kernel<false, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops);
+        else                 hipLaunchKernelGGL((dct32_kernel<false, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace x266

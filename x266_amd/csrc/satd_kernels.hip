@@ -1,0 +1,181 @@
+// satd_kernels.hip -- batched 8x8 Hadamard SATD for gfx950 (MI355X, CDNA4).
+//
+// Arithmetic contract (bit-exact): satd8x8(), src_tb/satd.c:31-118 -- 8-point
+// Hadamard on rows then columns with every intermediate stored to int16
+// (wraps), sum of |coefficient|, (sum + 2) >> 2.  Only add/sub are involved, so
+// the result equals "exact integer Hadamard, keep the low 16 bits as signed,
+// then abs" (SURVEY.md section 9.3); the coefficient order is irrelevant under
+// the sum.  RTL twin: mkSatd8, src/mkSatd.bsv:83-176.
+//
+// Mapping: the 2-D Hadamard of a block is one 64x64 +-1
+// matrix applied to the block's 64 samples, so 32 blocks at a time are one
+// 64 x 64 x 32 integer GEMM on the int8 matrix core:
+//      D[m][blk] = sum_s H64[m][s] * d[blk][s]
+// with the int16 samples split into byte planes exactly as in the DCT kernel
+// (d = 256*hi + (lo ^ 0x80) + 128; the +128 only reaches the DC coefficient:
+// 128 * sum_s H[m][s] = 8192 for m = 0, 0 otherwise).  8 MFMAs per 32 blocks.
+// Lane l owns block (l & 31) and loads the contiguous 64-byte half (l >> 5) of
+// it; the two halves of a block meet inside the MFMA's K reduction.  The
+// epilogue truncates to int16 by packing, takes |.| of two int16 at once with
+// v_sad_u16 against a bias, and one cross-half add finishes the block.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "x266_device.hpp"
+#include "x266_tables.hpp"
+
+namespace x266 {
+namespace {
+
+__device__ __forceinline__ uint32_t bperm(uint32_t hi_src, uint32_t lo_src, uint32_t sel)
+{
+    return __builtin_amdgcn_perm(hi_src, lo_src, sel);
+}
+
+__device__ __forceinline__ v16i mfma(const v4i &a, const v4i &b, const v16i &c)
+{
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+}
+
+// 8 dwords of int16 pairs -> low-byte plane (offset to signed) and high-byte plane
+__device__ __forceinline__ void split_planes(const v4i &w0, const v4i &w1, v4i &lo, v4i &hi)
+{
+    const uint32_t w[8] = {(uint32_t)w0[0], (uint32_t)w0[1], (uint32_t)w0[2], (uint32_t)w0[3],
+                           (uint32_t)w1[0], (uint32_t)w1[1], (uint32_t)w1[2], (uint32_t)w1[3]};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        lo[p] = (int)(bperm(w[2 * p + 1], w[2 * p], 0x06040200u) ^ 0x80808080u);
+        hi[p] = (int)bperm(w[2 * p + 1], w[2 * p], 0x07050301u);
+    }
+}
+
+// sum over 16 accumulators of |(int16)(256*hi + lo)|
+__device__ __forceinline__ uint32_t abs_sum16(const v16i &hi, const v16i &lo, uint32_t sum)
+{
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const uint32_t a = ((uint32_t)hi[2 * m] << 8) + (uint32_t)lo[2 * m];
+        const uint32_t b = ((uint32_t)hi[2 * m + 1] << 8) + (uint32_t)lo[2 * m + 1];
+        // low halves of (a, b) side by side, biased so that unsigned |x - bias| = |int16|
+        const uint32_t pk = bperm(b, a, 0x05040100u) ^ 0x80008000u;
+        sum = __builtin_amdgcn_sad_u16(pk, 0x80008000u, sum);
+    }
+    return sum;
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict__ diff,
+                                                      uint32_t *__restrict__ out, size_t n_blocks,
+                                                      const SatdOps *__restrict__ ops)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t n_groups = (n_blocks + 31) >> 5;           // 32 blocks per wave-iteration
+    if (wave >= n_groups) return;
+
+    v4i h00 = *reinterpret_cast<const v4i *>(ops->a[0][0][lane]);
+    v4i h01 = *reinterpret_cast<const v4i *>(ops->a[0][1][lane]);
+    v4i h10 = *reinterpret_cast<const v4i *>(ops->a[1][0][lane]);
+    v4i h11 = *reinterpret_cast<const v4i *>(ops->a[1][1][lane]);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // see dct32_kernels.hip
+
+    const int blk = lane & 31, half = lane >> 5;
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // DC fix for the byte-plane offset: coefficient m = 0 lives in tile 0, reg 0, half 0
+    v16i dcfix = zero;
+    dcfix[0] = half == 0 ? 128 * 64 : 0;
+
+    for (size_t g = wave; g < n_groups; g += n_waves) {
+        size_t b = g * 32 + blk;
+        const bool live = b < n_blocks;
+        if (!live) b = n_blocks - 1;                        // ragged tail: re-read the last block
+        const char *p = reinterpret_cast<const char *>(diff) + b * 128 + (size_t)half * 64;
+        const v4i w0 = load16<NT>(p), w1 = load16<NT>(p + 16);
+        const v4i w2 = load16<NT>(p + 32), w3 = load16<NT>(p + 48);
+
+        v4i lo0, hi0, lo1, hi1;
+        split_planes(w0, w1, lo0, hi0);                     // K-step 0: samples 32*half + 0..15
+        split_planes(w2, w3, lo1, hi1);                     // K-step 1: samples 32*half + 16..31
+
+        uint32_t sum = 0;
+        {   // coefficients 0..31
+            v16i ah = mfma(h00, hi0, zero);   ah = mfma(h01, hi1, ah);
+            v16i al = mfma(h00, lo0, dcfix);  al = mfma(h01, lo1, al);
+            sum = abs_sum16(ah, al, sum);
+        }
+        {   // coefficients 32..63
+            v16i ah = mfma(h10, hi0, zero);   ah = mfma(h11, hi1, ah);
+            v16i al = mfma(h10, lo0, zero);   al = mfma(h11, lo1, al);
+            sum = abs_sum16(ah, al, sum);
+        }
+        // the other half of the coefficient rows sits in lane ^ 32
+        sum += (uint32_t)__shfl_xor((int)sum, 32);
+        if (live && half == 0) out[b] = (sum + 2) >> 2;
+    }
+}
+
+// ---- synthetic residual stream ---------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t index)
+{
+    uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void fill_residual_kernel(int16_t *__restrict__ dst, size_t n_samples,
+                                                            uint64_t seed, uint64_t first_index)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n_vec = n_samples >> 3;                    // 8 samples = 16 bytes per thread step
+    for (size_t v = tid; v < n_vec; v += stride) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t r0 = splitmix64_at(seed, first_index + v * 8 + 2 * i);
+            const uint64_t r1 = splitmix64_at(seed, first_index + v * 8 + 2 * i + 1);
+            const int s0 = (int)(r0 & 0xFF) - (int)((r0 >> 8) & 0xFF);
+            const int s1 = (int)(r1 & 0xFF) - (int)((r1 >> 8) & 0xFF);
+            w[i] = ((uint32_t)s0 & 0xFFFFu) | ((uint32_t)s1 << 16);
+        }
+        reinterpret_cast<v4i *>(dst)[v] = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    }
+    // tail (n_samples not a multiple of 8)
+    for (size_t i = (n_vec << 3) + tid; i < n_samples; i += stride) {
+        const uint64_t r = splitmix64_at(seed, first_index + i);
+        dst[i] = (int16_t)((int)(r & 0xFF) - (int)((r >> 8) & 0xFF));
+    }
+}
+
+}  // namespace
+
+hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks,
+                          const SatdOps *d_ops, const LaunchCfg &cfg, hipStream_t stream)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const size_t groups = (n_blocks + 31) / 32;
+    size_t wgs = (groups + 3) / 4;
+    const size_t cap = (size_t)cfg.cu_count * (size_t)cfg.wgs_per_cu;
+    if (wgs > cap) wgs = cap;
+    dim3 grid((unsigned)wgs), block(256);
+    if (cfg.nontemporal) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, 0, stream, d_diff, d_out, n_blocks, d_ops);
+    else                 hipLaunchKernelGGL((satd8x8_kernel<false>), grid, block, 0, stream, d_diff, d_out, n_blocks, d_ops);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_residual(int16_t *d_dst, size_t n_samples, uint64_t seed,
+                                uint64_t first_index, const LaunchCfg &cfg, hipStream_t stream)
+{
+    if (n_samples == 0) return hipSuccess;
+    size_t wgs = (n_samples / 8 + 255) / 256;
+    const size_t cap = (size_t)cfg.cu_count * 8;
+    if (wgs > cap) wgs = cap;
+    if (wgs == 0) wgs = 1;
+    hipLaunchKernelGGL(fill_residual_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, d_dst, n_samples, seed, first_index);
+    return hipGetLastError();
+}
+
+}  // namespace x266

@@ -1,0 +1,48 @@
+// x266_device.hpp -- shared device-side types and helpers (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace x266 {
+
+typedef int v4i  __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// 16-byte global accesses; NT = streaming (non-temporal) cache policy.
+template <bool NT>
+__device__ __forceinline__ v4i load16(const void *p)
+{
+    const v4i *q = reinterpret_cast<const v4i *>(p);
+    if (NT) return __builtin_nontemporal_load(q);
+    return *q;
+}
+
+template <bool NT>
+__device__ __forceinline__ void store16(void *p, const v4i &v)
+{
+    v4i *q = reinterpret_cast<v4i *>(p);
+    if (NT) __builtin_nontemporal_store(v, q);
+    else    *q = v;
+}
+
+struct LaunchCfg {
+    int cu_count;      // compute units of the device
+    int wgs_per_cu;    // resident 256-thread workgroups per CU to launch
+    int nontemporal;   // use streaming loads/stores
+    int variant;       // kernel variant (per op)
+};
+
+struct DctOps;
+struct SatdOps;
+
+hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_blocks,
+                        const DctOps *d_ops, const LaunchCfg &cfg, hipStream_t stream);
+hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks,
+                          const SatdOps *d_ops, const LaunchCfg &cfg, hipStream_t stream);
+hipError_t launch_fill_residual(int16_t *d_dst, size_t n_samples, uint64_t seed,
+                                uint64_t first_index, const LaunchCfg &cfg, hipStream_t stream);
+
+}  // namespace x266

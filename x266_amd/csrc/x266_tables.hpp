@@ -1,0 +1,166 @@
+// x266_tables.hpp -- coefficient matrix and the per-lane MFMA operand images
+// derived from it (host side, built once per context).
+//
+// Reference: const int16_t g_t32[32][32], src_tb/dct32.c:30-64 (row k =
+// frequency, column n = sample; half-table twin src/mkDct32.bsv:39-73).
+// The matrix is generated at compile time from the 32 magnitudes of its first
+// column: entry (k,n) is +/- magnitude[fold((2n+1)k mod 128)], the integer
+// cosine cos((2n+1)k*pi/64) folded into the first quadrant.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+
+namespace x266 {
+
+struct Table32 { int16_t v[32][32]; };
+
+constexpr int kMag[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                          61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
+
+constexpr int coef32(int k, int n)
+{
+    if (k == 0) return 64;
+    int a = ((2 * n + 1) * k) % 128;          // angle, units of pi/64, period 128
+    if (a > 64) a = 128 - a;                  // cos(2pi - t) = cos(t)
+    return a > 32 ? -kMag[64 - a] : kMag[a];  // cos(pi - t) = -cos(t)
+}
+
+constexpr Table32 make_table32()
+{
+    Table32 t{};
+    for (int k = 0; k < 32; ++k)
+        for (int n = 0; n < 32; ++n) t.v[k][n] = static_cast<int16_t>(coef32(k, n));
+    return t;
+}
+
+// ---------------------------------------------------------------------------
+// MFMA fragment geometry for v_mfma_i32_32x32x32_i8 (wave64):
+//   A (32 x 32, M x K):  lane l holds row  M = l & 31, 16 K-slots of half l >> 5
+//   B (32 x 32, K x N):  lane l holds col  N = l & 31, the SAME 16 K-slots
+//   D (32 x 32, M x N):  lane l holds col  N = l & 31, reg r -> row
+//                        M = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+// A and B pair K-slots positionally (byte t of half h with byte t of half h),
+// so any meaning may be given to slot (h, t) as long as both operands agree.
+// ---------------------------------------------------------------------------
+constexpr int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// Output-order permutation: lane index i of a data operand is given the index
+// kappa(i) such that a D fragment's reg r of half h lands on 16*h + r, i.e.
+// every lane ends up with 16 CONSECUTIVE outputs (32 contiguous bytes).
+constexpr int kappa(int i) { return ((i >> 2) & 1) * 16 + (i >> 3) * 4 + (i & 3); }
+
+// One 64-byte record per lane; device code loads it once per wave.
+struct DctLaneOps {
+    uint32_t p1[4];     // constant operand of pass 1 (16 int8)
+    uint32_t p2[4];     // constant operand of pass 2 (16 int8)
+    uint32_t tr[4];     // inverse only: permuted identity for the MFMA transpose
+    int32_t  c1;        // pass-1 accumulator constant: rounding + byte-plane offset fix
+    int32_t  c2;        // pass-2 accumulator constant (forward: per lane)
+    int32_t  pad[2];
+};
+
+struct DctOps {
+    DctLaneOps lane[64];
+    int32_t    c2r[64][16];   // inverse pass-2 constants, per lane and accumulator reg
+};
+
+inline uint32_t pack4(const int8_t *b)
+{
+    uint32_t w;
+    std::memcpy(&w, b, 4);
+    return w;
+}
+
+// Forward transform operand images.
+//   pass 1:  D1[j][c]  = sum_n X[j][n] * g[kappa(c)][n]        data = A, const = B
+//            slot (h,t) <-> n = 16h + t
+//   pass 2:  D2[i][c]  = sum_j Y[j][kappa(i)] * g[c][j]        data = A, const = B
+//            slot (h,t) <-> j = acc_row(t, h)   (the rows a pass-1 lane holds)
+// The low byte plane is fed as (byte ^ 0x80) = byte - 128, so every sum misses
+// 128 * sum_n g[k][n], which is 128*2048 for k = 0 and 0 otherwise.
+inline void build_fwd_ops(DctOps &o)
+{
+    constexpr Table32 g = make_table32();
+    for (int l = 0; l < 64; ++l) {
+        const int c = l & 31, h = l >> 5;
+        int8_t b1[16], b2[16];
+        for (int t = 0; t < 16; ++t) {
+            b1[t] = static_cast<int8_t>(g.v[kappa(c)][16 * h + t]);
+            b2[t] = static_cast<int8_t>(g.v[c][acc_row(t, h)]);
+        }
+        for (int q = 0; q < 4; ++q) {
+            o.lane[l].p1[q] = pack4(b1 + 4 * q);
+            o.lane[l].p2[q] = pack4(b2 + 4 * q);
+            o.lane[l].tr[q] = 0;
+        }
+        o.lane[l].c1 = (1 << 3)  + (kappa(c) == 0 ? 128 * 2048 : 0);
+        o.lane[l].c2 = (1 << 10) + (c == 0 ? 128 * 2048 : 0);
+        o.lane[l].pad[0] = o.lane[l].pad[1] = 0;
+        for (int r = 0; r < 16; ++r) o.c2r[l][r] = o.lane[l].c2;
+    }
+}
+
+// Inverse transform operand images.
+//   transpose: Dt[v][c] = sum_u Z[v][u] * [u == kappa(c)]       data = A, const = B
+//              slot (h,t) <-> u = 16h + t
+//   pass A:    Da[i][y] = sum_v Zt[v][kappa(i)] * g[v][y]       data = A, const = B
+//              slot (h,t) <-> v = acc_row(t, h); per-lane constant (depends on y)
+//   pass B:    Db[i][y] = sum_u g[u][kappa(i)] * T[u][y]        const = A, data = B
+//              slot (h,t) <-> u = 16h + t; constant depends on x = 16h + r
+// Offset fix: 128 * sum_k g[k][n] (a COLUMN sum here, non-zero for every n).
+inline void build_inv_ops(DctOps &o)
+{
+    constexpr Table32 g = make_table32();
+    int colsum[32] = {};
+    for (int n = 0; n < 32; ++n)
+        for (int k = 0; k < 32; ++k) colsum[n] += g.v[k][n];
+    for (int l = 0; l < 64; ++l) {
+        const int c = l & 31, h = l >> 5;
+        int8_t ba[16], ab[16], id[16];
+        for (int t = 0; t < 16; ++t) {
+            ba[t] = static_cast<int8_t>(g.v[acc_row(t, h)][c]);        // pass A: g[v][y=c]
+            ab[t] = static_cast<int8_t>(g.v[16 * h + t][kappa(c)]);    // pass B: g[u][x=kappa(c)]
+            id[t] = static_cast<int8_t>((16 * h + t) == kappa(c) ? 1 : 0);
+        }
+        for (int q = 0; q < 4; ++q) {
+            o.lane[l].p1[q] = pack4(ba + 4 * q);
+            o.lane[l].p2[q] = pack4(ab + 4 * q);
+            o.lane[l].tr[q] = pack4(id + 4 * q);
+        }
+        o.lane[l].c1 = (1 << 6) + 128 * colsum[c];
+        o.lane[l].c2 = 0;
+        o.lane[l].pad[0] = o.lane[l].pad[1] = 0;
+        for (int r = 0; r < 16; ++r) o.c2r[l][r] = (1 << 11) + 128 * colsum[16 * h + r];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// SATD: 64 x 64 natural-order Hadamard, H[m][s] = (-1)^popcount(m & s), with
+// s = 8*row + col, which equals H8 (x) H8 applied to the 8x8 block.  The
+// reference's butterfly order (src_tb/satd.c:38-103) yields the same
+// coefficients in another order and the cost sums |.| over all of them.
+// Operand images for D[m][blk] = sum_s H[m][s] * d[blk][s]:
+//   const = A (M = coefficient m, two 32-row tiles), data = B (N = block).
+//   K-step st, slot (h,t) <-> s = 32h + 16st + t
+// ---------------------------------------------------------------------------
+struct SatdOps {
+    uint32_t a[2][2][64][4];     // [tile][kstep][lane][4 dwords]
+};
+
+inline void build_satd_ops(SatdOps &o)
+{
+    for (int tile = 0; tile < 2; ++tile)
+        for (int st = 0; st < 2; ++st)
+            for (int l = 0; l < 64; ++l) {
+                const int m = 32 * tile + (l & 31), h = l >> 5;
+                int8_t b[16];
+                for (int t = 0; t < 16; ++t) {
+                    const int s = 32 * h + 16 * st + t;
+                    b[t] = static_cast<int8_t>((__builtin_popcount(m & s) & 1) ? -1 : 1);
+                }
+                for (int q = 0; q < 4; ++q) o.a[tile][st][l][q] = pack4(b + 4 * q);
+            }
+}
+
+}  // namespace x266

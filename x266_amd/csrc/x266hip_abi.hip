@@ -1,0 +1,375 @@
+// x266hip_abi.hip -- host side of libx266hip.so: context, batch entry points,
+// device-memory helpers and kernel timing behind the C ABI of include/x266hip.h.
+//
+// Conventions follow src/x266.cpp (xCodecInit/xCodecFree :494-524: context
+// struct first, caller-owned buffers, int 0 / negative returns, no exceptions
+// across the boundary).  There is deliberately NO CPU fallback: every compute
+// entry point needs a gfx950 device and fails loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/x266hip.h"
+#include "x266_device.hpp"
+#include "x266_tables.hpp"
+
+using namespace x266;
+
+struct x266hip_ctx {
+    int device = 0;
+    hipDeviceProp_t prop{};
+    DctOps *d_fwd = nullptr;
+    DctOps *d_inv = nullptr;
+    SatdOps *d_satd = nullptr;
+    // options
+    int wgs_per_cu_dct = 8;
+    int wgs_per_cu_inv = 5;
+    int wgs_per_cu_satd = 8;
+    int nontemporal = 1;
+    int dct_variant = 0;
+    int satd_variant = 0;
+    // host-pointer staging (lazily allocated)
+    static constexpr int kSlots = 2;
+    void *d_stage_in[kSlots] = {nullptr, nullptr};
+    void *d_stage_out[kSlots] = {nullptr, nullptr};
+    size_t stage_in_bytes = 0, stage_out_bytes = 0;
+    hipStream_t stage_stream[kSlots] = {nullptr, nullptr};
+    std::string err;
+};
+
+namespace {
+
+int fail(x266hip_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) {
+            ctx->err += ": ";
+            ctx->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define X_HIP(ctx, call)                                                     \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return fail((ctx), X266HIP_EDEVICE, #call, e_); \
+    } while (0)
+
+LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
+{
+    LaunchCfg c;
+    c.cu_count = ctx->prop.multiProcessorCount;
+    c.wgs_per_cu = op == 0 ? ctx->wgs_per_cu_dct : (op == 1 ? ctx->wgs_per_cu_inv : ctx->wgs_per_cu_satd);
+    c.nontemporal = ctx->nontemporal;
+    c.variant = op == 2 ? ctx->satd_variant : ctx->dct_variant;
+    return c;
+}
+
+int launch_op(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n, hipStream_t s)
+{
+    hipError_t e;
+    switch (op) {
+    case 0: e = launch_dct32(false, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_fwd, cfg_for(ctx, 0), s); break;
+    case 1: e = launch_dct32(true, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_inv, cfg_for(ctx, 1), s); break;
+    case 2: e = launch_satd8x8((const int16_t *)d_in, (uint32_t *)d_out, n, ctx->d_satd, cfg_for(ctx, 2), s); break;
+    default: return fail(ctx, X266HIP_EINVAL, "unknown op");
+    }
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "kernel launch", e);
+    return X266HIP_OK;
+}
+
+bool bad_ptrs(const void *a, const void *b, size_t n)
+{
+    if (n == 0) return false;
+    if (!a || !b) return true;
+    return (((uintptr_t)a | (uintptr_t)b) & 15u) != 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *xHipVersion(void) { return "x266hip 0.1 (gfx950)"; }
+
+int xHipCodecInit(x266hip_ctx **out, int device_id)
+{
+    if (!out) return X266HIP_EINVAL;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        std::fprintf(stderr, "x266hip: no HIP device available (this library has no CPU path)\n");
+        return X266HIP_EDEVICE;
+    }
+    if (device_id < 0 || device_id >= n_dev) return X266HIP_EINVAL;
+    x266hip_ctx *ctx = new (std::nothrow) x266hip_ctx;
+    if (!ctx) return X266HIP_ENOMEM;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess) {
+        delete ctx;
+        return X266HIP_EDEVICE;
+    }
+    if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "x266hip: device %d is %s; the kernels are built for gfx950 only\n", device_id,
+                     ctx->prop.gcnArchName);
+        delete ctx;
+        return X266HIP_EDEVICE;
+    }
+    DctOps *h = new (std::nothrow) DctOps;
+    SatdOps *hs = new (std::nothrow) SatdOps;
+    bool ok = h && hs;
+    if (ok) ok = hipMalloc((void **)&ctx->d_fwd, sizeof(DctOps)) == hipSuccess &&
+                 hipMalloc((void **)&ctx->d_inv, sizeof(DctOps)) == hipSuccess &&
+                 hipMalloc((void **)&ctx->d_satd, sizeof(SatdOps)) == hipSuccess;
+    if (ok) {
+        build_fwd_ops(*h);
+        ok = hipMemcpy(ctx->d_fwd, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (ok) {
+        build_inv_ops(*h);
+        ok = hipMemcpy(ctx->d_inv, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (ok) {
+        build_satd_ops(*hs);
+        ok = hipMemcpy(ctx->d_satd, hs, sizeof(SatdOps), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    delete h;
+    delete hs;
+    if (!ok) {
+        xHipCodecFree(ctx);
+        return X266HIP_ENOMEM;
+    }
+    *out = ctx;
+    return X266HIP_OK;
+}
+
+void xHipCodecFree(x266hip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < x266hip_ctx::kSlots; ++i) {
+        if (ctx->d_stage_in[i]) (void)hipFree(ctx->d_stage_in[i]);
+        if (ctx->d_stage_out[i]) (void)hipFree(ctx->d_stage_out[i]);
+        if (ctx->stage_stream[i]) (void)hipStreamDestroy(ctx->stage_stream[i]);
+    }
+    if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
+    if (ctx->d_inv) (void)hipFree(ctx->d_inv);
+    if (ctx->d_satd) (void)hipFree(ctx->d_satd);
+    delete ctx;
+}
+
+const char *xHipLastError(const x266hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap, int *cu_count, int *clock_mhz,
+                   size_t *hbm_bytes)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (name && name_cap) {
+        std::snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    }
+    if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = ctx->prop.clockRate / 1000;
+    if (hbm_bytes) *hbm_bytes = ctx->prop.totalGlobalMem;
+    return X266HIP_OK;
+}
+
+static int *option_slot(x266hip_ctx *ctx, const char *key)
+{
+    if (!ctx || !key) return nullptr;
+    if (!std::strcmp(key, "dct32_wgs_per_cu")) return &ctx->wgs_per_cu_dct;
+    if (!std::strcmp(key, "dct32_inv_wgs_per_cu")) return &ctx->wgs_per_cu_inv;
+    if (!std::strcmp(key, "satd_wgs_per_cu")) return &ctx->wgs_per_cu_satd;
+    if (!std::strcmp(key, "nontemporal")) return &ctx->nontemporal;
+    if (!std::strcmp(key, "dct32_variant")) return &ctx->dct_variant;
+    if (!std::strcmp(key, "satd_variant")) return &ctx->satd_variant;
+    return nullptr;
+}
+
+int xHipSetOption(x266hip_ctx *ctx, const char *key, int value)
+{
+    int *slot = option_slot(ctx, key);
+    if (!slot) return X266HIP_EINVAL;
+    if (std::strstr(key, "wgs_per_cu") && (value < 1 || value > 64)) return fail(ctx, X266HIP_EINVAL, "wgs_per_cu out of range");
+    *slot = value;
+    return X266HIP_OK;
+}
+
+int xHipGetOption(const x266hip_ctx *ctx, const char *key, int *value)
+{
+    int *slot = option_slot(const_cast<x266hip_ctx *>(ctx), key);
+    if (!slot || !value) return X266HIP_EINVAL;
+    *value = *slot;
+    return X266HIP_OK;
+}
+
+// ---- device-pointer batch API ------------------------------------------------
+int xDct32FwdBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out, size_t n, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xDct32FwdBatchDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_op(ctx, 0, d_in, d_out, n, (hipStream_t)stream);
+}
+
+int xDct32InvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out, size_t n, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xDct32InvBatchDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_op(ctx, 1, d_in, d_out, n, (hipStream_t)stream);
+}
+
+int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out, size_t n, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (n && (!d_diff || !d_out || ((uintptr_t)d_diff & 15u) || ((uintptr_t)d_out & 3u)))
+        return fail(ctx, X266HIP_EINVAL, "xSatd8x8BatchDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_op(ctx, 2, d_diff, d_out, n, (hipStream_t)stream);
+}
+
+int xFillResidualDev(x266hip_ctx *ctx, int16_t *d_dst, size_t n_samples, uint64_t seed, uint64_t first_index,
+                     void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (n_samples && (!d_dst || ((uintptr_t)d_dst & 15u)))
+        return fail(ctx, X266HIP_EINVAL, "xFillResidualDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_fill_residual(d_dst, n_samples, seed, first_index, cfg_for(ctx, 0), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fill launch", e);
+    return X266HIP_OK;
+}
+
+// ---- host-pointer batch API --------------------------------------------------
+// Chunks of the batch alternate between two staging slots, each with its own
+// stream: H2D(i+1) and D2H(i-1) overlap kernel(i).
+static int ensure_staging(x266hip_ctx *ctx, size_t in_bytes, size_t out_bytes)
+{
+    for (int i = 0; i < x266hip_ctx::kSlots; ++i)
+        if (!ctx->stage_stream[i]) X_HIP(ctx, hipStreamCreateWithFlags(&ctx->stage_stream[i], hipStreamNonBlocking));
+    if (in_bytes > ctx->stage_in_bytes) {
+        for (int i = 0; i < x266hip_ctx::kSlots; ++i) {
+            if (ctx->d_stage_in[i]) (void)hipFree(ctx->d_stage_in[i]);
+            ctx->d_stage_in[i] = nullptr;
+            if (hipMalloc(&ctx->d_stage_in[i], in_bytes) != hipSuccess) { ctx->stage_in_bytes = 0; return fail(ctx, X266HIP_ENOMEM, "staging alloc"); }
+        }
+        ctx->stage_in_bytes = in_bytes;
+    }
+    if (out_bytes > ctx->stage_out_bytes) {
+        for (int i = 0; i < x266hip_ctx::kSlots; ++i) {
+            if (ctx->d_stage_out[i]) (void)hipFree(ctx->d_stage_out[i]);
+            ctx->d_stage_out[i] = nullptr;
+            if (hipMalloc(&ctx->d_stage_out[i], out_bytes) != hipSuccess) { ctx->stage_out_bytes = 0; return fail(ctx, X266HIP_ENOMEM, "staging alloc"); }
+        }
+        ctx->stage_out_bytes = out_bytes;
+    }
+    return X266HIP_OK;
+}
+
+static int host_batch(x266hip_ctx *ctx, int op, const void *in, void *out, size_t n, size_t in_unit, size_t out_unit)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (n == 0) return X266HIP_OK;
+    if (!in || !out) return fail(ctx, X266HIP_EINVAL, "NULL host buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t chunk_bytes = (size_t)32 << 20;                       // 32 MiB of input per chunk
+    size_t chunk = chunk_bytes / in_unit;
+    if (chunk > n) chunk = n;
+    int rc = ensure_staging(ctx, chunk * in_unit, chunk * out_unit);
+    if (rc) return rc;
+    size_t done = 0;
+    int slot = 0;
+    while (done < n) {
+        const size_t cnt = (n - done < chunk) ? n - done : chunk;
+        hipStream_t s = ctx->stage_stream[slot];
+        X_HIP(ctx, hipStreamSynchronize(s));                           // slot's previous chunk fully drained
+        X_HIP(ctx, hipMemcpyAsync(ctx->d_stage_in[slot], (const char *)in + done * in_unit, cnt * in_unit, hipMemcpyHostToDevice, s));
+        rc = launch_op(ctx, op, ctx->d_stage_in[slot], ctx->d_stage_out[slot], cnt, s);
+        if (rc) return rc;
+        X_HIP(ctx, hipMemcpyAsync((char *)out + done * out_unit, ctx->d_stage_out[slot], cnt * out_unit, hipMemcpyDeviceToHost, s));
+        done += cnt;
+        slot ^= 1;
+    }
+    for (int i = 0; i < x266hip_ctx::kSlots; ++i) X_HIP(ctx, hipStreamSynchronize(ctx->stage_stream[i]));
+    return X266HIP_OK;
+}
+
+int xDct32FwdBatch(x266hip_ctx *ctx, const int16_t *in, int16_t *out, size_t n) { return host_batch(ctx, 0, in, out, n, 2048, 2048); }
+int xDct32InvBatch(x266hip_ctx *ctx, const int16_t *in, int16_t *out, size_t n) { return host_batch(ctx, 1, in, out, n, 2048, 2048); }
+int xSatd8x8Batch(x266hip_ctx *ctx, const int16_t *diff, uint32_t *out, size_t n) { return host_batch(ctx, 2, diff, out, n, 128, 4); }
+
+// ---- memory / stream helpers ---------------------------------------------------
+int xHipMalloc(x266hip_ctx *ctx, void **d_ptr, size_t bytes)
+{
+    if (!ctx || !d_ptr) return X266HIP_EINVAL;
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    *d_ptr = nullptr;
+    if (bytes == 0) return X266HIP_OK;
+    hipError_t e = hipMalloc(d_ptr, bytes);
+    if (e != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "hipMalloc", e);
+    return X266HIP_OK;
+}
+
+int xHipFree(x266hip_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (!d_ptr) return X266HIP_OK;
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_HIP(ctx, hipFree(d_ptr));
+    return X266HIP_OK;
+}
+
+int xHipMemcpyH2D(x266hip_ctx *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    if (!ctx || (bytes && (!d_dst || !src))) return X266HIP_EINVAL;
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_HIP(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return X266HIP_OK;
+}
+
+int xHipMemcpyD2H(x266hip_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !d_src))) return X266HIP_EINVAL;
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_HIP(ctx, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return X266HIP_OK;
+}
+
+int xHipStreamSync(x266hip_ctx *ctx, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return X266HIP_OK;
+}
+
+int xHipTimeKernel(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n, int reps, void *stream,
+                   double *ms_per_launch)
+{
+    if (!ctx || !ms_per_launch || reps < 1) return X266HIP_EINVAL;
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    X_HIP(ctx, hipEventCreate(&e0));
+    X_HIP(ctx, hipEventCreate(&e1));
+    int rc = X266HIP_OK;
+    hipError_t e = hipEventRecord(e0, s);
+    for (int i = 0; i < reps && rc == X266HIP_OK && e == hipSuccess; ++i) rc = launch_op(ctx, op, d_in, d_out, n, s);
+    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "event timing", e);
+    *ms_per_launch = (double)ms / reps;
+    return X266HIP_OK;
+}
+
+}  // extern "C"
