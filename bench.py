@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the x266 DCT32 / SATD hot path on MI355X.
+
+Contract (one JSON line on stdout from rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload = BASELINE.json configs[1]: 1,048,576 synthetic 9-bit residual blocks of
+32x32 int16 per GPU, resident in HBM before the timed region (values a-b, a,b
+uniform bytes -- the reference's stimulus distribution, src_tb/dct32.c:191-193 --
+from SplitMix64 seed 0x266).  A "step" is one forward 2-D DCT32 pass over the
+batch (xDct32FwdBatchDev through the C ABI).  `value` is whole-job forward
+blocks/s over all ranks; the inverse transform and the 8x8 SATD residual batch
+(2^24 blocks, seed 0x267) are measured the same way and reported under "also".
+
+Independent blocks shard across ranks with no data-path collective (weak
+scaling: every rank owns its own 1 Mi-block slice of the one seeded stream);
+torch.distributed (RCCL) carries only the barrier, the max-over-ranks time and a
+checksum reduction.
+
+"roofline": algorithmic bytes per launch (4096 B per DCT block, 132 B per SATD
+block) / mean kernel duration measured with HIP events on
+the launching stream, against the 8 TB/s HBM3E peak.
+"cpu_baseline": the reference C path on this node's host cores (oracle/_ref =
+the real src_tb/dct32.c when its prebuilt .so is present, else the oracle's
+restatement), bounded sample, rank 0 at N = 1 only.  The oracle is used here and
+nowhere in the product.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_BYTES_PER_S = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+DCT_BLOCKS_PER_GPU = 1 << 20           # BASELINE configs[1]
+SATD_BLOCKS_PER_GPU = 1 << 24          # 2 GiB of 8x8 residual blocks
+DCT_BYTES_PER_BLOCK = 4096             # 2048 read + 2048 written   
+SATD_BYTES_PER_BLOCK = 132             # 128 read + 4 written
+DCT_SEED, SATD_SEED = 0x266, 0x267
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dct-blocks", type=int, default=DCT_BLOCKS_PER_GPU)
+    ap.add_argument("--satd-blocks", type=int, default=SATD_BLOCKS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the inverse / SATD legs")
+    return ap.parse_args()
+
+
+def cpu_baseline_dct(x_host, gpu_out_host):
+    """Reference C path timed on the host cores (rank 0, N = 1).  Returns the
+    cpu_baseline object; also checks the GPU output against it bit-for-bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _util import Oracle, Reference, ref_path
+
+    orc = Oracle()
+    cores = orc.hw_threads()
+    n = x_host.shape[0]
+    # single thread, small sample
+    n1 = min(n, 16384)
+    t = time.perf_counter()
+    orc.dct32_fwd(x_host[:n1], threads=1)
+    single = n1 / (time.perf_counter() - t)
+
+    have_ref = os.path.exists(ref_path())
+    out = np.empty_like(x_host)
+    if have_ref:
+        ref = Reference()
+        bounds = np.linspace(0, n, cores + 1).astype(np.int64)
+
+        def work(i):
+            b, e = int(bounds[i]), int(bounds[i + 1])
+            if e > b:
+                ref.lib.ref_dct32_fwd(ctypes.c_void_p(x_host[b:e].ctypes.data), ctypes.c_void_p(out[b:e].ctypes.data),
+                                      ctypes.c_ulong(e - b))
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+        t = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dt = time.perf_counter() - t
+        kind = "reference"
+    else:
+        t = time.perf_counter()
+        out = orc.dct32_fwd(x_host, threads=cores)
+        dt = time.perf_counter() - t
+        kind = "port"
+    exact = bool(np.array_equal(out, gpu_out_host))
+    return {
+        "value": n / dt, "unit": "blocks/s", "cores": cores, "kind": kind,
+        "sample": "%d of the %d blocks of the GPU batch (same inputs), one contiguous shard per thread, -O2" % (n, n),
+        "single_thread_blocks_per_s": single,
+        "gpu_output_bit_exact_vs_cpu": exact,
+    }, exact
+
+
+def main():
+    args = parse_args()
+    import torch
+    import x266_amd
+    from x266_amd._lib import OP_DCT32_FWD, OP_DCT32_INV, OP_SATD8X8
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libx266hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    codec = x266_amd.Codec(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream           # the stream every launch and event uses
+    n_dct, n_satd = args.dct_blocks, args.satd_blocks
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- inputs resident in HBM: this rank's slice of the one seeded stream -----------------
+    x = torch.empty(n_dct * 1024, dtype=torch.int16, device="cuda")
+    z = torch.empty_like(x)
+    codec.fill_residual_dev(x.data_ptr(), n_dct * 1024, DCT_SEED, rank * n_dct * 1024, stream)
+    torch.cuda.synchronize()
+
+    def run_leg(op, fn, d_in, d_out, n_units, steps, warmup):
+        for _ in range(warmup):
+            fn(d_in, d_out, n_units, stream)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn(d_in, d_out, n_units, stream)
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        # per-launch kernel duration: HIP events recorded on the launching stream itself
+        kernel_ms = codec.time_kernel(op, d_in, d_out, n_units, steps, stream)
+        return wall, kernel_ms
+
+    wall, k_ms = run_leg(OP_DCT32_FWD, codec.dct32_fwd_dev, x.data_ptr(), z.data_ptr(), n_dct, args.steps, args.warmup)
+    value = world * n_dct * args.steps / wall
+
+    def roofline(bytes_per_unit, n_units, kernel_ms, traffic=None):
+        achieved = bytes_per_unit * n_units / (kernel_ms * 1e-3)
+        return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": traffic,
+                "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_unit * n_units}
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch, if collected
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("dct32_fwd_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "dct32_fwd_blocks_per_s", "value": value, "unit": "blocks/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: batched 32x32 forward DCT, %d random 9-bit residual blocks per GPU "
+                               "resident in HBM (inverse + 8x8 SATD legs under 'also')" % n_dct,
+                   "blocks_per_gpu": n_dct, "block_bytes_in_plus_out": DCT_BYTES_PER_BLOCK,
+                   "arithmetic": "int16 data as two int8 planes x int8 coefficients on v_mfma_i32_32x32x32_i8, int32 accumulate",
+                   "sharding": "contiguous shard per rank, no data-path collective"},
+        "roofline": roofline(DCT_BYTES_PER_BLOCK, n_dct, k_ms, traffic),
+    }
+
+    # ---- checksum of the forward output across ranks (validates the sharded run) ----------------
+    csum = int(z.view(torch.int16).to(torch.int64).sum().item())
+    if dist is not None:
+        t = torch.tensor([csum], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        csum = int(t.item())
+    result["output_checksum_sum_i16"] = csum
+
+    # ---- also: inverse DCT32 and SATD residual batch ---------------------------------------------
+    if not args.no_also:
+        also = {}
+        r = torch.empty_like(x)
+        wall_i, k_ms_i = run_leg(OP_DCT32_INV, codec.dct32_inv_dev, z.data_ptr(), r.data_ptr(), n_dct, args.steps, args.warmup)
+        also["dct32_inv"] = {"value": world * n_dct * args.steps / wall_i, "unit": "blocks/s",
+                             "ms_per_step": wall_i / args.steps * 1e3,
+                             "roofline": roofline(DCT_BYTES_PER_BLOCK, n_dct, k_ms_i),
+                             "parity": "unpinned (no inverse in the reference); bit-exact vs this repo's oracle"}
+        err = (r[: 4096 * 1024].to(torch.int32) - x[: 4096 * 1024].to(torch.int32)).abs().max().item()
+        also["dct32_inv"]["roundtrip_max_abs_err"] = int(err)
+        del r
+        d = torch.empty(n_satd * 64, dtype=torch.int16, device="cuda")
+        s = torch.empty(n_satd, dtype=torch.int32, device="cuda")
+        codec.fill_residual_dev(d.data_ptr(), n_satd * 64, SATD_SEED, rank * n_satd * 64, stream)
+        wall_s, k_ms_s = run_leg(OP_SATD8X8, codec.satd8x8_dev, d.data_ptr(), s.data_ptr(), n_satd, args.steps, args.warmup)
+        also["satd8x8"] = {"value": world * n_satd * args.steps / wall_s, "unit": "blocks/s",
+                           "ms_per_step": wall_s / args.steps * 1e3, "blocks_per_gpu": n_satd,
+                           "roofline": roofline(SATD_BYTES_PER_BLOCK, n_satd, k_ms_s)}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from _util import Oracle
+            orc = Oracle()
+            ns = min(n_satd, 1 << 22)
+            dh = d[: ns * 64].cpu().numpy()
+            t0 = time.perf_counter()
+            ref_s = orc.satd8x8(dh, threads=orc.hw_threads())
+            dt = time.perf_counter() - t0
+            also["satd8x8"]["cpu_baseline"] = {
+                "value": ns / dt, "unit": "blocks/s", "cores": orc.hw_threads(), "kind": "port",
+                "sample": "first %d blocks of the GPU batch" % ns,
+                "gpu_output_bit_exact_vs_cpu": bool(np.array_equal(ref_s.astype(np.int32), s[:ns].cpu().numpy()))}
+        del d, s
+        result["also"] = also
+
+    # ---- CPU baseline for the headline leg (rank 0, N = 1 only) ------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, exact = cpu_baseline_dct(x.cpu().numpy().reshape(n_dct, 1024), z.cpu().numpy().reshape(n_dct, 1024))
+        result["cpu_baseline"] = base
+        if not exact:
+            result["error"] = "GPU output differs from the CPU reference"
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        info = codec.device_info()
+        result["device"] = info["name"].strip()
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

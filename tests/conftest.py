@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from _util import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    """The real reference golden models (oracle/_ref); absent outside the build
+    container unless the prebuilt .so travelled with the snapshot."""
+    from _util import Reference, ref_path
+    if not os.path.exists(ref_path()):
+        pytest.skip("oracle/_ref/libx266ref.so not built (needs /root/reference)")
+    return Reference()
+
+
+@pytest.fixture(scope="session")
+def codec():
+    """GPU context through the C ABI.  No fallback: a missing library or device
+    is a hard failure for -m gpu tests."""
+    import x266_amd
+    return x266_amd.Codec(0)

@@ -1,0 +1,80 @@
+"""CPU: the C-ABI library builds for gfx950 without a GPU, loads, exports every
+symbol include/x266hip.h declares, and its host-only entry points behave.  No
+kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import x266_amd
+from _util import GOLDEN_DIR, ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    x266_amd.build_library()
+    return x266_amd.load_library()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "x266hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)
+    skip = {"defined", "if"}
+    return sorted({n for n in names if n not in skip and not n.startswith("X266HIP_")})
+
+
+def test_header_symbols_exported(lib):
+    names = _declared_symbols()
+    for required in ("dct32_genNew", "dct32_getDiff", "dct32_getDct", "satd8x8_genNew", "satd8x8_getDiff",
+                     "satd8x8_getSatd", "xDct32FwdBatchDev", "xDct32InvBatchDev", "xSatd8x8BatchDev",
+                     "xDct32FwdBatch", "xSatd8x8Batch", "xHipCodecInit", "xHipCodecFree"):
+        assert required in names
+    for n in names:
+        assert hasattr(lib, n), "include/x266hip.h declares %s but libx266hip.so does not export it" % n
+    assert ctypes.c_int16.in_dll(lib, "g_t32") is not None
+
+
+def test_exported_table_is_the_reference_matrix(lib, oracle):
+    tab = np.ctypeslib.as_array((ctypes.c_int16 * 1024).in_dll(lib, "g_t32")).reshape(32, 32)
+    assert np.array_equal(tab, oracle.table())
+
+
+def test_pack_helpers_match_reference_sequence(lib, oracle):
+    g = np.load(os.path.join(GOLDEN_DIR, "bdpi_dct32.npz"))
+    for b in range(g["blocks"].shape[0]):
+        for i in range(16):
+            assert np.array_equal(x266_amd.pack_diff_rows(g["blocks"][b], 2 * i), g["diff_words"][b, i])
+        got = [x266_amd.pack_dct_word(g["dcts"][b], 4 * i) for i in range(256)]
+        assert got == [int(w) for w in g["dct_words"][b]]
+        assert got[7] == oracle.pack_dct_word(g["dcts"][b], 28)
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU the context cannot be created and nothing computes."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the -m gpu tests")
+    with pytest.raises(x266_amd.X266Error):
+        x266_amd.Codec(0)
+    ctx = ctypes.c_void_p()
+    assert lib.xHipCodecInit(ctypes.byref(ctx), 0) < 0 and not ctx.value
+    # NULL context is rejected, not dereferenced
+    assert lib.xDct32FwdBatchDev(None, None, None, 4, None) < 0
+    assert lib.xSatd8x8Batch(None, None, None, 4) < 0
+
+
+def test_product_does_not_link_the_oracle():
+    """The shipped library must not reference anything under oracle/."""
+    import subprocess
+    out = subprocess.check_output(["ldd", x266_amd.lib_path()]).decode()
+    assert "liborc" not in out and "x266ref" not in out
+    syms = subprocess.check_output(["nm", "-D", x266_amd.lib_path()]).decode()
+    assert "orc_" not in syms and "partialButterfly" not in syms
+    for root, _, files in os.walk(os.path.join(ROOT, "x266_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert "liborc" not in text and "oracle/" not in text.replace("oracle/ ", ""), f

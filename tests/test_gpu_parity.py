@@ -1,0 +1,257 @@
+"""GPU (-m gpu): parity of the HIP path against the oracle and the golden
+vectors, always THROUGH the C ABI of libx266hip.so (host-pointer and
+device-pointer entry points, and the six BDPI symbols).  Bit-exact: integer work,
+no tolerance anywhere."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from _util import (GOLDEN_DIR, ROOT, dct_edge_blocks, extremes_np, fullrange_np, residual_np,
+                   satd_edge_blocks)
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name))
+
+
+def _mixed(n_each, unit, seed):
+    return np.concatenate([
+        residual_np(n_each * unit, seed).reshape(n_each, unit),
+        fullrange_np(n_each * unit, seed + 1).reshape(n_each, unit),
+        extremes_np(n_each * unit, seed + 2).reshape(n_each, unit)])
+
+
+# ---------------------------------------------------------------- DCT32 forward
+def test_native_library_is_loaded(codec):
+    """The kernels under test live in the in-tree libx266hip.so, nowhere else."""
+    maps = open("/proc/self/maps").read()
+    assert "x266_amd/libx266hip.so" in maps
+    info = codec.device_info()
+    assert "gfx950" in info["name"] and info["cu_count"] > 0
+
+
+def test_dct32_fwd_golden(codec):
+    g = _golden("dct32_fwd.npz")
+    assert np.array_equal(codec.dct32_fwd(g["inputs"]), g["outputs"])
+
+
+def test_dct32_fwd_config0_single_block(codec, oracle):
+    """BASELINE configs[0]: one block, block 0 of the seeded stream."""
+    x = residual_np(1024, 0x266)
+    out = codec.dct32_fwd(x)
+    assert np.array_equal(out, _golden("dct32_fwd.npz")["outputs"][:1])
+    assert np.array_equal(out, oracle.dct32_fwd(x))
+
+
+def test_dct32_fwd_random_vs_oracle(codec, oracle):
+    x = _mixed(4000, 1024, 101)
+    assert np.array_equal(codec.dct32_fwd(x), oracle.dct32_fwd(x, threads=8))
+
+
+def test_dct32_fwd_edges_and_transpose_detection(codec, oracle):
+    edge, names = dct_edge_blocks()
+    got, want = codec.dct32_fwd(edge), oracle.dct32_fwd(edge)
+    for i, n in enumerate(names):
+        assert np.array_equal(got[i], want[i]), n
+    # an asymmetric block and its transpose must transform to transposes of each other only up to
+    # the different rounding of the two passes -- compare with the oracle, not with each other
+    a = edge[names.index("asymmetric")].reshape(32, 32)
+    assert np.array_equal(codec.dct32_fwd(a.T.copy()), oracle.dct32_fwd(a.T.copy()))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 63, 64, 65, 255, 1023, 1025, 4099])
+def test_dct32_fwd_ragged_counts(codec, oracle, n):
+    x = residual_np(max(n, 1) * 1024, 200 + n)[: n * 1024]
+    got = codec.dct32_fwd(x.reshape(-1, 1024)) if n else codec.dct32_fwd(np.zeros((0, 1024), np.int16))
+    assert got.shape == (n, 1024)
+    if n:
+        assert np.array_equal(got, oracle.dct32_fwd(x))
+
+
+# ---------------------------------------------------------------- DCT32 inverse
+def test_dct32_inv_vs_oracle(codec, oracle):
+    x = _mixed(1500, 1024, 301)
+    z = oracle.dct32_fwd(x, threads=8)
+    assert np.array_equal(codec.dct32_inv(z), oracle.dct32_inv(z, threads=8))       # realistic coefficients
+    assert np.array_equal(codec.dct32_inv(x), oracle.dct32_inv(x, threads=8))       # full-range: clipping paths
+    edge, _ = dct_edge_blocks()
+    assert np.array_equal(codec.dct32_inv(edge), oracle.dct32_inv(edge))
+
+
+def test_dct32_roundtrip_on_device(codec):
+    x = residual_np(2048 * 1024, 0x266).reshape(-1, 1024)
+    r = codec.dct32_inv(codec.dct32_fwd(x))
+    err = np.abs(r.astype(np.int32) - x.astype(np.int32))
+    assert err.max() <= 6 and err.mean() < 1.0                                      # same frozen bound as the oracle
+
+
+# ---------------------------------------------------------------- SATD
+def test_satd_golden_and_known_answers(codec):
+    g = _golden("satd8x8.npz")
+    assert np.array_equal(codec.satd8x8(g["inputs"]), g["outputs"])
+    edge, names = satd_edge_blocks()
+    got = dict(zip(names, codec.satd8x8(edge).tolist()))
+    assert (got["zeros"], got["all_255"], got["all_m256"], got["all_32767"], got["alt_extreme"]) == \
+        (0, 4080, 4096, 16, 16)
+
+
+def test_satd_random_vs_oracle(codec, oracle):
+    d = _mixed(150000, 64, 401)
+    assert np.array_equal(codec.satd8x8(d), oracle.satd8x8(d, threads=8))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 31, 32, 33, 63, 64, 65, 127, 1000, 4097])
+def test_satd_ragged_counts(codec, oracle, n):
+    d = fullrange_np(max(n, 1) * 64, 500 + n)[: n * 64].reshape(-1, 64)
+    got = codec.satd8x8(d)
+    assert got.shape == (n,)
+    if n:
+        assert np.array_equal(got, oracle.satd8x8(d))
+
+
+# ---------------------------------------------------------------- device-pointer API
+def test_device_pointer_api_and_fill(codec, oracle):
+    n = 5000
+    din, dout = codec.alloc(n * 2048), codec.alloc(n * 2048)
+    codec.fill_residual_dev(din.ptr, n * 1024, 0x266, 12345)
+    codec.dct32_fwd_dev(din.ptr, dout.ptr, n)
+    codec.stream_sync()
+    x = din.download(np.int16, n * 1024)
+    assert np.array_equal(x, residual_np(n * 1024, 0x266, 12345))                   # device PRNG == host twins
+    z = dout.download(np.int16, n * 1024).reshape(n, 1024)
+    assert np.array_equal(z, oracle.dct32_fwd(x, threads=8))
+    codec.dct32_inv_dev(dout.ptr, din.ptr, n)
+    codec.stream_sync()
+    assert np.array_equal(din.download(np.int16, n * 1024).reshape(n, 1024), oracle.dct32_inv(z, threads=8))
+    ns = 70001
+    sin, sout = codec.alloc(ns * 128), codec.alloc(ns * 4)
+    codec.fill_residual_dev(sin.ptr, ns * 64, 0x267)
+    codec.satd8x8_dev(sin.ptr, sout.ptr, ns)
+    codec.stream_sync()
+    assert np.array_equal(sout.download(np.uint32, ns), oracle.satd8x8(residual_np(ns * 64, 0x267), threads=8))
+
+
+def test_argument_errors(codec):
+    L = codec.L
+    assert L.xDct32FwdBatchDev(codec.ctx, None, None, 4, None) < 0                  # NULL with n > 0
+    assert L.xDct32FwdBatchDev(codec.ctx, None, None, 0, None) == 0                 # n == 0 is a no-op
+    buf = codec.alloc(4096)
+    assert L.xDct32FwdBatchDev(codec.ctx, buf.ptr + 2, buf.ptr, 1, None) < 0        # misaligned
+    assert L.xSatd8x8Batch(codec.ctx, None, None, 3) < 0
+    assert L.xHipSetOption(codec.ctx, b"no_such_option", 1) < 0
+    assert b"" != L.xHipLastError(codec.ctx)
+
+
+@pytest.mark.parametrize("nt", [0, 1])
+@pytest.mark.parametrize("wgs", [1, 3, 8])
+def test_launch_geometry_options_do_not_change_results(codec, oracle, nt, wgs):
+    x = residual_np(3000 * 1024, 0x266).reshape(-1, 1024)
+    d = x.reshape(-1, 64)[:100003]
+    saved = {k: codec.get_option(k) for k in ("nontemporal", "dct32_wgs_per_cu", "dct32_inv_wgs_per_cu",
+                                              "satd_wgs_per_cu")}
+    try:
+        codec.set_option("nontemporal", nt)
+        for k in ("dct32_wgs_per_cu", "dct32_inv_wgs_per_cu", "satd_wgs_per_cu"):
+            codec.set_option(k, wgs)
+        z = oracle.dct32_fwd(x, threads=8)
+        assert np.array_equal(codec.dct32_fwd(x), z)
+        assert np.array_equal(codec.dct32_inv(z), oracle.dct32_inv(z, threads=8))
+        assert np.array_equal(codec.satd8x8(d), oracle.satd8x8(d, threads=8))
+    finally:
+        for k, v in saved.items():
+            codec.set_option(k, v)
+
+
+# ---------------------------------------------------------------- full size (BASELINE configs[1])
+def test_full_size_batch_properties(codec, oracle):
+    """1 Mi blocks resident in HBM: (a) a strided sample is bit-exact with the oracle,
+    (b) the order-independent checksum of the whole output equals the oracle's on all host cores,
+    (c) transforming the batch in two halves gives the same bytes (block independence),
+    (d) fwd -> inv reconstructs within the frozen bound."""
+    n = 1 << 20
+    din, dout = codec.alloc(n * 2048), codec.alloc(n * 2048)
+    codec.fill_residual_dev(din.ptr, n * 1024, 0x266)
+    codec.dct32_fwd_dev(din.ptr, dout.ptr, n)
+    codec.stream_sync()
+    z = dout.download(np.int16, n * 1024).reshape(n, 1024)
+    x = din.download(np.int16, n * 1024).reshape(n, 1024)
+    idx = np.arange(0, n, 257)
+    assert np.array_equal(z[idx], oracle.dct32_fwd(x[idx], threads=8))                       # (a)
+    threads = oracle.hw_threads()
+    want = oracle.dct32_fwd(x, threads=threads)                                              # (b) whole batch
+    assert int(z.view(np.uint16).astype(np.uint64).sum()) == int(want.view(np.uint16).astype(np.uint64).sum())
+    assert np.array_equal(z, want)
+    half = n // 2                                                                            # (c)
+    codec.dct32_fwd_dev(din.ptr + half * 2048, dout.ptr + half * 2048, n - half)
+    codec.dct32_fwd_dev(din.ptr, dout.ptr, half)
+    codec.stream_sync()
+    assert np.array_equal(dout.download(np.int16, n * 1024).reshape(n, 1024), z)
+    del want
+    codec.dct32_inv_dev(dout.ptr, din.ptr, n)                                                # (d)
+    codec.stream_sync()
+    r = din.download(np.int16, n * 1024).reshape(n, 1024)
+    sample = np.arange(0, n, 64)
+    assert np.array_equal(r[sample], oracle.dct32_inv(z[sample], threads=8))
+    assert np.abs(r[sample].astype(np.int32) - x[sample].astype(np.int32)).max() <= 6
+
+
+def test_full_size_satd(codec, oracle):
+    n = 1 << 24                                                                              # 2 GiB of residual blocks
+    din, dout = codec.alloc(n * 128), codec.alloc(n * 4)
+    codec.fill_residual_dev(din.ptr, n * 64, 0x267)
+    codec.satd8x8_dev(din.ptr, dout.ptr, n)
+    codec.stream_sync()
+    got = dout.download(np.uint32, n)
+    want = oracle.satd8x8(din.download(np.int16, n * 64), threads=oracle.hw_threads())
+    assert np.array_equal(got, want)
+    assert got.max() <= 29750 and got.min() > 0                                              # 9-bit residual range
+
+
+# ---------------------------------------------------------------- BDPI drop-in surface
+def _run_tb(mode, n):
+    exe = os.path.join(ROOT, "host", "tb_protocol")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "--no-print-directory"])
+    out = subprocess.check_output([exe, mode, str(n)], timeout=300).decode().split("\n")
+    return [l.split() for l in out if l]
+
+
+def test_bdpi_dct_protocol_matches_reference_stream():
+    """A fresh process (glibc rand, default seed) driving the six BDPI symbols in
+    mkTb's order reproduces the real reference's word stream exactly."""
+    g = _golden("bdpi_dct32.npz")
+    lines = _run_tb("dct", 3)
+    d = np.array([int(v, 16) for k, v in lines if k == "D"], dtype=np.uint64).reshape(3, 16, 32)
+    c = np.array([int(v, 16) for k, v in lines if k == "C"], dtype=np.uint64).reshape(3, 256)
+    assert np.array_equal(d.astype(np.uint32), g["diff_words"])
+    assert np.array_equal(c, g["dct_words"])
+    assert int(c[0, 0]) == 0xFFF70017FDBAFF87
+
+
+def test_bdpi_satd_protocol_matches_reference_stream():
+    g = _golden("bdpi_satd.npz")
+    lines = _run_tb("satd", 8)
+    d = np.array([int(v, 16) for k, v in lines if k == "D"], dtype=np.uint64).reshape(8, 8, 4)
+    s = np.array([int(v) for k, v in lines if k == "S"], dtype=np.uint32)
+    assert np.array_equal(d.astype(np.uint32), g["diff_words"])
+    assert np.array_equal(s, g["satd"]) and s[:3].tolist() == [10867, 10533, 11552]
+
+
+def test_bdpi_in_process(codec):
+    """Same symbols through ctypes; srand(1) restores the default rand() sequence."""
+    L = codec.L
+    libc = ctypes.CDLL(None)
+    libc.srand(1)
+    g = _golden("bdpi_dct32.npz")
+    res = (ctypes.c_uint * 32)()
+    L.dct32_genNew()
+    for i in range(16):
+        L.dct32_getDiff(res)
+        assert np.array_equal(np.frombuffer(res, np.uint32), g["diff_words"][0, i])
+    words = [L.dct32_getDct() for _ in range(256)]
+    assert words == [int(w) for w in g["dct_words"][0]]

@@ -1,0 +1,89 @@
+"""CPU: structural properties of the oracle (table symmetries, dense == butterfly,
+the self-defined inverse against a numpy statement of its definition, the
+round-trip bound, SATD invariances, the PRNG twins)."""
+import numpy as np
+
+from _util import extremes_np, fullrange_np, residual_np, splitmix64
+
+
+def test_table_structure(oracle):
+    g = oracle.table().astype(np.int64)
+    assert g.shape == (32, 32) and np.all(g[0] == 64)
+    n = np.arange(32)
+    for k in range(32):                         # g[k][31-n] = (-1)^k g[k][n]   
+        assert np.array_equal(g[k, 31 - n], (-1) ** k * g[k, n])
+    assert g.sum(axis=1).tolist() == [2048] + [0] * 31       # row sums (byte-plane offset fix relies on it)
+    assert np.abs(g).max() == 90                             # fits int8
+    # near-orthogonality of the integer basis
+    gram = g @ g.T
+    assert np.abs(gram - np.diag(np.diag(gram))).max() < 0.004 * np.diag(gram).min()
+    assert np.all(np.abs(np.diag(gram) - 64 * 64 * 32) < 200)
+    # column 0 reproduces the 32 magnitudes the generators start from
+    assert g[:, 0].tolist() == [64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64, 61, 57,
+                                54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4]
+
+
+def test_dense_equals_butterfly(oracle):
+    x = np.concatenate([residual_np(64 * 1024, 3), fullrange_np(64 * 1024, 4), extremes_np(64 * 1024, 5)])
+    for blk in x.reshape(-1, 1024):
+        for shift in (4, 11):
+            assert np.array_equal(oracle.dct32_pass(blk, shift), oracle.dct32_pass(blk, shift, dense=True))
+
+
+def test_fwd_is_two_passes_and_matches_numpy(oracle):
+    g = oracle.table().astype(np.int64)
+    x = fullrange_np(8 * 1024, 7).reshape(8, 32, 32)
+    out = oracle.dct32_fwd(x)
+    for b in range(8):
+        y = ((np.einsum("kn,jn->kj", g, x[b].astype(np.int64)) + 8) >> 4).astype(np.int16)          # coef[k][j]
+        z = ((np.einsum("vj,kj->vk", g, y.astype(np.int64)) + 1024) >> 11).astype(np.int16)          # dct[v][k]
+        assert np.array_equal(out[b].reshape(32, 32), z)
+
+
+def test_inverse_definition(oracle):
+    """UNPINNED path: the C inverse equals this numpy statement of its definition."""
+    g = oracle.table().astype(np.int64)
+    z = np.concatenate([oracle.dct32_fwd(residual_np(6 * 1024, 9)).ravel(), fullrange_np(6 * 1024, 10)])
+    z = z.reshape(12, 32, 32)
+    out = oracle.dct32_inv(z)
+    for b in range(12):
+        t = np.clip((np.einsum("vy,vu->uy", g, z[b].astype(np.int64)) + 64) >> 7, -32768, 32767)    # T[u][y]
+        r = np.clip((np.einsum("ux,uy->yx", g, t) + 2048) >> 12, -32768, 32767)                      # R[y][x]
+        assert np.array_equal(out[b].reshape(32, 32), r.astype(np.int16))
+
+
+def test_roundtrip_bound(oracle):
+    """fwd -> inv of 9-bit residuals reconstructs within a few LSB (frozen bound)."""
+    x = residual_np(4096 * 1024, 0x266)
+    r = oracle.dct32_inv(oracle.dct32_fwd(x, threads=4), threads=4)
+    err = np.abs(r.ravel().astype(np.int32) - x.astype(np.int32))
+    assert err.max() <= 6
+    assert err.mean() < 1.0
+
+
+def test_satd_invariances(oracle):
+    d = residual_np(512 * 64, 12).reshape(512, 8, 8)
+    base = oracle.satd8x8(d)
+    assert np.array_equal(oracle.satd8x8(-d), base)                          # |.| is even
+    assert np.array_equal(oracle.satd8x8(d.transpose(0, 2, 1)), base)        # H X H^T symmetric in the two axes
+    assert np.array_equal(oracle.satd8x8(d[:, ::-1, :]), base)               # row reversal = sign flips of H rows
+    dc = np.full((1, 8, 8), 3, np.int16)
+    assert oracle.satd8x8(dc)[0] == (3 * 64 + 2) >> 2
+
+
+def test_satd_matches_numpy_truncation_model(oracle):
+    """exact integer Hadamard, low 16 bits as signed, abs, sum."""
+    h2 = np.array([[1, 1], [1, -1]], np.int64)
+    h8 = np.kron(np.kron(h2, h2), h2)
+    d = np.concatenate([fullrange_np(300 * 64, 13), extremes_np(300 * 64, 14)]).reshape(600, 8, 8)
+    c = np.einsum("ij,bjk,lk->bil", h8, d.astype(np.int64), h8)
+    c16 = ((c + 32768) % 65536) - 32768
+    want = ((np.abs(c16).sum(axis=(1, 2)) + 2) >> 2).astype(np.uint32)
+    assert np.array_equal(oracle.satd8x8(d), want)
+
+
+def test_prng_twins(oracle):
+    assert np.array_equal(oracle.fill_residual(5000, 0x266, 77), residual_np(5000, 0x266, 77))
+    r = residual_np(200000, 1)
+    assert r.min() >= -255 and r.max() <= 255 and abs(float(r.mean())) < 1.0
+    assert splitmix64(0, 0, 1)[0] == np.uint64(0xE220A8397B1DCDAF)           # SplitMix64 reference value
