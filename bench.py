@@ -175,13 +175,17 @@ def main():
                 "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": traffic,
                 "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_unit * n_units}
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch, if collected
-    if os.path.exists(tpath):
+    # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected
+    # with this same command on this workload; FETCH_SIZE x2 gfx950 correction applied there).
+    # They only describe the default workload size.
+    pmc = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and n_dct == DCT_BLOCKS_PER_GPU and n_satd == SATD_BLOCKS_PER_GPU:
         try:
-            traffic = json.load(open(tpath)).get("dct32_fwd_bytes_per_launch")
+            pmc = json.load(open(tpath))
         except Exception:
-            traffic = None
+            pmc = {}
+    traffic = pmc.get("dct32_fwd_bytes_per_launch")
 
     result = {
         "metric": "dct32_fwd_blocks_per_s", "value": value, "unit": "blocks/s", "n_gpus": world,
@@ -211,7 +215,7 @@ def main():
         wall_i, k_ms_i = run_leg(OP_DCT32_INV, codec.dct32_inv_dev, z.data_ptr(), r.data_ptr(), n_dct, args.steps, args.warmup)
         also["dct32_inv"] = {"value": world * n_dct * args.steps / wall_i, "unit": "blocks/s",
                              "ms_per_step": wall_i / args.steps * 1e3,
-                             "roofline": roofline(DCT_BYTES_PER_BLOCK, n_dct, k_ms_i),
+                             "roofline": roofline(DCT_BYTES_PER_BLOCK, n_dct, k_ms_i, pmc.get("dct32_inv_bytes_per_launch")),
                              "parity": "unpinned (no inverse in the reference); bit-exact vs this repo's oracle"}
         err = (r[: 4096 * 1024].to(torch.int32) - x[: 4096 * 1024].to(torch.int32)).abs().max().item()
         also["dct32_inv"]["roundtrip_max_abs_err"] = int(err)
@@ -222,7 +226,7 @@ def main():
         wall_s, k_ms_s = run_leg(OP_SATD8X8, codec.satd8x8_dev, d.data_ptr(), s.data_ptr(), n_satd, args.steps, args.warmup)
         also["satd8x8"] = {"value": world * n_satd * args.steps / wall_s, "unit": "blocks/s",
                            "ms_per_step": wall_s / args.steps * 1e3, "blocks_per_gpu": n_satd,
-                           "roofline": roofline(SATD_BYTES_PER_BLOCK, n_satd, k_ms_s)}
+                           "roofline": roofline(SATD_BYTES_PER_BLOCK, n_satd, k_ms_s, pmc.get("satd8x8_bytes_per_launch"))}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from _util import Oracle

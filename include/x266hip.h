@@ -62,8 +62,16 @@ const char *xHipLastError(const x266hip_ctx *ctx);
 /* Device facts for reports: name, CU count, max engine clock (MHz), HBM bytes. */
 int  xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap,
                     int *cu_count, int *clock_mhz, size_t *hbm_bytes);
-/* Kernel variant selection for A/B measurement ("dct32_variant", "satd_variant",
- * "waves_per_cu" ...).  Unknown keys return X266HIP_EINVAL. */
+/* Launch-geometry options, for A/B measurement (defaults are the measured optimum):
+ *   "dct32_variant" / "satd_variant"   0 = streaming launch (grid covers the batch; each wave
+ *                                          transforms a short run of consecutive blocks),
+ *                                      1 = persistent grid-stride launch
+ *   "dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "satd_groups_per_wave"
+ *                                      run length per wave of the streaming launch
+ *   "dct32_wgs_per_cu", "dct32_inv_wgs_per_cu", "satd_wgs_per_cu"
+ *                                      resident workgroups per CU of the persistent launch
+ *   "wg_threads" (64..256), "nontemporal" (0/1)
+ * Results never depend on them.  Unknown keys return X266HIP_EINVAL. */
 int  xHipSetOption(x266hip_ctx *ctx, const char *key, int value);
 int  xHipGetOption(const x266hip_ctx *ctx, const char *key, int *value);
 

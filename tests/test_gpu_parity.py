@@ -147,15 +147,23 @@ def test_argument_errors(codec):
     assert b"" != L.xHipLastError(codec.ctx)
 
 
-@pytest.mark.parametrize("nt", [0, 1])
-@pytest.mark.parametrize("wgs", [1, 3, 8])
-def test_launch_geometry_options_do_not_change_results(codec, oracle, nt, wgs):
-    x = residual_np(3000 * 1024, 0x266).reshape(-1, 1024)
+@pytest.mark.parametrize("variant,nt,tpb,per_wave,wgs", [
+    (0, 0, 64, 1, 8), (0, 1, 256, 3, 8), (0, 0, 128, 16, 8), (0, 0, 192, 7, 8),
+    (1, 0, 256, 1, 1), (1, 1, 64, 1, 3), (1, 0, 256, 1, 8)])
+def test_launch_geometry_options_do_not_change_results(codec, oracle, variant, nt, tpb, per_wave, wgs):
+    x = residual_np(3001 * 1024, 0x266).reshape(-1, 1024)
     d = x.reshape(-1, 64)[:100003]
-    saved = {k: codec.get_option(k) for k in ("nontemporal", "dct32_wgs_per_cu", "dct32_inv_wgs_per_cu",
-                                              "satd_wgs_per_cu")}
+    keys = ("nontemporal", "wg_threads", "dct32_variant", "satd_variant", "dct32_blocks_per_wave",
+            "dct32_inv_blocks_per_wave", "satd_groups_per_wave", "dct32_wgs_per_cu", "dct32_inv_wgs_per_cu",
+            "satd_wgs_per_cu")
+    saved = {k: codec.get_option(k) for k in keys}
     try:
         codec.set_option("nontemporal", nt)
+        codec.set_option("wg_threads", tpb)
+        for k in ("dct32_variant", "satd_variant"):
+            codec.set_option(k, variant)
+        for k in ("dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "satd_groups_per_wave"):
+            codec.set_option(k, per_wave)
         for k in ("dct32_wgs_per_cu", "dct32_inv_wgs_per_cu", "satd_wgs_per_cu"):
             codec.set_option(k, wgs)
         z = oracle.dct32_fwd(x, threads=8)

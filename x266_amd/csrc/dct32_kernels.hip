@@ -190,17 +190,42 @@ __device__ __forceinline__ void inv_block(const v4i &w0, const v4i &w1, const La
 }
 
 // ---- kernel ----------------------------------------------------------------
-// Persistent waves, grid-stride over blocks, next block's loads issued before
-// the current block's arithmetic (register double buffer).
+// Each wave transforms `count` blocks: start, start + stride, ...  Two launch
+// shapes use it:
+//   streaming  : stride 1, count = blocks_per_wave, one wave per chunk, a grid
+//                as large as the batch.  The hardware dispatcher then walks the
+//                batch in address order, which is what HBM likes best (a plain
+//                one-element-per-thread copy is ~15 % faster on this chip than
+//                any persistent grid-stride copy).
+//   persistent : stride = number of waves, resident grid, grid-stride.
+// The next block's loads are issued before the current block's arithmetic
+// (two register sets in ping-pong).
 template <bool INVERSE, bool NT>
 __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ in,
                                                     int16_t *__restrict__ out, size_t n_blocks,
-                                                    const DctOps *__restrict__ ops)
+                                                    const DctOps *__restrict__ ops,
+                                                    unsigned blocks_per_wave)
 {
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    if (wave >= n_blocks) return;
+    size_t b, stride, end;
+    if (blocks_per_wave) {                    // streaming: contiguous chunk
+        b = wave * blocks_per_wave;
+        stride = 1;
+        end = b + blocks_per_wave < n_blocks ? b + blocks_per_wave : n_blocks;
+    } else {                                  // persistent: grid-stride
+        b = wave;
+        stride = ((size_t)gridDim.x * blockDim.x) >> 6;
+        end = n_blocks;
+    }
+    if (b >= end) return;
+
+    const size_t lane_off = (size_t)(lane & 31) * 64 + (size_t)(lane >> 5) * 32;   // bytes
+    const char *src = reinterpret_cast<const char *>(in) + lane_off;
+    char *dst = reinterpret_cast<char *>(out) + lane_off;
+
+    // first block's loads go out before the operand images are fetched
+    v4i a0 = load16<NT>(src + b * 2048), a1 = load16<NT>(src + b * 2048 + 16);
 
     const LaneConsts k = load_consts(ops, lane);
     v16i c2r;
@@ -208,24 +233,10 @@ __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) c2r[r] = ops->c2r[lane][r];
     }
-
-    const size_t lane_off = (size_t)(lane & 31) * 64 + (size_t)(lane >> 5) * 32;   // bytes
-    const char *src = reinterpret_cast<const char *>(in) + lane_off;
-    char *dst = reinterpret_cast<char *>(out) + lane_off;
-
-    // The operand images must have landed before the loop: otherwise the
-    // compiler's in-loop wait for them is a vmcnt(0) that also drains every
-    // prefetch it was meant to leave in flight.
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt/expcnt untouched
-
-    // Two register sets in ping-pong: the loads of block b + n_waves are in
-    // flight while block b is transformed.
-    size_t b = wave;
-    v4i a0 = load16<NT>(src + b * 2048), a1 = load16<NT>(src + b * 2048 + 16);
     v4i b0 = a0, b1 = a1, o0, o1;
     while (true) {
-        size_t nb = b + n_waves;
-        if (nb < n_blocks) {
+        size_t nb = b + stride;
+        if (nb < end) {
             b0 = load16<NT>(src + nb * 2048);
             b1 = load16<NT>(src + nb * 2048 + 16);
         }
@@ -233,10 +244,10 @@ __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ 
         else         fwd_block(a0, a1, k, o0, o1);
         store16<NT>(dst + b * 2048, o0);
         store16<NT>(dst + b * 2048 + 16, o1);
-        if (nb >= n_blocks) break;
+        if (nb >= end) break;
         b = nb;
-        nb = b + n_waves;
-        if (nb < n_blocks) {
+        nb = b + stride;
+        if (nb < end) {
             a0 = load16<NT>(src + nb * 2048);
             a1 = load16<NT>(src + nb * 2048 + 16);
         }
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ 
         else         fwd_block(b0, b1, k, o0, o1);
         store16<NT>(dst + b * 2048, o0);
         store16<NT>(dst + b * 2048 + 16, o1);
-        if (nb >= n_blocks) break;
+        if (nb >= end) break;
         b = nb;
     }
 }
@@ -256,17 +267,27 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
                         const DctOps *d_ops, const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
-    const size_t waves_wanted = n_blocks;
-    size_t wgs = (waves_wanted + 3) / 4;
-    const size_t cap = (size_t)cfg.cu_count * (size_t)cfg.wgs_per_cu;
-    if (wgs > cap) wgs = cap;
-    dim3 grid((unsigned)wgs), block(256);
+    const unsigned tpb = cfg.wg_threads;                       // 64 .. 256, multiple of 64
+    const size_t waves_per_wg = tpb / 64;
+    unsigned bpw = 0;
+    size_t wgs;
+    if (cfg.variant == 0) {                                    // streaming launch
+        bpw = cfg.units_per_wave < 1 ? 1u : (unsigned)cfg.units_per_wave;
+        const size_t waves = (n_blocks + bpw - 1) / bpw;
+        wgs = (waves + waves_per_wg - 1) / waves_per_wg;
+    } else {                                                   // persistent launch
+        wgs = (n_blocks + waves_per_wg - 1) / waves_per_wg;
+        const size_t cap = (size_t)cfg.cu_count * (size_t)cfg.wgs_per_cu;
+        if (wgs > cap) wgs = cap;
+    }
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)wgs), block(tpb);
     if (inverse) {
-        if (cfg.nontemporal) hipLaunchKernelGGL((dct32_kernel<true, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops);
-        else                 hipLaunchKernelGGL((dct32_kernel<true, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops);
+        if (cfg.nontemporal) hipLaunchKernelGGL((dct32_kernel<true, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else                 hipLaunchKernelGGL((dct32_kernel<true, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, bpw);
     } else {
-        if (cfg.nontemporal) hipLaunchKernelGGL((dct32_kernel<false, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops);
-        else                 hipLaunchKernelGGL((dct32_kernel<false, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops);
+        if (cfg.nontemporal) hipLaunchKernelGGL((dct32_kernel<false, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else                 hipLaunchKernelGGL((dct32_kernel<false, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, bpw);
     }
     return hipGetLastError();
 }

@@ -67,19 +67,28 @@ __device__ __forceinline__ uint32_t abs_sum16(const v16i &hi, const v16i &lo, ui
 template <bool NT>
 __global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict__ diff,
                                                       uint32_t *__restrict__ out, size_t n_blocks,
-                                                      const SatdOps *__restrict__ ops)
+                                                      const SatdOps *__restrict__ ops,
+                                                      unsigned groups_per_wave)
 {
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const size_t n_groups = (n_blocks + 31) >> 5;           // 32 blocks per wave-iteration
-    if (wave >= n_groups) return;
+    size_t g, stride, end;
+    if (groups_per_wave) {                                  // streaming launch (see dct32_kernels.hip)
+        g = wave * groups_per_wave;
+        stride = 1;
+        end = g + groups_per_wave < n_groups ? g + groups_per_wave : n_groups;
+    } else {                                                // persistent grid-stride
+        g = wave;
+        stride = ((size_t)gridDim.x * blockDim.x) >> 6;
+        end = n_groups;
+    }
+    if (g >= end) return;
 
-    v4i h00 = *reinterpret_cast<const v4i *>(ops->a[0][0][lane]);
-    v4i h01 = *reinterpret_cast<const v4i *>(ops->a[0][1][lane]);
-    v4i h10 = *reinterpret_cast<const v4i *>(ops->a[1][0][lane]);
-    v4i h11 = *reinterpret_cast<const v4i *>(ops->a[1][1][lane]);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                     // see dct32_kernels.hip
+    const v4i h00 = *reinterpret_cast<const v4i *>(ops->a[0][0][lane]);
+    const v4i h01 = *reinterpret_cast<const v4i *>(ops->a[0][1][lane]);
+    const v4i h10 = *reinterpret_cast<const v4i *>(ops->a[1][0][lane]);
+    const v4i h11 = *reinterpret_cast<const v4i *>(ops->a[1][1][lane]);
 
     const int blk = lane & 31, half = lane >> 5;
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict_
     v16i dcfix = zero;
     dcfix[0] = half == 0 ? 128 * 64 : 0;
 
-    for (size_t g = wave; g < n_groups; g += n_waves) {
+    for (; g < end; g += stride) {
         size_t b = g * 32 + blk;
         const bool live = b < n_blocks;
         if (!live) b = n_blocks - 1;                        // ragged tail: re-read the last block
@@ -157,12 +166,23 @@ hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_block
 {
     if (n_blocks == 0) return hipSuccess;
     const size_t groups = (n_blocks + 31) / 32;
-    size_t wgs = (groups + 3) / 4;
-    const size_t cap = (size_t)cfg.cu_count * (size_t)cfg.wgs_per_cu;
-    if (wgs > cap) wgs = cap;
-    dim3 grid((unsigned)wgs), block(256);
-    if (cfg.nontemporal) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, 0, stream, d_diff, d_out, n_blocks, d_ops);
-    else                 hipLaunchKernelGGL((satd8x8_kernel<false>), grid, block, 0, stream, d_diff, d_out, n_blocks, d_ops);
+    const unsigned tpb = cfg.wg_threads;
+    const size_t waves_per_wg = tpb / 64;
+    unsigned gpw = 0;
+    size_t wgs;
+    if (cfg.variant == 0) {                                    // streaming launch
+        gpw = cfg.units_per_wave < 1 ? 1u : (unsigned)cfg.units_per_wave;
+        const size_t waves = (groups + gpw - 1) / gpw;
+        wgs = (waves + waves_per_wg - 1) / waves_per_wg;
+    } else {                                                   // persistent launch
+        wgs = (groups + waves_per_wg - 1) / waves_per_wg;
+        const size_t cap = (size_t)cfg.cu_count * (size_t)cfg.wgs_per_cu;
+        if (wgs > cap) wgs = cap;
+    }
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)wgs), block(tpb);
+    if (cfg.nontemporal) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, 0, stream, d_diff, d_out, n_blocks, d_ops, gpw);
+    else                 hipLaunchKernelGGL((satd8x8_kernel<false>), grid, block, 0, stream, d_diff, d_out, n_blocks, d_ops, gpw);
     return hipGetLastError();
 }
 

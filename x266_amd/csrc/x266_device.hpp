@@ -29,10 +29,12 @@ __device__ __forceinline__ void store16(void *p, const v4i &v)
 }
 
 struct LaunchCfg {
-    int cu_count;      // compute units of the device
-    int wgs_per_cu;    // resident 256-thread workgroups per CU to launch
-    int nontemporal;   // use streaming loads/stores
-    int variant;       // kernel variant (per op)
+    int cu_count;        // compute units of the device
+    int wgs_per_cu;      // persistent launch: resident workgroups per CU
+    int nontemporal;     // use streaming loads/stores
+    int variant;         // 0 = streaming launch (grid covers the batch), 1 = persistent grid-stride
+    int units_per_wave;  // streaming launch: consecutive units (DCT blocks / 32-block SATD groups) per wave
+    int wg_threads;      // workgroup size, multiple of 64
 };
 
 struct DctOps;

@@ -29,9 +29,11 @@ struct x266hip_ctx {
     int wgs_per_cu_dct = 8;
     int wgs_per_cu_inv = 5;
     int wgs_per_cu_satd = 8;
-    int nontemporal = 1;
-    int dct_variant = 0;
-    int satd_variant = 0;
+    int nontemporal = 0;
+    int dct_variant = 0, satd_variant = 0;          // 0 streaming launch, 1 persistent
+    // streaming launch: consecutive units per wave (measured optimum on MI355X, profiles/r01_sweep.txt)
+    int dct_blocks_per_wave = 2, dct_inv_blocks_per_wave = 8, satd_groups_per_wave = 8;
+    int wg_threads = 256;
     // host-pointer staging (lazily allocated)
     static constexpr int kSlots = 2;
     void *d_stage_in[kSlots] = {nullptr, nullptr};
@@ -68,6 +70,8 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
     c.wgs_per_cu = op == 0 ? ctx->wgs_per_cu_dct : (op == 1 ? ctx->wgs_per_cu_inv : ctx->wgs_per_cu_satd);
     c.nontemporal = ctx->nontemporal;
     c.variant = op == 2 ? ctx->satd_variant : ctx->dct_variant;
+    c.units_per_wave = op == 2 ? ctx->satd_groups_per_wave : (op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave);
+    c.wg_threads = ctx->wg_threads;
     return c;
 }
 
@@ -187,6 +191,10 @@ static int *option_slot(x266hip_ctx *ctx, const char *key)
     if (!std::strcmp(key, "nontemporal")) return &ctx->nontemporal;
     if (!std::strcmp(key, "dct32_variant")) return &ctx->dct_variant;
     if (!std::strcmp(key, "satd_variant")) return &ctx->satd_variant;
+    if (!std::strcmp(key, "dct32_blocks_per_wave")) return &ctx->dct_blocks_per_wave;
+    if (!std::strcmp(key, "dct32_inv_blocks_per_wave")) return &ctx->dct_inv_blocks_per_wave;
+    if (!std::strcmp(key, "satd_groups_per_wave")) return &ctx->satd_groups_per_wave;
+    if (!std::strcmp(key, "wg_threads")) return &ctx->wg_threads;
     return nullptr;
 }
 
@@ -195,6 +203,8 @@ int xHipSetOption(x266hip_ctx *ctx, const char *key, int value)
     int *slot = option_slot(ctx, key);
     if (!slot) return X266HIP_EINVAL;
     if (std::strstr(key, "wgs_per_cu") && (value < 1 || value > 64)) return fail(ctx, X266HIP_EINVAL, "wgs_per_cu out of range");
+    if (std::strstr(key, "_per_wave") && (value < 1 || value > 4096)) return fail(ctx, X266HIP_EINVAL, "units per wave out of range");
+    if (!std::strcmp(key, "wg_threads") && (value < 64 || value > 256 || value % 64)) return fail(ctx, X266HIP_EINVAL, "wg_threads must be 64, 128, 192 or 256");
     *slot = value;
     return X266HIP_OK;
 }

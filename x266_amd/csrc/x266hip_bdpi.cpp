@@ -50,6 +50,21 @@ namespace {
 
 x266hip_ctx *g_ctx = nullptr;
 
+// The stimulus comes from libc rand(), whose state is process-global.  Anything
+// the HIP runtime draws from it (it does, while initialising) would shift the
+// stimulus stream away from upstream's.  Every trip into the runtime therefore
+// runs on a private random state; the caller's state is put back untouched.
+class RandStateGuard {
+public:
+    RandStateGuard() { prev_ = initstate(0x266u, scratch_, sizeof scratch_); }
+    ~RandStateGuard() { if (prev_) setstate(prev_); }
+    RandStateGuard(const RandStateGuard &) = delete;
+    RandStateGuard &operator=(const RandStateGuard &) = delete;
+private:
+    char scratch_[256];
+    char *prev_ = nullptr;
+};
+
 void release_ctx() { xHipCodecFree(g_ctx); g_ctx = nullptr; }
 
 x266hip_ctx *bdpi_ctx()
@@ -94,8 +109,11 @@ extern "C" {
 void dct32_genNew(void)
 {
     for (int i = 0; i < 32 * 32; ++i) s_dct_in[i] = draw_residual();
-    const int rc = xDct32FwdBatch(bdpi_ctx(), s_dct_in, s_dct_out, 1);
-    if (rc != X266HIP_OK) die("xDct32FwdBatch", rc);
+    {
+        RandStateGuard guard;
+        const int rc = xDct32FwdBatch(bdpi_ctx(), s_dct_in, s_dct_out, 1);
+        if (rc != X266HIP_OK) die("xDct32FwdBatch", rc);
+    }
     s_next_diff_row = 0;
     s_next_dct_idx = 0;
 }
@@ -117,8 +135,11 @@ void satd8x8_genNew(void)
 {
     for (int i = 0; i < 8 * 8; ++i) s_satd_in[i] = draw_residual();
     uint32_t v = 0;
-    const int rc = xSatd8x8Batch(bdpi_ctx(), s_satd_in, &v, 1);
-    if (rc != X266HIP_OK) die("xSatd8x8Batch", rc);
+    {
+        RandStateGuard guard;
+        const int rc = xSatd8x8Batch(bdpi_ctx(), s_satd_in, &v, 1);
+        if (rc != X266HIP_OK) die("xSatd8x8Batch", rc);
+    }
     s_satd_val = v;
     s_satd_row = 0;
 }
