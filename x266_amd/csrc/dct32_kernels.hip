@@ -200,7 +200,9 @@ __device__ __forceinline__ void inv_block(const v4i &w0, const v4i &w1, const La
 //   persistent : stride = number of waves, resident grid, grid-stride.
 // The next block's loads are issued before the current block's arithmetic
 // (two register sets in ping-pong).
-template <bool INVERSE, bool NT>
+// MODE 0 forward, 1 inverse, 2 pass-through (diagnostic only: same loads, stores and loop,
+// no arithmetic -- measures what the memory system gives this launch shape)
+template <int MODE, bool NT>
 __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ in,
                                                     int16_t *__restrict__ out, size_t n_blocks,
                                                     const DctOps *__restrict__ ops,
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ 
 
     const LaneConsts k = load_consts(ops, lane);
     v16i c2r;
+    constexpr bool INVERSE = MODE == 1;
     if (INVERSE) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) c2r[r] = ops->c2r[lane][r];
@@ -240,8 +243,9 @@ __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ 
             b0 = load16<NT>(src + nb * 2048);
             b1 = load16<NT>(src + nb * 2048 + 16);
         }
-        if (INVERSE) inv_block(a0, a1, k, c2r, o0, o1);
-        else         fwd_block(a0, a1, k, o0, o1);
+        if (MODE == 1)      inv_block(a0, a1, k, c2r, o0, o1);
+        else if (MODE == 0) fwd_block(a0, a1, k, o0, o1);
+        else                { o0 = a0 ^ k.p1; o1 = a1 ^ k.p2; }
         store16<NT>(dst + b * 2048, o0);
         store16<NT>(dst + b * 2048 + 16, o1);
         if (nb >= end) break;
@@ -251,8 +255,9 @@ __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ 
             a0 = load16<NT>(src + nb * 2048);
             a1 = load16<NT>(src + nb * 2048 + 16);
         }
-        if (INVERSE) inv_block(b0, b1, k, c2r, o0, o1);
-        else         fwd_block(b0, b1, k, o0, o1);
+        if (MODE == 1)      inv_block(b0, b1, k, c2r, o0, o1);
+        else if (MODE == 0) fwd_block(b0, b1, k, o0, o1);
+        else                { o0 = b0 ^ k.p1; o1 = b1 ^ k.p2; }
         store16<NT>(dst + b * 2048, o0);
         store16<NT>(dst + b * 2048 + 16, o1);
         if (nb >= end) break;
@@ -282,13 +287,11 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
     }
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs), block(tpb);
-    if (inverse) {
-        if (cfg.nontemporal) hipLaunchKernelGGL((dct32_kernel<true, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, bpw);
-        else                 hipLaunchKernelGGL((dct32_kernel<true, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, bpw);
-    } else {
-        if (cfg.nontemporal) hipLaunchKernelGGL((dct32_kernel<false, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, bpw);
-        else                 hipLaunchKernelGGL((dct32_kernel<false, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, bpw);
-    }
+    const int mode = cfg.passthrough ? 2 : (inverse ? 1 : 0);
+#define X266_LAUNCH(MODE, NT) hipLaunchKernelGGL((dct32_kernel<MODE, NT>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_in, d_out, n_blocks, d_ops, bpw)
+    if (cfg.nontemporal) { if (mode == 0) X266_LAUNCH(0, true); else if (mode == 1) X266_LAUNCH(1, true); else X266_LAUNCH(2, true); }
+    else                 { if (mode == 0) X266_LAUNCH(0, false); else if (mode == 1) X266_LAUNCH(1, false); else X266_LAUNCH(2, false); }
+#undef X266_LAUNCH
     return hipGetLastError();
 }
 

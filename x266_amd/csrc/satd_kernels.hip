@@ -13,7 +13,8 @@
 //      D[m][blk] = sum_s H64[m][s] * d[blk][s]
 // with the int16 samples split into byte planes exactly as in the DCT kernel
 // (d = 256*hi + (lo ^ 0x80) + 128; the +128 only reaches the DC coefficient:
-// 128 * sum_s H[m][s] = 8192 for m = 0, 0 otherwise).  8 MFMAs per 32 blocks.
+// 128 * sum_s H[m][s] = 8192 for m = 0, 0 otherwise).  8 MFMAs per 32 blocks; the
+// +-1 operand images are built in registers from the lane index (no table).
 // Lane l owns block (l & 31) and loads the contiguous 64-byte half (l >> 5) of
 // it; the two halves of a block meet inside the MFMA's K reduction.  The
 // epilogue truncates to int16 by packing, takes |.| of two int16 at once with
@@ -67,7 +68,6 @@ __device__ __forceinline__ uint32_t abs_sum16(const v16i &hi, const v16i &lo, ui
 template <bool NT>
 __global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict__ diff,
                                                       uint32_t *__restrict__ out, size_t n_blocks,
-                                                      const SatdOps *__restrict__ ops,
                                                       unsigned groups_per_wave)
 {
     const int lane = threadIdx.x & 63;
@@ -85,12 +85,28 @@ __global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict_
     }
     if (g >= end) return;
 
-    const v4i h00 = *reinterpret_cast<const v4i *>(ops->a[0][0][lane]);
-    const v4i h01 = *reinterpret_cast<const v4i *>(ops->a[0][1][lane]);
-    const v4i h10 = *reinterpret_cast<const v4i *>(ops->a[1][0][lane]);
-    const v4i h11 = *reinterpret_cast<const v4i *>(ops->a[1][1][lane]);
-
     const int blk = lane & 31, half = lane >> 5;
+
+    // The four +-1 operand images (tile x K-step) of H64[m][s] = (-1)^popcount(m & s) are built
+    // in registers (~25 VALU) instead of being fetched: with one 4 KiB group per wave that would
+    // double the wave's load instructions.  m = 32*tile + blk, s = 32*half + 16*step + t:
+    //   popcount parity splits over disjoint bit ranges, so
+    //   sign = [bits 0-1 of m vs t] ^ [bits 2-3 of m vs t>>2] ^ [bit 4 of m & step] ^ [tile & half]
+    // and negating a +-1 byte is an XOR with 0xFE.
+    v4i h00, h01, h10, h11;
+    {
+        const uint32_t NEG = 0xFEFEFEFEu;
+        const uint32_t m = (uint32_t)blk;
+        const uint32_t inner = (m & 1) ? ((m & 2) ? 0x01FFFF01u : 0xFF01FF01u)     // bytes j = 0..3: (-1)^popcount(m & 3 & j)
+                                       : ((m & 2) ? 0xFFFF0101u : 0x01010101u);
+        const uint32_t f2 = (m & 4) ? NEG : 0u, f3 = (m & 8) ? NEG : 0u;          // dword q flips on popcount((m >> 2) & q)
+        const uint32_t f4 = (m & 16) ? NEG : 0u, fh = half ? NEG : 0u;
+        const uint32_t b0 = inner, b1 = inner ^ f2, b2 = inner ^ f3, b3 = inner ^ f2 ^ f3;
+        h00 = v4i{(int)b0, (int)b1, (int)b2, (int)b3};                             // tile 0, step 0
+        h01 = v4i{(int)(b0 ^ f4), (int)(b1 ^ f4), (int)(b2 ^ f4), (int)(b3 ^ f4)}; // tile 0, step 1: m bit 4 & step
+        h10 = v4i{(int)(b0 ^ fh), (int)(b1 ^ fh), (int)(b2 ^ fh), (int)(b3 ^ fh)}; // tile 1, step 0: m bit 5 & s bit 5
+        h11 = h01 ^ v4i{(int)fh, (int)fh, (int)fh, (int)fh};
+    }
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // DC fix for the byte-plane offset: coefficient m = 0 lives in tile 0, reg 0, half 0
     v16i dcfix = zero;
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(256) void fill_residual_kernel(int16_t *__restrict_
 }  // namespace
 
 hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks,
-                          const SatdOps *d_ops, const LaunchCfg &cfg, hipStream_t stream)
+                          const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
     const size_t groups = (n_blocks + 31) / 32;
@@ -181,8 +197,8 @@ hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_block
     }
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs), block(tpb);
-    if (cfg.nontemporal) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, 0, stream, d_diff, d_out, n_blocks, d_ops, gpw);
-    else                 hipLaunchKernelGGL((satd8x8_kernel<false>), grid, block, 0, stream, d_diff, d_out, n_blocks, d_ops, gpw);
+    if (cfg.nontemporal) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
+    else                 hipLaunchKernelGGL((satd8x8_kernel<false>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
     return hipGetLastError();
 }
 

@@ -35,15 +35,16 @@ struct LaunchCfg {
     int variant;         // 0 = streaming launch (grid covers the batch), 1 = persistent grid-stride
     int units_per_wave;  // streaming launch: consecutive units (DCT blocks / 32-block SATD groups) per wave
     int wg_threads;      // workgroup size, multiple of 64
+    int lds_pad_bytes;   // unused dynamic LDS per workgroup: caps resident waves per CU (fewer bytes in flight)
+    int passthrough;     // diagnostic: skip the arithmetic (timing of the memory pattern only)
 };
 
 struct DctOps;
-struct SatdOps;
 
 hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_blocks,
                         const DctOps *d_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks,
-                          const SatdOps *d_ops, const LaunchCfg &cfg, hipStream_t stream);
+                          const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_fill_residual(int16_t *d_dst, size_t n_samples, uint64_t seed,
                                 uint64_t first_index, const LaunchCfg &cfg, hipStream_t stream);
 

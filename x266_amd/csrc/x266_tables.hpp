@@ -135,32 +135,4 @@ inline void build_inv_ops(DctOps &o)
     }
 }
 
-// ---------------------------------------------------------------------------
-// SATD: 64 x 64 natural-order Hadamard, H[m][s] = (-1)^popcount(m & s), with
-// s = 8*row + col, which equals H8 (x) H8 applied to the 8x8 block.  The
-// reference's butterfly order (src_tb/satd.c:38-103) yields the same
-// coefficients in another order and the cost sums |.| over all of them.
-// Operand images for D[m][blk] = sum_s H[m][s] * d[blk][s]:
-//   const = A (M = coefficient m, two 32-row tiles), data = B (N = block).
-//   K-step st, slot (h,t) <-> s = 32h + 16st + t
-// ---------------------------------------------------------------------------
-struct SatdOps {
-    uint32_t a[2][2][64][4];     // [tile][kstep][lane][4 dwords]
-};
-
-inline void build_satd_ops(SatdOps &o)
-{
-    for (int tile = 0; tile < 2; ++tile)
-        for (int st = 0; st < 2; ++st)
-            for (int l = 0; l < 64; ++l) {
-                const int m = 32 * tile + (l & 31), h = l >> 5;
-                int8_t b[16];
-                for (int t = 0; t < 16; ++t) {
-                    const int s = 32 * h + 16 * st + t;
-                    b[t] = static_cast<int8_t>((__builtin_popcount(m & s) & 1) ? -1 : 1);
-                }
-                for (int q = 0; q < 4; ++q) o.a[tile][st][l][q] = pack4(b + 4 * q);
-            }
-}
-
 }  // namespace x266

@@ -24,7 +24,6 @@ struct x266hip_ctx {
     hipDeviceProp_t prop{};
     DctOps *d_fwd = nullptr;
     DctOps *d_inv = nullptr;
-    SatdOps *d_satd = nullptr;
     // options
     int wgs_per_cu_dct = 8;
     int wgs_per_cu_inv = 5;
@@ -32,8 +31,10 @@ struct x266hip_ctx {
     int nontemporal = 0;
     int dct_variant = 0, satd_variant = 0;          // 0 streaming launch, 1 persistent
     // streaming launch: consecutive units per wave (measured optimum on MI355X, profiles/r01_sweep.txt)
-    int dct_blocks_per_wave = 2, dct_inv_blocks_per_wave = 8, satd_groups_per_wave = 8;
+    int dct_blocks_per_wave = 2, dct_inv_blocks_per_wave = 8, satd_groups_per_wave = 1;
     int wg_threads = 256;
+    int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
+    int passthrough = 0;                            // diagnostic, see x266_device.hpp
     // host-pointer staging (lazily allocated)
     static constexpr int kSlots = 2;
     void *d_stage_in[kSlots] = {nullptr, nullptr};
@@ -72,6 +73,8 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
     c.variant = op == 2 ? ctx->satd_variant : ctx->dct_variant;
     c.units_per_wave = op == 2 ? ctx->satd_groups_per_wave : (op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave);
     c.wg_threads = ctx->wg_threads;
+    c.passthrough = ctx->passthrough;
+    c.lds_pad_bytes = op == 2 ? ctx->lds_pad_satd : (op == 1 ? ctx->lds_pad_inv : ctx->lds_pad_dct);
     return c;
 }
 
@@ -81,7 +84,7 @@ int launch_op(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n,
     switch (op) {
     case 0: e = launch_dct32(false, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_fwd, cfg_for(ctx, 0), s); break;
     case 1: e = launch_dct32(true, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_inv, cfg_for(ctx, 1), s); break;
-    case 2: e = launch_satd8x8((const int16_t *)d_in, (uint32_t *)d_out, n, ctx->d_satd, cfg_for(ctx, 2), s); break;
+    case 2: e = launch_satd8x8((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s); break;
     default: return fail(ctx, X266HIP_EINVAL, "unknown op");
     }
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "kernel launch", e);
@@ -125,11 +128,9 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
         return X266HIP_EDEVICE;
     }
     DctOps *h = new (std::nothrow) DctOps;
-    SatdOps *hs = new (std::nothrow) SatdOps;
-    bool ok = h && hs;
+    bool ok = h != nullptr;
     if (ok) ok = hipMalloc((void **)&ctx->d_fwd, sizeof(DctOps)) == hipSuccess &&
-                 hipMalloc((void **)&ctx->d_inv, sizeof(DctOps)) == hipSuccess &&
-                 hipMalloc((void **)&ctx->d_satd, sizeof(SatdOps)) == hipSuccess;
+                 hipMalloc((void **)&ctx->d_inv, sizeof(DctOps)) == hipSuccess;
     if (ok) {
         build_fwd_ops(*h);
         ok = hipMemcpy(ctx->d_fwd, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
@@ -138,12 +139,7 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
         build_inv_ops(*h);
         ok = hipMemcpy(ctx->d_inv, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
     }
-    if (ok) {
-        build_satd_ops(*hs);
-        ok = hipMemcpy(ctx->d_satd, hs, sizeof(SatdOps), hipMemcpyHostToDevice) == hipSuccess;
-    }
     delete h;
-    delete hs;
     if (!ok) {
         xHipCodecFree(ctx);
         return X266HIP_ENOMEM;
@@ -163,7 +159,6 @@ void xHipCodecFree(x266hip_ctx *ctx)
     }
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
     if (ctx->d_inv) (void)hipFree(ctx->d_inv);
-    if (ctx->d_satd) (void)hipFree(ctx->d_satd);
     delete ctx;
 }
 
@@ -195,6 +190,10 @@ static int *option_slot(x266hip_ctx *ctx, const char *key)
     if (!std::strcmp(key, "dct32_inv_blocks_per_wave")) return &ctx->dct_inv_blocks_per_wave;
     if (!std::strcmp(key, "satd_groups_per_wave")) return &ctx->satd_groups_per_wave;
     if (!std::strcmp(key, "wg_threads")) return &ctx->wg_threads;
+    if (!std::strcmp(key, "diag_passthrough")) return &ctx->passthrough;
+    if (!std::strcmp(key, "dct32_lds_pad_bytes")) return &ctx->lds_pad_dct;
+    if (!std::strcmp(key, "dct32_inv_lds_pad_bytes")) return &ctx->lds_pad_inv;
+    if (!std::strcmp(key, "satd_lds_pad_bytes")) return &ctx->lds_pad_satd;
     return nullptr;
 }
 
@@ -204,6 +203,7 @@ int xHipSetOption(x266hip_ctx *ctx, const char *key, int value)
     if (!slot) return X266HIP_EINVAL;
     if (std::strstr(key, "wgs_per_cu") && (value < 1 || value > 64)) return fail(ctx, X266HIP_EINVAL, "wgs_per_cu out of range");
     if (std::strstr(key, "_per_wave") && (value < 1 || value > 4096)) return fail(ctx, X266HIP_EINVAL, "units per wave out of range");
+    if (std::strstr(key, "lds_pad_bytes") && (value < 0 || value > 160 * 1024)) return fail(ctx, X266HIP_EINVAL, "lds pad out of range");
     if (!std::strcmp(key, "wg_threads") && (value < 64 || value > 256 || value % 64)) return fail(ctx, X266HIP_EINVAL, "wg_threads must be 64, 128, 192 or 256");
     *slot = value;
     return X266HIP_OK;
