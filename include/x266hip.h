@@ -94,6 +94,24 @@ int xDct32InvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out,
  * (src_tb/satd.c:31-118), including its int16 wraparound.  d_out[n] uint32. */
 int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out,
                      size_t n_blocks, void *stream);
+/* Full-search motion estimation with the 8x8 SATD cost (BASELINE configs[2]).
+ * For every 8x8 block of `cur` (block grid aligned to (0,0); width, height
+ * multiples of 8) and every displacement (dx,dy) in [-range, range]^2,
+ *     cost = satd8x8(cur_block - ref_block_at(x+dx, y+dy))      (src_tb/satd.c:31-118)
+ * and d_best[by * (width/8) + bx] receives the minimum; among equal costs the
+ * first candidate in raster order (dy ascending, then dx ascending) wins.
+ * `ref` points at pixel (0,0) of a frame padded by at least `range` pixels on
+ * every side (rows are ref_stride bytes apart; negative offsets are read).
+ * 1 <= range <= 64.  d_costs may be NULL; otherwise it receives every cost,
+ * d_costs[block * (2*range+1)^2 + (dy+range)*(2*range+1) + (dx+range)].
+ * Strides follow src/x266.cpp:419 (intptr_t, in bytes). */
+typedef struct x266_me_result_t {
+    int16_t  mvx, mvy;      /* best displacement */
+    uint32_t cost;          /* its SATD          */
+} x266_me_result_t;
+int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride,
+                      const uint8_t *d_ref, intptr_t ref_stride, int width, int height,
+                      int range, x266_me_result_t *d_best, uint32_t *d_costs, void *stream);
 /* Synthetic residual stream with the reference's stimulus distribution
  * ((rand()&0xFF)-(rand()&0xFF), src_tb/dct32.c:191-193) from a counter-based
  * SplitMix64: sample i = lo8(r) - lo8(r>>8), r = mix(seed+(first_index+i+1)*phi). */

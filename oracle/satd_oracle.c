@@ -72,3 +72,65 @@ void orc_satd8x8_batch_mt(const int16_t *diff, uint32_t *out, size_t n, int thre
     for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
     free(tid); free(job);
 }
+
+/* ------------------------------------------------------------------------- */
+/* Full-search harness around satd8x8 (BASELINE configs[2]).  The per-candidate */
+/* cost is the reference's satd8x8 on the 9-bit difference block; the harness   */
+/* itself (raster candidate order dy-major, first minimum wins, reference frame */
+/* padded by `range`) is this repository's definition -- UNPINNED upstream, see */
+/* include/x266hip.h: xSatd8x8SearchDev.                                        */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    const uint8_t *cur, *ref;
+    ptrdiff_t cs, rs;
+    int w, h, range, by0, by1;
+    int16_t *mv;
+    uint32_t *cost, *costs;
+} me_job_t;
+
+static void *me_worker(void *p)
+{
+    me_job_t *j = (me_job_t *)p;
+    const int bxn = j->w / 8, span = 2 * j->range + 1;
+    for (int by = j->by0; by < j->by1; by++)
+        for (int bx = 0; bx < bxn; bx++) {
+            uint32_t best = 0xFFFFFFFFu;
+            int bdx = 0, bdy = 0;
+            for (int dy = -j->range; dy <= j->range; dy++)
+                for (int dx = -j->range; dx <= j->range; dx++) {
+                    int16_t d[64];
+                    for (int y = 0; y < 8; y++)
+                        for (int x = 0; x < 8; x++)
+                            d[8 * y + x] = (int16_t)((int)j->cur[(by * 8 + y) * j->cs + bx * 8 + x] -
+                                                     (int)j->ref[(by * 8 + y + dy) * j->rs + bx * 8 + x + dx]);
+                    const uint32_t c = orc_satd8x8(d);
+                    if (j->costs)
+                        j->costs[((size_t)by * bxn + bx) * (size_t)(span * span) + (size_t)(dy + j->range) * span + (dx + j->range)] = c;
+                    if (c < best) { best = c; bdx = dx; bdy = dy; }
+                }
+            j->mv[2 * (by * bxn + bx)] = (int16_t)bdx;
+            j->mv[2 * (by * bxn + bx) + 1] = (int16_t)bdy;
+            j->cost[by * bxn + bx] = best;
+        }
+    return NULL;
+}
+
+void orc_satd8x8_search(const uint8_t *cur, ptrdiff_t cur_stride, const uint8_t *ref, ptrdiff_t ref_stride,
+                        int width, int height, int range, int16_t *best_mv, uint32_t *best_cost,
+                        uint32_t *costs, int threads)
+{
+    const int byn = height / 8;
+    if (threads < 1) threads = 1;
+    if (threads > byn) threads = byn;
+    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    me_job_t *job = (me_job_t *)malloc(sizeof(me_job_t) * threads);
+    int done = 0;
+    for (int t = 0; t < threads; t++) {
+        const int cnt = byn / threads + (t < byn % threads ? 1 : 0);
+        job[t] = (me_job_t){cur, ref, cur_stride, ref_stride, width, height, range, done, done + cnt, best_mv, best_cost, costs};
+        done += cnt;
+        pthread_create(&tid[t], NULL, me_worker, &job[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    free(tid); free(job);
+}

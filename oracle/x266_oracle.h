@@ -53,6 +53,13 @@ uint32_t orc_satd8x8(const int16_t diff[64]);
 void orc_satd8x8_batch(const int16_t *diff, uint32_t *out, size_t n_blocks);
 void orc_satd8x8_batch_mt(const int16_t *diff, uint32_t *out, size_t n_blocks, int threads);
 
+/* ---- full-search harness around satd8x8 (BASELINE configs[2]) ---- cost PINNED, harness UNPINNED */
+/* ref points at pixel (0,0) of a frame padded by >= range; candidates in raster
+ * order (dy-major), first minimum wins; best_mv[2*b] = dx, [2*b+1] = dy. */
+void orc_satd8x8_search(const uint8_t *cur, ptrdiff_t cur_stride, const uint8_t *ref, ptrdiff_t ref_stride,
+                        int width, int height, int range, int16_t *best_mv, uint32_t *best_cost,
+                        uint32_t *costs /* NULL or [blocks][(2R+1)^2] */, int threads);
+
 /* ---- BDPI word packing (src_tb/dct32.c:205-246, satd.c:143-147) ---- PINNED */
 void     orc_pack_diff_rows(const int16_t *mat, int first_row, uint32_t res[32]);
 uint64_t orc_pack_dct_word(const int16_t *dct, int idx);

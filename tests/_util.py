@@ -66,6 +66,21 @@ class Oracle:
         self.lib.orc_satd8x8_batch_mt(_P(d.ctypes.data), _P(out.ctypes.data), _SZ(d.shape[0]), threads)
         return out
 
+    def satd_search(self, cur, ref_padded, pad, rng, threads=1, want_costs=False):
+        """cur [H,W] uint8; ref_padded [H+2*pad, W+2*pad] uint8 with pad >= rng."""
+        cur = np.ascontiguousarray(cur, np.uint8)
+        refp = np.ascontiguousarray(ref_padded, np.uint8)
+        h, w = cur.shape
+        nb = (h // 8) * (w // 8)
+        mv = np.empty((nb, 2), np.int16)
+        cost = np.empty(nb, np.uint32)
+        costs = np.empty((nb, (2 * rng + 1) ** 2), np.uint32) if want_costs else None
+        origin = refp.ctypes.data + pad * refp.strides[0] + pad
+        self.lib.orc_satd8x8_search(_P(cur.ctypes.data), ctypes.c_ssize_t(cur.strides[0]), _P(origin),
+                                    ctypes.c_ssize_t(refp.strides[0]), w, h, rng, _P(mv.ctypes.data),
+                                    _P(cost.ctypes.data), _P(costs.ctypes.data if want_costs else None), threads)
+        return mv, cost, costs
+
     def fill_residual(self, n_samples, seed, first_index=0):
         out = np.empty(n_samples, np.int16)
         self.lib.orc_fill_residual(_P(out.ctypes.data), _SZ(n_samples), ctypes.c_uint64(seed),
@@ -157,6 +172,26 @@ def fullrange_np(n_samples, seed, first_index=0):
 def extremes_np(n_samples, seed, first_index=0):
     r = splitmix64(seed, first_index, n_samples)
     return np.where((r >> np.uint64(40)) & np.uint64(1), np.int16(32767), np.int16(-32768)).astype(np.int16)
+
+
+def me_frames(w, h, pad, seed, mv=(3, -2), noise=6):
+    """Synthetic frame pair: smooth-ish random cur; ref = cur displaced by a known global
+    motion vector plus noise, padded by `pad` (edge replication).  uint8."""
+    M = 16                                                            # margin: |mv| <= 16
+    assert max(abs(mv[0]), abs(mv[1])) <= M
+    r = splitmix64(seed, 0, (h + 2 * pad + 2 * M) * (w + 2 * pad + 2 * M))
+    base = (r & np.uint64(0xFF)).astype(np.float64).reshape(h + 2 * pad + 2 * M, w + 2 * pad + 2 * M)
+    k = np.ones(5) / 5.0                                             # separable low-pass so that motion is findable
+    base = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 0, base)
+    base = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 1, base)
+    base = np.clip((base - 128.0) * 3.0 + 128.0, 0, 255)
+    big = base.astype(np.uint8)
+    cur = big[pad + M:pad + M + h, pad + M:pad + M + w].copy()
+    # ref(x + mvx, y + mvy) == cur(x, y)  =>  the best displacement is mv
+    refp = big[M - mv[1]:M - mv[1] + h + 2 * pad, M - mv[0]:M - mv[0] + w + 2 * pad].astype(np.int16)
+    nz = splitmix64(seed + 1, 0, refp.size)
+    refp = refp + ((nz & np.uint64(0xFF)).astype(np.int16).reshape(refp.shape) % (2 * noise + 1) - noise)
+    return cur, np.clip(refp, 0, 255).astype(np.uint8)
 
 
 def dct_edge_blocks():

@@ -1,0 +1,83 @@
+"""GPU (-m gpu): full-search SATD motion estimation (BASELINE configs[2]) through
+xSatd8x8SearchDev against the oracle's brute-force search (per-candidate cost =
+the reference's satd8x8 on the difference block).  Bit-exact costs, identical
+winners including the tie-break."""
+import numpy as np
+import pytest
+
+from _util import me_frames, splitmix64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("w,h,rng,tile_rows", [
+    (64, 16, 4, 2), (64, 48, 8, 1), (64, 48, 8, 2), (64, 48, 8, 4), (136, 72, 16, 2), (136, 72, 16, 4),
+    (72, 40, 1, 2), (200, 24, 33, 2), (8, 8, 5, 2), (128, 64, 64, 2), (24, 136, 64, 4)])
+def test_every_candidate_cost_and_winner(codec, oracle, w, h, rng, tile_rows):
+    pad = rng + 3
+    cur, refp = me_frames(w, h, pad, 100 + w + h + rng, mv=(min(rng, 3), -min(rng, 2)))
+    codec.set_option("me_tile_rows", tile_rows)
+    try:
+        mv, cost, costs = codec.satd_search(cur, refp, pad, rng, want_costs=True)
+    finally:
+        codec.set_option("me_tile_rows", 2)
+    omv, ocost, ocosts = oracle.satd_search(cur, refp, pad, rng, threads=8, want_costs=True)
+    assert np.array_equal(costs, ocosts)                 # all (2R+1)^2 costs of every block
+    assert np.array_equal(cost, ocost)
+    assert np.array_equal(mv, omv)                       # same winner => same tie-break
+
+
+def test_tie_break_is_first_in_raster_order(codec, oracle):
+    """Flat frames: every candidate costs the same, the first one (-R,-R) must win."""
+    w, h, rng, pad = 64, 32, 6, 8
+    cur = np.full((h, w), 77, np.uint8)
+    refp = np.full((h + 2 * pad, w + 2 * pad), 80, np.uint8)
+    mv, cost, _ = codec.satd_search(cur, refp, pad, rng)
+    assert np.all(mv == [-rng, -rng]) and np.all(cost == (3 * 64 + 2) >> 2)
+    omv, ocost, _ = oracle.satd_search(cur, refp, pad, rng)
+    assert np.array_equal(mv, omv) and np.array_equal(cost, ocost)
+
+
+def test_extreme_pixels(codec, oracle):
+    """0/255 checkerboards drive the coefficients to their largest magnitudes."""
+    w, h, rng, pad = 64, 32, 5, 8
+    yy, xx = np.mgrid[0:h, 0:w]
+    cur = np.where((xx + yy) % 2 == 0, 255, 0).astype(np.uint8)
+    r = splitmix64(9, 0, (h + 2 * pad) * (w + 2 * pad))
+    refp = np.where((r >> np.uint64(13)) & np.uint64(1), 255, 0).astype(np.uint8).reshape(h + 2 * pad, w + 2 * pad)
+    mv, cost, costs = codec.satd_search(cur, refp, pad, rng, want_costs=True)
+    omv, ocost, ocosts = oracle.satd_search(cur, refp, pad, rng, threads=4, want_costs=True)
+    assert np.array_equal(costs, ocosts) and np.array_equal(mv, omv) and np.array_equal(cost, ocost)
+    assert costs.max() <= 32640
+
+
+def test_planted_motion_is_found(codec):
+    w, h, rng, pad = 256, 128, 24, 24
+    cur, refp = me_frames(w, h, pad, 4242, mv=(-11, 7), noise=3)
+    mv, cost, _ = codec.satd_search(cur, refp, pad, rng)
+    assert (mv == [-11, 7]).all(axis=1).mean() > 0.95
+
+
+def test_argument_errors(codec):
+    L = codec.L
+    buf = codec.alloc(1 << 16)
+    assert L.xSatd8x8SearchDev(codec.ctx, buf.ptr, 64, buf.ptr, 200, 60, 32, 8, buf.ptr, None, None) < 0    # width % 8
+    assert L.xSatd8x8SearchDev(codec.ctx, buf.ptr, 64, buf.ptr, 200, 64, 32, 65, buf.ptr, None, None) < 0   # range
+    assert L.xSatd8x8SearchDev(codec.ctx, buf.ptr, 64, buf.ptr, 64, 64, 32, 8, buf.ptr, None, None) < 0     # ref stride
+    assert L.xSatd8x8SearchDev(codec.ctx, None, 64, buf.ptr, 200, 64, 32, 8, buf.ptr, None, None) < 0
+
+
+def test_full_frame_4k_sampled(codec, oracle):
+    """BASELINE configs[2] at full size: 3840x2160, window +-64.  The oracle scores a strided
+    sample of block rows (whole-frame brute force is ~2e9 SATDs)."""
+    w, h, rng, pad = 3840, 2160, 64, 64
+    cur, refp = me_frames(w, h, pad, 2160, mv=(5, -3), noise=4)
+    mv, cost, _ = codec.satd_search(cur, refp, pad, rng)
+    assert (mv == [5, -3]).all(axis=1).mean() > 0.9
+    bxn = w // 8
+    for by in (0, 1, 133, 268, 269):                                   # top edge, interior, bottom edge
+        cs = cur[by * 8:by * 8 + 8]
+        rs = refp[by * 8:by * 8 + 8 + 2 * pad]                         # this block row's padded reference stripe
+        omv, ocost, _ = oracle.satd_search(cs, rs, pad, rng, threads=oracle.hw_threads())
+        assert np.array_equal(mv[by * bxn:(by + 1) * bxn], omv)
+        assert np.array_equal(cost[by * bxn:(by + 1) * bxn], ocost)

@@ -56,6 +56,8 @@ def load_library():
     for name in ("xDct32FwdBatchDev", "xDct32InvBatchDev", "xSatd8x8BatchDev"):
         getattr(L, name).argtypes = [_P, _P, _P, _SZ, _P]
     L.xFillResidualDev.argtypes = [_P, _P, _SZ, _U64, _U64, _P]
+    L.xSatd8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, _P, _P, _P]
     for name in ("xDct32FwdBatch", "xDct32InvBatch", "xSatd8x8Batch"):
         getattr(L, name).argtypes = [_P, _P, _P, _SZ]
     L.xHipMalloc.argtypes = [_P, ctypes.POINTER(_P), _SZ]
@@ -195,6 +197,31 @@ class Codec:
 
     def satd8x8_dev(self, d_in, d_out, n_blocks, stream=0):
         self._check(self.L.xSatd8x8BatchDev(self.ctx, d_in, d_out, n_blocks, stream), "xSatd8x8BatchDev")
+
+    def satd_search_dev(self, d_cur, cur_stride, d_ref_origin, ref_stride, width, height, rng, d_best, d_costs=0,
+                        stream=0):
+        self._check(self.L.xSatd8x8SearchDev(self.ctx, d_cur, cur_stride, d_ref_origin, ref_stride, width, height,
+                                             rng, d_best, d_costs or None, stream), "xSatd8x8SearchDev")
+
+    def satd_search(self, cur, ref_padded, pad, rng, want_costs=False):
+        """numpy convenience around xSatd8x8SearchDev: cur [H,W] uint8, ref_padded [H+2*pad, W+2*pad]."""
+        cur = np.ascontiguousarray(cur, np.uint8)
+        refp = np.ascontiguousarray(ref_padded, np.uint8)
+        h, w = cur.shape
+        nb = (h // 8) * (w // 8)
+        ncand = (2 * rng + 1) ** 2
+        dc, dr, db = self.alloc(cur.nbytes), self.alloc(refp.nbytes), self.alloc(nb * 8)
+        dcost = self.alloc(nb * ncand * 4) if want_costs else None
+        dc.upload(cur)
+        dr.upload(refp)
+        self.satd_search_dev(dc.ptr, cur.strides[0], dr.ptr + pad * refp.strides[0] + pad, refp.strides[0], w, h, rng,
+                             db.ptr, dcost.ptr if want_costs else 0)
+        self.stream_sync()
+        raw = db.download(np.uint8, nb * 8)
+        mv = raw.view(np.int16).reshape(nb, 4)[:, :2].copy()
+        cost = raw.view(np.uint32).reshape(nb, 2)[:, 1].copy()
+        costs = dcost.download(np.uint32, nb * ncand).reshape(nb, ncand) if want_costs else None
+        return mv, cost, costs
 
     def fill_residual_dev(self, d_dst, n_samples, seed, first_index=0, stream=0):
         self._check(self.L.xFillResidualDev(self.ctx, d_dst, n_samples, seed, first_index, stream),

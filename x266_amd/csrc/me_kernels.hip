@@ -1,0 +1,291 @@
+// me_kernels.hip -- full-search 8x8 SATD motion estimation for gfx950 (BASELINE
+// configs[2]: 3840x2160 luma, 8x8 blocks, window +-64 => 2.157e9 SATDs / frame).
+//
+// Per-candidate cost is pinned by the reference: satd8x8(cur - ref) with
+// satd8x8 = src_tb/satd.c:31-118 (9-bit differences, as the testbench feeds
+// them, src/mkSatd.bsv:229).  The search harness around it -- candidate
+// order, tie-break, padding -- has no upstream counterpart and is defined in
+// include/x266hip.h (raster order dy-major, first minimum wins).
+//
+// Algorithm.  The Hadamard transform is linear and a 9-bit
+// difference cannot wrap int16 (|coefficient| <= 64*255), so
+//      satd(cur - ref) = (sum_m |Hc[m] - Hr[m]| + 2) >> 2,   Hc = H64*cur, Hr = H64*ref
+// exactly.  Each workgroup owns a tile of 8 x TBY blocks:
+//   1. the reference window of the tile (pixels ^ 0x80, i.e. signed) is staged in
+//      LDS once (<= 30 KB of the CU's 160 KB);
+//   2. Hc of the tile's blocks: one int8 MFMA group, kept in LDS in the lanes' own
+//      fragment order (128 B per block, read back as broadcasts);
+//   3. a wave takes 32 consecutive candidate POSITIONS of one window row, forms
+//      Hr for all 32 with 4 x v_mfma_i32_32x32x32_i8 (pixels are one byte plane;
+//      the -128 offset hits Hc and Hr alike and cancels), packs the 64
+//      coefficients to 16 dwords per lane, and then scores those positions
+//      against every block of the tile whose window contains them: 16 x
+//      v_sad_u16 per block and lane (two |a-b| per instruction).  Blocks are
+//      scored in pairs so that one v_permlane32_swap + add joins the two
+//      coefficient halves of both;
+//   4. running minima are kept as (cost << 16 | candidate index) keys, so one
+//      v_min_u32 implements "lowest cost, then first in raster order".
+// The bound is VALU issue (v_sad_u16), not HBM: the frame pair is ~18 MB.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "x266_device.hpp"
+
+namespace x266 {
+namespace {
+
+constexpr int kTileBlocksX = 8;           // blocks per tile row (64 pixels)
+
+__device__ __forceinline__ uint32_t bperm(uint32_t hi_src, uint32_t lo_src, uint32_t sel)
+{
+    return __builtin_amdgcn_perm(hi_src, lo_src, sel);
+}
+
+__device__ __forceinline__ v16i mfma(const v4i &a, const v4i &b, const v16i &c)
+{
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+}
+
+// +-1 operand images of H64[m][s] = (-1)^popcount(m & s), built from the lane index
+// (same construction as satd_kernels.hip; m = 32*tile + (lane & 31),
+//  s = 32*(lane >> 5) + 16*step + t).
+struct HadamardOps { v4i t0s0, t0s1, t1s0, t1s1; };
+
+__device__ __forceinline__ HadamardOps make_hadamard_ops(int lane)
+{
+    const uint32_t NEG = 0xFEFEFEFEu;
+    const uint32_t m = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5;
+    const uint32_t inner = (m & 1) ? ((m & 2) ? 0x01FFFF01u : 0xFF01FF01u) : ((m & 2) ? 0xFFFF0101u : 0x01010101u);
+    const uint32_t f2 = (m & 4) ? NEG : 0u, f3 = (m & 8) ? NEG : 0u, f4 = (m & 16) ? NEG : 0u, fh = half ? NEG : 0u;
+    const uint32_t b0 = inner, b1 = inner ^ f2, b2 = inner ^ f3, b3 = inner ^ f2 ^ f3;
+    HadamardOps o;
+    o.t0s0 = v4i{(int)b0, (int)b1, (int)b2, (int)b3};
+    o.t0s1 = v4i{(int)(b0 ^ f4), (int)(b1 ^ f4), (int)(b2 ^ f4), (int)(b3 ^ f4)};
+    o.t1s0 = v4i{(int)(b0 ^ fh), (int)(b1 ^ fh), (int)(b2 ^ fh), (int)(b3 ^ fh)};
+    o.t1s1 = o.t0s1 ^ v4i{(int)fh, (int)fh, (int)fh, (int)fh};
+    return o;
+}
+
+// 64 coefficients of 32 windows -> per lane 16 dwords of biased uint16 pairs.
+// b0 / b1: the lane's half of the window, rows (4h, 4h+1) and (4h+2, 4h+3), 8 signed pixels each.
+__device__ __forceinline__ void hadamard_pack(const HadamardOps &H, const v4i &b0, const v4i &b1, uint32_t (&p)[16])
+{
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v16i a0 = mfma(H.t0s0, b0, zero);
+    a0 = mfma(H.t0s1, b1, a0);
+    v16i a1 = mfma(H.t1s0, b0, zero);
+    a1 = mfma(H.t1s1, b1, a1);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        p[k]     = bperm((uint32_t)a0[2 * k + 1], (uint32_t)a0[2 * k], 0x05040100u) ^ 0x80008000u;
+        p[8 + k] = bperm((uint32_t)a1[2 * k + 1], (uint32_t)a1[2 * k], 0x05040100u) ^ 0x80008000u;
+    }
+}
+
+__device__ __forceinline__ uint32_t sad16(const uint32_t (&p)[16], const uint32_t *__restrict__ c, uint32_t init)
+{
+    // c: 16 dwords of this lane's half of a block's coefficients (LDS, broadcast reads)
+    const v4i c0 = *reinterpret_cast<const v4i *>(c), c1 = *reinterpret_cast<const v4i *>(c + 4);
+    const v4i c2 = *reinterpret_cast<const v4i *>(c + 8), c3 = *reinterpret_cast<const v4i *>(c + 12);
+    uint32_t s = init;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s = __builtin_amdgcn_sad_u16(p[k], (uint32_t)c0[k], s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s = __builtin_amdgcn_sad_u16(p[4 + k], (uint32_t)c1[k], s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s = __builtin_amdgcn_sad_u16(p[8 + k], (uint32_t)c2[k], s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s = __builtin_amdgcn_sad_u16(p[12 + k], (uint32_t)c3[k], s);
+    return s;
+}
+
+struct MeParams {
+    const uint8_t *cur;
+    const uint8_t *ref;           // pixel (0,0); valid for x,y in [-range, dim + range)
+    long long cur_stride, ref_stride;
+    int width, height, range;
+    int blocks_x, blocks_y;       // width / 8, height / 8
+    int tiles_x;
+    int n_groups;                 // 32-position groups per window row
+    int n_rows;                   // candidate rows per tile
+    int pitch;                    // LDS bytes per window row
+    x266_me_result_t *best;
+    uint32_t *costs;              // optional [block][(2R+1)^2]
+};
+
+template <int TBY>
+__global__ __launch_bounds__(256) void satd_search_kernel(const MeParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NBLK = kTileBlocksX * TBY;
+    const int R = P.range, span = 2 * R + 1;
+    const int win_rows = P.n_rows + 7;
+    // LDS carve: [coefficients NBLK*128 B][best NBLK*4 B, padded to 128][window win_rows*pitch]
+    uint32_t *c_lds = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *best_lds = reinterpret_cast<uint32_t *>(smem + NBLK * 128);
+    unsigned char *win = smem + NBLK * 128 + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int n = lane & 31, half = lane >> 5;
+    const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
+    const int x0 = tx * (8 * kTileBlocksX), y0 = ty * (8 * TBY);       // tile origin in pixels
+
+    // ---- 1. stage the reference window (signed pixels), 4 bytes per thread step -------------
+    {
+        const int dwords_per_row = P.pitch >> 2;
+        const int total = win_rows * dwords_per_row;
+        for (int i = tid; i < total; i += blockDim.x) {
+            const int ry = i / dwords_per_row, cx = (i - ry * dwords_per_row) * 4;
+            int gy = y0 - R + ry;
+            gy = gy < -R ? -R : (gy > P.height + R - 1 ? P.height + R - 1 : gy);
+            const uint8_t *row = P.ref + (long long)gy * P.ref_stride;
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int gx = x0 - R + cx + b;
+                gx = gx < -R ? -R : (gx > P.width + R - 1 ? P.width + R - 1 : gx);
+                v |= (uint32_t)row[gx] << (8 * b);
+            }
+            reinterpret_cast<uint32_t *>(win)[i] = v ^ 0x80808080u;
+        }
+    }
+    const HadamardOps H = make_hadamard_ops(lane);
+
+    // ---- 2. transform the tile's current blocks (wave 0), initialise the minima ---------------
+    if (tid < NBLK) best_lds[tid] = 0x7FFFFFFFu;
+    if (wave == 0) {
+        const int blk = n < NBLK ? n : NBLK - 1;
+        int bx = tx * kTileBlocksX + (blk % kTileBlocksX), by = ty * TBY + (blk / kTileBlocksX);
+        bx = bx < P.blocks_x ? bx : P.blocks_x - 1;                   // tiles hanging over the frame edge
+        by = by < P.blocks_y ? by : P.blocks_y - 1;
+        const uint8_t *src = P.cur + (long long)(by * 8 + 4 * half) * P.cur_stride + bx * 8;
+        uint32_t w[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint8_t *q = src + (long long)r * P.cur_stride;
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { lo |= (uint32_t)q[b] << (8 * b); hi |= (uint32_t)q[4 + b] << (8 * b); }
+            w[2 * r] = lo ^ 0x80808080u;
+            w[2 * r + 1] = hi ^ 0x80808080u;
+        }
+        uint32_t p[16];
+        hadamard_pack(H, v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, p);
+        if (n < NBLK) {
+            uint32_t *dst = c_lds + (n * 2 + half) * 16;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dst[k] = p[k];
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. candidate rows x position groups, round-robin over the waves ----------------------
+    uint32_t best[TBY][4];
+#pragma unroll
+    for (int j = 0; j < TBY; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) best[j][q] = 0x7FFFFFFFu;
+
+    const uint32_t round_init = half ? 0u : 2u;                        // the "+2" of (sum + 2) >> 2, once per candidate
+    const int sh = (n & 3) * 8;                                        // byte alignment of this lane's window column
+    const int n_items = P.n_rows * P.n_groups;
+    for (int item = wave; item < n_items; item += n_waves) {
+        const int r = item / P.n_groups, g = item - r * P.n_groups;    // wave-uniform
+        // window rows r + 4*half .. +3, columns 32g + n .. +7  (aligned dwords + funnel shift)
+        const unsigned char *base = win + (r + 4 * half) * P.pitch + ((32 * g + n) & ~3);
+        uint32_t px[8];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(base + rr * P.pitch);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+            px[2 * rr]     = __builtin_amdgcn_alignbit(d1, d0, sh);
+            px[2 * rr + 1] = __builtin_amdgcn_alignbit(d2, d1, sh);
+        }
+        uint32_t p[16];
+        hadamard_pack(H, v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]}, v4i{(int)px[4], (int)px[5], (int)px[6], (int)px[7]}, p);
+
+#pragma unroll
+        for (int j = 0; j < TBY; ++j) {
+            const int dyi = r - 8 * j;                                 // candidate row index of block row j
+            if (dyi < 0 || dyi >= span) continue;                      // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int lo0 = 32 * g - 16 * q;                       // dx index of lane 0 for block 2q; block 2q+1: lo0 - 8
+                if (!((lo0 + 31 >= 0 && lo0 < span) || (lo0 + 23 >= 0 && lo0 - 8 < span))) continue;   // wave-uniform
+                const uint32_t *c = c_lds + ((j * kTileBlocksX + 2 * q) * 2 + half) * 16;
+                const uint32_t s0 = sad16(p, c, round_init);           // block 2q,   this lane's coefficient half
+                const uint32_t s1 = sad16(p, c + 32, round_init);      // block 2q+1
+                // lanes 0-31 end with block 2q, lanes 32-63 with block 2q+1, both halves summed
+                const auto sw = __builtin_amdgcn_permlane32_swap(s0, s1, false, false);
+                const uint32_t tot = (uint32_t)sw[0] + (uint32_t)sw[1];
+                const int dxi = lo0 + n - 8 * half;
+                const uint32_t idx = (uint32_t)(dyi * span + dxi);
+                uint32_t key = ((tot >> 2) << 16) | idx;
+                const bool ok = (unsigned)dxi < (unsigned)span;
+                key = ok ? key : 0x7FFFFFFFu;
+                best[j][q] = key < best[j][q] ? key : best[j][q];
+                if (P.costs) {
+                    const int bx = tx * kTileBlocksX + 2 * q + half, by = ty * TBY + j;
+                    if (ok && bx < P.blocks_x && by < P.blocks_y)
+                        P.costs[((size_t)by * P.blocks_x + bx) * (size_t)(span * span) + idx] = tot >> 2;
+                }
+            }
+        }
+    }
+
+    // ---- 4. minima: across the 32 lanes of each half, then across waves (LDS) -----------------
+#pragma unroll
+    for (int j = 0; j < TBY; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t v = best[j][q];
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)v, m);
+                v = o < v ? o : v;
+            }
+            if (n == 0) atomicMin(&best_lds[j * kTileBlocksX + 2 * q + half], v);
+        }
+    __syncthreads();
+    if (tid < NBLK) {
+        const int bx = tx * kTileBlocksX + (tid % kTileBlocksX), by = ty * TBY + (tid / kTileBlocksX);
+        if (bx < P.blocks_x && by < P.blocks_y) {
+            const uint32_t key = best_lds[tid];
+            const int idx = (int)(key & 0xFFFFu);
+            x266_me_result_t res;
+            res.mvx = (int16_t)(idx % span - R);
+            res.mvy = (int16_t)(idx / span - R);
+            res.cost = key >> 16;
+            P.best[(size_t)by * P.blocks_x + bx] = res;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
+                              int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
+                              int tile_rows, hipStream_t stream)
+{
+    MeParams P;
+    P.cur = d_cur; P.ref = d_ref; P.cur_stride = cur_stride; P.ref_stride = ref_stride;
+    P.width = width; P.height = height; P.range = range;
+    P.blocks_x = width / 8; P.blocks_y = height / 8;
+    P.tiles_x = (P.blocks_x + kTileBlocksX - 1) / kTileBlocksX;
+    const int tby = tile_rows == 4 ? 4 : (tile_rows == 1 ? 1 : 2);
+    const int tiles_y = (P.blocks_y + tby - 1) / tby;
+    const int span = 2 * range + 1;
+    P.n_groups = (8 * (kTileBlocksX - 1) + span + 31) / 32;
+    P.n_rows = 8 * (tby - 1) + span;
+    P.pitch = 32 * P.n_groups + 12;
+    P.best = d_best; P.costs = d_costs;
+    const size_t lds = (size_t)kTileBlocksX * tby * 128 + 128 + (size_t)(P.n_rows + 7) * P.pitch;
+    dim3 grid((unsigned)(P.tiles_x * tiles_y)), block(256);
+    if (tby == 4)      hipLaunchKernelGGL((satd_search_kernel<4>), grid, block, lds, stream, P);
+    else if (tby == 1) hipLaunchKernelGGL((satd_search_kernel<1>), grid, block, lds, stream, P);
+    else               hipLaunchKernelGGL((satd_search_kernel<2>), grid, block, lds, stream, P);
+    return hipGetLastError();
+}
+
+}  // namespace x266

@@ -34,6 +34,7 @@ struct x266hip_ctx {
     int dct_blocks_per_wave = 2, dct_inv_blocks_per_wave = 8, satd_groups_per_wave = 1;
     int wg_threads = 256;
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
+    int me_tile_rows = 2;                           // block rows per ME tile (1, 2 or 4)
     int passthrough = 0;                            // diagnostic, see x266_device.hpp
     // host-pointer staging (lazily allocated)
     static constexpr int kSlots = 2;
@@ -191,6 +192,7 @@ static int *option_slot(x266hip_ctx *ctx, const char *key)
     if (!std::strcmp(key, "satd_groups_per_wave")) return &ctx->satd_groups_per_wave;
     if (!std::strcmp(key, "wg_threads")) return &ctx->wg_threads;
     if (!std::strcmp(key, "diag_passthrough")) return &ctx->passthrough;
+    if (!std::strcmp(key, "me_tile_rows")) return &ctx->me_tile_rows;
     if (!std::strcmp(key, "dct32_lds_pad_bytes")) return &ctx->lds_pad_dct;
     if (!std::strcmp(key, "dct32_inv_lds_pad_bytes")) return &ctx->lds_pad_inv;
     if (!std::strcmp(key, "satd_lds_pad_bytes")) return &ctx->lds_pad_satd;
@@ -252,6 +254,23 @@ int xFillResidualDev(x266hip_ctx *ctx, int16_t *d_dst, size_t n_samples, uint64_
     X_HIP(ctx, hipSetDevice(ctx->device));
     hipError_t e = launch_fill_residual(d_dst, n_samples, seed, first_index, cfg_for(ctx, 0), (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fill launch", e);
+    return X266HIP_OK;
+}
+
+int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride, const uint8_t *d_ref,
+                      intptr_t ref_stride, int width, int height, int range, x266_me_result_t *d_best,
+                      uint32_t *d_costs, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (!d_cur || !d_ref || !d_best) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: NULL buffer");
+    if (width < 8 || height < 8 || (width & 7) || (height & 7)) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: frame size must be a multiple of 8");
+    if (range < 1 || range > 64) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: range must be 1..64");
+    if (cur_stride < width || ref_stride < width + 2 * range) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: stride too small");
+    if (((uintptr_t)d_best & 7u) || ((uintptr_t)d_costs & 3u)) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: unaligned output");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_satd_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
+                                      d_best, d_costs, ctx->me_tile_rows, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "search launch", e);
     return X266HIP_OK;
 }
 
