@@ -10,17 +10,22 @@ from _util import me_frames, splitmix64
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("variant,row_pairs", [(1, 1), (2, 1), (2, 2), (2, 3)])
 @pytest.mark.parametrize("w,h,rng,tile_rows", [
     (64, 16, 4, 2), (64, 48, 8, 1), (64, 48, 8, 2), (64, 48, 8, 4), (136, 72, 16, 2), (136, 72, 16, 4),
     (72, 40, 1, 2), (200, 24, 33, 2), (8, 8, 5, 2), (128, 64, 64, 2), (24, 136, 64, 4)])
-def test_every_candidate_cost_and_winner(codec, oracle, w, h, rng, tile_rows):
+def test_every_candidate_cost_and_winner(codec, oracle, w, h, rng, tile_rows, variant, row_pairs):
     pad = rng + 3
     cur, refp = me_frames(w, h, pad, 100 + w + h + rng, mv=(min(rng, 3), -min(rng, 2)))
     codec.set_option("me_tile_rows", tile_rows)
+    codec.set_option("me_variant", variant)
+    codec.set_option("me_row_pairs", row_pairs)
     try:
         mv, cost, costs = codec.satd_search(cur, refp, pad, rng, want_costs=True)
     finally:
-        codec.set_option("me_tile_rows", 2)
+        codec.set_option("me_tile_rows", 4)
+        codec.set_option("me_variant", 2)
+        codec.set_option("me_row_pairs", 1)
     omv, ocost, ocosts = oracle.satd_search(cur, refp, pad, rng, threads=8, want_costs=True)
     assert np.array_equal(costs, ocosts)                 # all (2R+1)^2 costs of every block
     assert np.array_equal(cost, ocost)

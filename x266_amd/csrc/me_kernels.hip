@@ -262,11 +262,213 @@ __global__ __launch_bounds__(256) void satd_search_kernel(const MeParams P)
     }
 }
 
+
+// ============================================================================
+// Variant 2 ("scalar coefficients").  The same 32 columns of two consecutive
+// candidate rows are transformed back to back and their coefficient halves
+// exchanged between the half-waves
+// (16 x v_permlane32_swap), after which EVERY lane owns all 64 coefficients of
+// one position.  All lanes then need the same block coefficients, so those come
+// from SGPRs (scalar loads of a table written by a small pre-pass kernel) and
+// the v_sad_u16 chain takes them as its scalar operand: no LDS traffic and no
+// cross-half reduction in the scoring loop.
+// ============================================================================
+
+// Pre-pass: Hc of every 8x8 block of the current frame, 32 dwords per block in the
+// order the search kernel's lanes hold a position: [coefficient set of half 0][half 1].
+__global__ __launch_bounds__(256) void me_coef_kernel(const uint8_t *__restrict__ cur, long long cur_stride,
+                                                      int blocks_x, int n_blocks, uint32_t *__restrict__ coef)
+{
+    const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+    const int group = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (group * 32 >= n_blocks) return;
+    int blk = group * 32 + n;
+    const bool live = blk < n_blocks;
+    if (!live) blk = n_blocks - 1;
+    const int bx = blk % blocks_x, by = blk / blocks_x;
+    const uint8_t *src = cur + (long long)(by * 8 + 4 * half) * cur_stride + bx * 8;
+    uint32_t w[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint8_t *q = src + (long long)r * cur_stride;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { lo |= (uint32_t)q[b] << (8 * b); hi |= (uint32_t)q[4 + b] << (8 * b); }
+        w[2 * r] = lo ^ 0x80808080u;
+        w[2 * r + 1] = hi ^ 0x80808080u;
+    }
+    const HadamardOps H = make_hadamard_ops(lane);
+    uint32_t p[16];
+    hadamard_pack(H, v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, p);
+    if (live) {
+        v4i *dst = reinterpret_cast<v4i *>(coef + (size_t)blk * 32 + 16 * half);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = v4i{(int)p[4 * k], (int)p[4 * k + 1], (int)p[4 * k + 2], (int)p[4 * k + 3]};
+    }
+}
+
+// window rows r + 4*half .. +3, 8 columns from byte column `col` (aligned dwords + funnel shift)
+__device__ __forceinline__ void load_window(const unsigned char *win, int pitch, int row, int col, int sh, v4i &b0, v4i &b1)
+{
+    const unsigned char *base = win + row * pitch + (col & ~3);
+    uint32_t px[8];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(base + rr * pitch);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        px[2 * rr]     = __builtin_amdgcn_alignbit(d1, d0, sh);
+        px[2 * rr + 1] = __builtin_amdgcn_alignbit(d2, d1, sh);
+    }
+    b0 = v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]};
+    b1 = v4i{(int)px[4], (int)px[5], (int)px[6], (int)px[7]};
+}
+
+// U = row pairs scored per coefficient fetch (each lane then holds U positions): the scalar
+// loads of a block's 32 coefficient dwords are amortised over 32*U v_sad_u16.
+template <int TBY, int U>
+__global__ __launch_bounds__(256) void satd_search_kernel_v2(const MeParams P, const uint32_t *__restrict__ coef)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NBLK = kTileBlocksX * TBY;
+    const int R = P.range, span = 2 * R + 1;
+    const int win_rows = P.n_rows + 7 + 2 * U;
+    uint32_t *best_lds = reinterpret_cast<uint32_t *>(smem);
+    unsigned char *win = smem + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, n_waves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // provably wave-uniform: scalar branches, scalar loads
+    const int n = lane & 31, half = lane >> 5;
+    const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
+    const int x0 = tx * (8 * kTileBlocksX), y0 = ty * (8 * TBY);
+
+    {   // reference window, signed pixels
+        const int dwords_per_row = P.pitch >> 2;
+        const int total = win_rows * dwords_per_row;
+        for (int i = tid; i < total; i += blockDim.x) {
+            const int ry = i / dwords_per_row, cx = (i - ry * dwords_per_row) * 4;
+            int gy = y0 - R + ry;
+            gy = gy < -R ? -R : (gy > P.height + R - 1 ? P.height + R - 1 : gy);
+            const uint8_t *row = P.ref + (long long)gy * P.ref_stride;
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int gx = x0 - R + cx + b;
+                gx = gx < -R ? -R : (gx > P.width + R - 1 ? P.width + R - 1 : gx);
+                v |= (uint32_t)row[gx] << (8 * b);
+            }
+            reinterpret_cast<uint32_t *>(win)[i] = v ^ 0x80808080u;
+        }
+    }
+    if (tid < NBLK) best_lds[tid] = 0x7FFFFFFFu;
+    const HadamardOps H = make_hadamard_ops(lane);
+    __syncthreads();
+
+    uint32_t best[TBY][kTileBlocksX];
+#pragma unroll
+    for (int j = 0; j < TBY; ++j)
+#pragma unroll
+        for (int i = 0; i < kTileBlocksX; ++i) best[j][i] = 0x7FFFFFFFu;
+
+    const int sh = (n & 3) * 8;
+    const int n_strips = (P.n_rows + 2 * U - 1) / (2 * U);             // unit = 2*U consecutive candidate rows x one group
+    const int n_items = n_strips * P.n_groups;
+    const int blocks_left_x = P.blocks_x - tx * kTileBlocksX, blocks_left_y = P.blocks_y - ty * TBY;
+    // after the half exchange lanes 0-31 own the odd row of a pair, lanes 32-63 the even row
+    const int lane_row = half ? 0 : 1;
+    const uint32_t lane_idx = (uint32_t)(lane_row * span + n);
+    for (int item = wave; item < n_items; item += n_waves) {
+        const int strip = item / P.n_groups, g = item - strip * P.n_groups;   // wave-uniform
+        const int r = 2 * U * strip;
+        uint32_t a[U][16], b[U][16];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v4i w0, w1;
+            load_window(win, P.pitch, r + 2 * u + 4 * half, 32 * g + n, sh, w0, w1);
+            hadamard_pack(H, w0, w1, a[u]);
+            load_window(win, P.pitch, r + 2 * u + 1 + 4 * half, 32 * g + n, sh, w0, w1);
+            hadamard_pack(H, w0, w1, b[u]);
+            // exchange halves: every lane now owns all 64 coefficients of one position,
+            // b[u][0..15] = coefficient set of half 0, a[u][0..15] = set of half 1
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(b[u][k], a[u][k], false, false);
+                b[u][k] = (uint32_t)sw[0];
+                a[u][k] = (uint32_t)sw[1];
+            }
+        }
+
+#pragma unroll
+        for (int j = 0; j < TBY; ++j) {
+            const int dy0 = r - 8 * j;                                 // candidate row index of row r for block row j
+            if (dy0 + 2 * U - 1 < 0 || dy0 >= span || j >= blocks_left_y) continue;   // wave-uniform
+#pragma unroll
+            for (int i = 0; i < kTileBlocksX; ++i) {
+                const int lo = 32 * g - 8 * i;                         // dx index of lane 0 for block i
+                if (lo + 31 < 0 || lo >= span || i >= blocks_left_x) continue;       // wave-uniform
+                const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
+                const uint32_t *__restrict__ c = coef + blk * 32;
+                uint32_t s[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) s[u] = 2u;                 // the "+2" of (sum + 2) >> 2
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) s[u] = __builtin_amdgcn_sad_u16(b[u][k], c[k], s[u]);
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) s[u] = __builtin_amdgcn_sad_u16(a[u][k], c[16 + k], s[u]);
+                const bool cols_ok = lo >= 0 && lo + 31 < span;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int dyu = dy0 + 2 * u;
+                    if (dyu + 1 < 0 || dyu >= span) continue;          // wave-uniform: this row pair is outside the window
+                    const uint32_t idx = lane_idx + (uint32_t)(dyu * span + lo);
+                    uint32_t key = ((s[u] << 14) & 0xFFFF0000u) | idx; // (s >> 2) << 16 | candidate index
+                    bool ok = true;
+                    if (!(cols_ok && dyu >= 0 && dyu + 1 < span)) {    // wave-uniform: unit straddles the window edge
+                        ok = (unsigned)(lo + n) < (unsigned)span && (unsigned)(dyu + lane_row) < (unsigned)span;
+                        key = ok ? key : 0x7FFFFFFFu;
+                    }
+                    best[j][i] = key < best[j][i] ? key : best[j][i];
+                    if (P.costs && ok) P.costs[blk * (size_t)(span * span) + idx] = s[u] >> 2;
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TBY; ++j)
+#pragma unroll
+        for (int i = 0; i < kTileBlocksX; ++i) {
+            uint32_t v = best[j][i];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)v, m);
+                v = o < v ? o : v;
+            }
+            if (lane == 0) atomicMin(&best_lds[j * kTileBlocksX + i], v);
+        }
+    __syncthreads();
+    if (tid < NBLK) {
+        const int bx = tx * kTileBlocksX + (tid % kTileBlocksX), by = ty * TBY + (tid / kTileBlocksX);
+        if (bx < P.blocks_x && by < P.blocks_y) {
+            const uint32_t key = best_lds[tid];
+            const int idx = (int)(key & 0xFFFFu);
+            x266_me_result_t res;
+            res.mvx = (int16_t)(idx % span - R);
+            res.mvy = (int16_t)(idx / span - R);
+            res.cost = key >> 16;
+            P.best[(size_t)by * P.blocks_x + bx] = res;
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
                               int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
-                              int tile_rows, hipStream_t stream)
+                              int tile_rows, int variant, int row_pairs, uint32_t *d_coef_scratch, hipStream_t stream)
 {
     MeParams P;
     P.cur = d_cur; P.ref = d_ref; P.cur_stride = cur_stride; P.ref_stride = ref_stride;
@@ -280,8 +482,23 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
     P.n_rows = 8 * (tby - 1) + span;
     P.pitch = 32 * P.n_groups + 12;
     P.best = d_best; P.costs = d_costs;
-    const size_t lds = (size_t)kTileBlocksX * tby * 128 + 128 + (size_t)(P.n_rows + 7) * P.pitch;
     dim3 grid((unsigned)(P.tiles_x * tiles_y)), block(256);
+    if (variant == 2) {
+        const int n_blocks = P.blocks_x * P.blocks_y;
+        const int groups = (n_blocks + 31) / 32;
+        hipLaunchKernelGGL(me_coef_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, stream, d_cur, cur_stride,
+                           P.blocks_x, n_blocks, d_coef_scratch);
+        const int U = row_pairs == 1 ? 1 : (row_pairs == 3 ? 3 : 2);
+        const size_t lds = 128 + (size_t)(P.n_rows + 7 + 2 * U) * P.pitch;   // the last strip may be partly empty
+        const uint32_t *cf = d_coef_scratch;
+#define X266_ME(T, UU) hipLaunchKernelGGL((satd_search_kernel_v2<T, UU>), grid, block, lds, stream, P, cf)
+        if (tby == 4)      { if (U == 1) X266_ME(4, 1); else if (U == 2) X266_ME(4, 2); else X266_ME(4, 3); }
+        else if (tby == 1) { if (U == 1) X266_ME(1, 1); else if (U == 2) X266_ME(1, 2); else X266_ME(1, 3); }
+        else               { if (U == 1) X266_ME(2, 1); else if (U == 2) X266_ME(2, 2); else X266_ME(2, 3); }
+#undef X266_ME
+        return hipGetLastError();
+    }
+    const size_t lds = (size_t)kTileBlocksX * tby * 128 + 128 + (size_t)(P.n_rows + 7) * P.pitch;
     if (tby == 4)      hipLaunchKernelGGL((satd_search_kernel<4>), grid, block, lds, stream, P);
     else if (tby == 1) hipLaunchKernelGGL((satd_search_kernel<1>), grid, block, lds, stream, P);
     else               hipLaunchKernelGGL((satd_search_kernel<2>), grid, block, lds, stream, P);

@@ -34,7 +34,11 @@ struct x266hip_ctx {
     int dct_blocks_per_wave = 2, dct_inv_blocks_per_wave = 8, satd_groups_per_wave = 1;
     int wg_threads = 256;
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
-    int me_tile_rows = 2;                           // block rows per ME tile (1, 2 or 4)
+    int me_tile_rows = 4;                           // block rows per ME tile (1, 2 or 4)
+    int me_row_pairs = 1;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
+    int me_variant = 2;                             // 1 = LDS coefficients, 2 = scalar coefficients (me_kernels.hip)
+    uint32_t *d_me_coef = nullptr;                  // variant 2 scratch: 128 B per 8x8 block of the current frame
+    size_t me_coef_bytes = 0;
     int passthrough = 0;                            // diagnostic, see x266_device.hpp
     // host-pointer staging (lazily allocated)
     static constexpr int kSlots = 2;
@@ -158,6 +162,7 @@ void xHipCodecFree(x266hip_ctx *ctx)
         if (ctx->d_stage_out[i]) (void)hipFree(ctx->d_stage_out[i]);
         if (ctx->stage_stream[i]) (void)hipStreamDestroy(ctx->stage_stream[i]);
     }
+    if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
     if (ctx->d_inv) (void)hipFree(ctx->d_inv);
     delete ctx;
@@ -193,6 +198,8 @@ static int *option_slot(x266hip_ctx *ctx, const char *key)
     if (!std::strcmp(key, "wg_threads")) return &ctx->wg_threads;
     if (!std::strcmp(key, "diag_passthrough")) return &ctx->passthrough;
     if (!std::strcmp(key, "me_tile_rows")) return &ctx->me_tile_rows;
+    if (!std::strcmp(key, "me_variant")) return &ctx->me_variant;
+    if (!std::strcmp(key, "me_row_pairs")) return &ctx->me_row_pairs;
     if (!std::strcmp(key, "dct32_lds_pad_bytes")) return &ctx->lds_pad_dct;
     if (!std::strcmp(key, "dct32_inv_lds_pad_bytes")) return &ctx->lds_pad_inv;
     if (!std::strcmp(key, "satd_lds_pad_bytes")) return &ctx->lds_pad_satd;
@@ -268,8 +275,16 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
     if (cur_stride < width || ref_stride < width + 2 * range) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: stride too small");
     if (((uintptr_t)d_best & 7u) || ((uintptr_t)d_costs & 3u)) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: unaligned output");
     X_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need = (size_t)(width / 8) * (size_t)(height / 8) * 128;
+    if (ctx->me_variant == 2 && need > ctx->me_coef_bytes) {          // grow-only scratch (not stream-ordered: sync first)
+        X_HIP(ctx, hipDeviceSynchronize());
+        if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
+        ctx->d_me_coef = nullptr; ctx->me_coef_bytes = 0;
+        if (hipMalloc((void **)&ctx->d_me_coef, need) != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "ME coefficient scratch");
+        ctx->me_coef_bytes = need;
+    }
     hipError_t e = launch_satd_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
-                                      d_best, d_costs, ctx->me_tile_rows, (hipStream_t)stream);
+                                      d_best, d_costs, ctx->me_tile_rows, ctx->me_variant, ctx->me_row_pairs, ctx->d_me_coef, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "search launch", e);
     return X266HIP_OK;
 }
