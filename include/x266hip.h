@@ -94,6 +94,20 @@ int xDct32InvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out,
  * (src_tb/satd.c:31-118), including its int16 wraparound.  d_out[n] uint32. */
 int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out,
                      size_t n_blocks, void *stream);
+/* The VVC transform set of BASELINE configs[3]: forward 2-D transforms of square N x N
+ * int16 blocks (row-major, N*N samples each), type DCT-II with N in {4, 8, 16, 32} or
+ * DST-VII with N in {4, 8, 16}.  Two passes with partialButterfly32's structure
+ * (src_tb/dct32.c:66-170): rows then columns, shifts log2N-1 and log2N+6, rounding
+ * half up, truncating int16 stores; the DCT-II matrices are the sub-matrices of g_t32
+ * that src/mkDct32.bsv:132-141 taps.  Only (DCT-II, 32) is pinned by upstream.
+ * d_offsets == NULL: block b lives at sample offset b*N*N in both buffers.
+ * d_offsets != NULL: block b lives at sample offset d_offsets[b] (a multiple of 8) in
+ * both buffers -- the per-CTU mixed batches: one call per (type, size) class over a
+ * shared residual / coefficient buffer pair. */
+#define X266_TR_DCT2 0
+#define X266_TR_DST7 1
+int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d_in, int16_t *d_out,
+                          size_t n_blocks, const uint32_t *d_offsets, void *stream);
 /* Full-search motion estimation with the 8x8 SATD cost (BASELINE configs[2]).
  * For every 8x8 block of `cur` (block grid aligned to (0,0); width, height
  * multiples of 8) and every displacement (dx,dy) in [-range, range]^2,

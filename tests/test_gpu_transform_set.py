@@ -1,0 +1,100 @@
+"""GPU (-m gpu): the VVC transform set of BASELINE configs[3] through
+xTransformFwdBatchDev, bit-exact against the oracle (DCT-II 4/8/16/32, DST-VII
+4/8/16; contiguous batches and per-CTU mixed batches placed by offset tables)."""
+import numpy as np
+import pytest
+
+from _util import extremes_np, fullrange_np, residual_np, splitmix64
+
+pytestmark = pytest.mark.gpu
+
+CLASSES = [(0, 4), (0, 8), (0, 16), (0, 32), (1, 4), (1, 8), (1, 16)]
+
+
+@pytest.mark.parametrize("ttype,n", CLASSES)
+def test_contiguous_batches(codec, oracle, ttype, n):
+    per = n * n
+    x = np.concatenate([residual_np(3001 * per, 50 + n), fullrange_np(2000 * per, 51 + n),
+                        extremes_np(500 * per, 52 + n)]).reshape(-1, per)
+    assert np.array_equal(codec.transform_fwd(ttype, n, x), oracle.transform_fwd(ttype, n, x))
+
+
+@pytest.mark.parametrize("ttype,n", [c for c in CLASSES if c[1] < 32])
+@pytest.mark.parametrize("count", [1, 2, 3, 5, 15, 16, 17, 63, 64, 65, 127, 129])
+def test_ragged_counts(codec, oracle, ttype, n, count):
+    x = fullrange_np(count * n * n, 900 + count + n).reshape(count, n * n)
+    assert np.array_equal(codec.transform_fwd(ttype, n, x), oracle.transform_fwd(ttype, n, x))
+
+
+def test_edge_blocks(codec, oracle):
+    for ttype, n in CLASSES:
+        per = n * n
+        blocks = [np.zeros(per), np.full(per, 255), np.full(per, -256), np.full(per, 32767), np.full(per, -32768),
+                  np.where(np.arange(per) % 2 == 0, 32767, -32768), (np.arange(per) % n) * 7 - (np.arange(per) // n) * 3]
+        x = np.stack(blocks).astype(np.int16)
+        assert np.array_equal(codec.transform_fwd(ttype, n, x), oracle.transform_fwd(ttype, n, x)), (ttype, n)
+
+
+def _random_ctu_partition(rng_state, n_ctus):
+    """Each 64x64 CTU (4096 residual samples, TU-major layout) is cut into a random mix of
+    square transform units; returns per-class offset lists (sample offsets into one flat buffer)."""
+    r = splitmix64(rng_state, 0, n_ctus * 64)
+    offsets = {c: [] for c in CLASSES}
+    pos, k = 0, 0
+    for ctu in range(n_ctus):
+        base, used = ctu * 4096, 0
+        while used < 4096:
+            pick = int(r[k % len(r)] % 7); k += 1
+            ttype, n = CLASSES[pick]
+            if used + n * n > 4096:
+                ttype, n = 0, 4                                         # fill the remainder with 4x4 DCT units
+            offsets[(ttype, n)].append(base + used)
+            used += n * n
+    return offsets
+
+
+def test_mixed_per_ctu_batches(codec, oracle):
+    """configs[3]: one residual buffer of CTUs, every TU class transformed by its own call
+    over an offset table; the whole coefficient buffer must equal the oracle's."""
+    n_ctus = 300
+    x = np.concatenate([residual_np(n_ctus * 2048, 77), fullrange_np(n_ctus * 2048, 78)])
+    offsets = _random_ctu_partition(1234, n_ctus)
+    assert sum(len(v) * c[1] * c[1] for c, v in offsets.items()) == n_ctus * 4096
+    want = np.zeros_like(x)
+    got = np.zeros_like(x)
+    din, dout = codec.alloc(x.nbytes), codec.alloc(x.nbytes)
+    din.upload(x)
+    dout.upload(got)
+    keep = []
+    for (ttype, n), offs in offsets.items():
+        if not offs:
+            continue
+        offs = np.array(offs, np.uint32)
+        idx = offs[:, None] + np.arange(n * n, dtype=np.uint32)[None, :]
+        want[idx] = oracle.transform_fwd(ttype, n, x[idx])
+        if n == 32:                                                    # 32x32 units of a CTU are gathered first
+            blocks = np.ascontiguousarray(x[idx])
+            got32 = codec.transform_fwd(0, 32, blocks)
+            assert np.array_equal(got32, want[idx])
+            continue
+        doff = codec.alloc(offs.nbytes)
+        doff.upload(offs)
+        keep.append(doff)
+        codec.transform_fwd_dev(ttype, n, din.ptr, dout.ptr, len(offs), doff.ptr)
+    codec.stream_sync()
+    got = dout.download(np.int16, x.size)
+    for (ttype, n), offs in offsets.items():
+        if n == 32 or not offs:
+            continue
+        idx = np.array(offs, np.uint32)[:, None] + np.arange(n * n, dtype=np.uint32)[None, :]
+        assert np.array_equal(got[idx], want[idx]), (ttype, n)
+
+
+def test_argument_errors(codec):
+    L = codec.L
+    buf = codec.alloc(1 << 16)
+    assert L.xTransformFwdBatchDev(codec.ctx, 0, 5, buf.ptr, buf.ptr + 4096, 4, None, None) < 0
+    assert L.xTransformFwdBatchDev(codec.ctx, 1, 32, buf.ptr, buf.ptr + 4096, 1, None, None) < 0      # no DST-VII 32
+    assert L.xTransformFwdBatchDev(codec.ctx, 2, 8, buf.ptr, buf.ptr + 4096, 4, None, None) < 0
+    assert L.xTransformFwdBatchDev(codec.ctx, 0, 8, None, buf.ptr, 4, None, None) < 0
+    assert L.xTransformFwdBatchDev(codec.ctx, 0, 8, None, None, 0, None, None) == 0

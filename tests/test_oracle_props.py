@@ -87,3 +87,39 @@ def test_prng_twins(oracle):
     r = residual_np(200000, 1)
     assert r.min() >= -255 and r.max() <= 255 and abs(float(r.mean())) < 1.0
     assert splitmix64(0, 0, 1)[0] == np.uint64(0xE220A8397B1DCDAF)           # SplitMix64 reference value
+
+
+# ---- VVC transform set (BASELINE configs[3]) ---------------------------------------------
+def test_transform_set_matrices(oracle):
+    g = oracle.table()
+    for n in (4, 8, 16, 32):
+        m = oracle.transform_matrix(0, n)
+        assert np.array_equal(m, g[:: 32 // n, :n])                    # sub-matrices of g_t32
+    assert oracle.transform_matrix(1, 4).tolist() == [[29, 55, 74, 84], [74, 74, 0, -74], [84, -29, -74, 55],
+                                                      [55, -84, 74, -29]]      # the VVC DST-VII 4-point table
+    for n in (4, 8, 16):
+        k, c = np.arange(n)[:, None], np.arange(n)[None, :]
+        want = np.round(64 * np.sqrt(n) * np.sqrt(4.0 / (2 * n + 1)) * np.sin(np.pi * (2 * k + 1) * (c + 1) / (2 * n + 1)))
+        m = oracle.transform_matrix(1, n)
+        assert np.array_equal(m, want.astype(np.int16))
+        assert np.abs(m).max() <= 90                                   # fits the int8 matrix core
+        gram = m.astype(np.int64) @ m.T.astype(np.int64)
+        assert np.abs(gram - np.diag(np.diag(gram))).max() < 0.01 * np.diag(gram).min()
+
+
+def test_transform_set_generic_equals_pinned_dct32(oracle):
+    x = np.concatenate([residual_np(40 * 1024, 31), fullrange_np(40 * 1024, 32)]).reshape(-1, 1024)
+    assert np.array_equal(oracle.transform_fwd(0, 32, x), oracle.dct32_fwd(x))
+
+
+def test_transform_set_matches_numpy(oracle):
+    for ttype in (0, 1):
+        for n in (4, 8, 16):
+            m = oracle.transform_matrix(ttype, n).astype(np.int64)
+            s1, s2 = int(np.log2(n)) - 1, int(np.log2(n)) + 6
+            x = fullrange_np(6 * n * n, 40 + n).reshape(6, n, n)
+            out = oracle.transform_fwd(ttype, n, x).reshape(6, n, n)
+            for b in range(6):
+                y = ((np.einsum("kc,jc->kj", m, x[b].astype(np.int64)) + (1 << (s1 - 1))) >> s1).astype(np.int16)
+                z = ((np.einsum("vj,kj->vk", m, y.astype(np.int64)) + (1 << (s2 - 1))) >> s2).astype(np.int16)
+                assert np.array_equal(out[b], z)

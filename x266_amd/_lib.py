@@ -56,6 +56,7 @@ def load_library():
     for name in ("xDct32FwdBatchDev", "xDct32InvBatchDev", "xSatd8x8BatchDev"):
         getattr(L, name).argtypes = [_P, _P, _P, _SZ, _P]
     L.xFillResidualDev.argtypes = [_P, _P, _SZ, _U64, _U64, _P]
+    L.xTransformFwdBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
     L.xSatd8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, _P, _P, _P]
     for name in ("xDct32FwdBatch", "xDct32InvBatch", "xSatd8x8Batch"):
@@ -197,6 +198,30 @@ class Codec:
 
     def satd8x8_dev(self, d_in, d_out, n_blocks, stream=0):
         self._check(self.L.xSatd8x8BatchDev(self.ctx, d_in, d_out, n_blocks, stream), "xSatd8x8BatchDev")
+
+    def transform_fwd_dev(self, ttype, size, d_in, d_out, n_blocks, d_offsets=0, stream=0):
+        self._check(self.L.xTransformFwdBatchDev(self.ctx, ttype, size, d_in, d_out, n_blocks, d_offsets or None, stream),
+                    "xTransformFwdBatchDev")
+
+    def transform_fwd(self, ttype, size, x, offsets=None, buf_samples=None):
+        """numpy convenience: contiguous blocks [n, size*size], or (offsets given) a flat sample
+        buffer `x` of which the blocks at `offsets` are transformed in place layout."""
+        x = np.ascontiguousarray(x, np.int16)
+        if offsets is None:
+            n = x.size // (size * size)
+            din, dout = self.alloc(max(x.nbytes, 16)), self.alloc(max(x.nbytes, 16))
+            din.upload(x)
+            self.transform_fwd_dev(ttype, size, din.ptr, dout.ptr, n)
+            self.stream_sync()
+            return dout.download(np.int16, x.size).reshape(n, size * size)
+        offsets = np.ascontiguousarray(offsets, np.uint32)
+        din, dout, doff = self.alloc(x.nbytes), self.alloc(x.nbytes), self.alloc(max(offsets.nbytes, 16))
+        din.upload(x)
+        dout.upload(np.zeros_like(x))
+        doff.upload(offsets)
+        self.transform_fwd_dev(ttype, size, din.ptr, dout.ptr, offsets.size, doff.ptr)
+        self.stream_sync()
+        return dout.download(np.int16, x.size)
 
     def satd_search_dev(self, d_cur, cur_stride, d_ref_origin, ref_stride, width, height, rng, d_best, d_costs=0,
                         stream=0):

@@ -1,0 +1,113 @@
+// transform_kernels.hip -- forward DCT-II 4/8/16 and DST-VII 4/8/16 for gfx950
+// (BASELINE configs[3]: the mixed VVC transform set).
+//
+// Reference anchor: the N-point DCT-II matrices are sub-matrices of g_t32
+// (src_tb/dct32.c:30-64; the RTL re-uses the adder-tree taps for 4/8/16,
+// src/mkDct32.bsv:132-141) and the pass structure / rounding / truncating store
+// are partialButterfly32's (src_tb/dct32.c:66-170) with shifts log2N-1 and
+// log2N+6.  Upstream has no C model for these sizes nor any DST-VII: parity is
+// UNPINNED and rests on the CPU statement kept with the tests.
+//
+// Mapping: (32/N)^2 small blocks form one 32x32 tile; transforming the tile with
+// the block-diagonal matrix diag(M_N,...) on both sides transforms every small
+// block on its own.  The tile runs through exactly the two-pass int8-MFMA
+// pipeline of dct32_kernels.hip (x266_mfma_blocks.hpp); only the lane -> address
+// pattern and the operand images differ.  Blocks are N x N int16 row-major and
+// either contiguous (block b at b*N*N samples) or placed by a per-block offset
+// table (the mixed per-CTU batches of configs[3]).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "x266_device.hpp"
+#include "x266_mfma_blocks.hpp"
+#include "x266_tables.hpp"
+
+namespace x266 {
+namespace {
+
+template <int LOGN, bool INDEXED>
+__global__ __launch_bounds__(256) void tr_fwd_small_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
+                                                           size_t n_blocks, const DctOps *__restrict__ ops,
+                                                           const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int PER = 32 / N;                 // small blocks per tile edge
+    constexpr int PIECES = 16 / N;              // small-block rows per lane (a lane holds 16 samples of a tile row)
+    constexpr int NSB = PER * PER;              // small blocks per tile
+    constexpr int S1 = LOGN - 1, S2 = LOGN + 6;
+
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_tiles = (n_blocks + NSB - 1) / NSB;
+    size_t t = wave * tiles_per_wave;
+    const size_t t_end = t + tiles_per_wave < n_tiles ? t + tiles_per_wave : n_tiles;
+    if (t >= t_end) return;
+    const LaneConsts k = load_consts(ops, lane);
+    const int row = c & (N - 1), tile_row = c >> LOGN;
+
+    for (; t < t_end; ++t) {
+        const size_t first = t * NSB + (size_t)tile_row * PER + (size_t)h * PIECES;
+        uint32_t w[8];
+        size_t off[PIECES];
+        bool live[PIECES];
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            size_t blk = first + q;
+            live[q] = blk < n_blocks;
+            if (!live[q]) blk = n_blocks - 1;                              // ragged tail: re-read the last block
+            const size_t base = INDEXED ? (size_t)offsets[blk] : blk * (size_t)(N * N);
+            off[q] = (base + (size_t)row * N) * 2;                         // bytes
+            const char *p = reinterpret_cast<const char *>(in) + off[q];
+            if (N == 16) {
+                const v4i a = *reinterpret_cast<const v4i *>(p), b = *reinterpret_cast<const v4i *>(p + 16);
+                w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = b[0]; w[5] = b[1]; w[6] = b[2]; w[7] = b[3];
+            } else if (N == 8) {
+                const v4i a = *reinterpret_cast<const v4i *>(p);
+                w[4 * q] = a[0]; w[4 * q + 1] = a[1]; w[4 * q + 2] = a[2]; w[4 * q + 3] = a[3];
+            } else {
+                const uint2 a = *reinterpret_cast<const uint2 *>(p);
+                w[2 * q] = a.x; w[2 * q + 1] = a.y;
+            }
+        }
+        v4i o0, o1;
+        fwd_block<S1, S2>(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, k, o0, o1);
+        const uint32_t z[8] = {(uint32_t)o0[0], (uint32_t)o0[1], (uint32_t)o0[2], (uint32_t)o0[3],
+                               (uint32_t)o1[0], (uint32_t)o1[1], (uint32_t)o1[2], (uint32_t)o1[3]};
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            if (!live[q]) continue;
+            char *p = reinterpret_cast<char *>(out) + off[q];
+            if (N == 16) {
+                *reinterpret_cast<v4i *>(p) = o0;
+                *reinterpret_cast<v4i *>(p + 16) = o1;
+            } else if (N == 8) {
+                *reinterpret_cast<v4i *>(p) = v4i{(int)z[4 * q], (int)z[4 * q + 1], (int)z[4 * q + 2], (int)z[4 * q + 3]};
+            } else {
+                *reinterpret_cast<uint2 *>(p) = make_uint2(z[2 * q], z[2 * q + 1]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
+                                  const uint32_t *d_offsets, const LaunchCfg &cfg, hipStream_t stream)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const size_t per_tile = (size_t)(32 >> log2n) * (size_t)(32 >> log2n);
+    const size_t tiles = (n_blocks + per_tile - 1) / per_tile;
+    const unsigned tpw = cfg.units_per_wave < 1 ? 1u : (unsigned)cfg.units_per_wave;
+    const size_t waves = (tiles + tpw - 1) / tpw;
+    const size_t wgs = (waves + 3) / 4;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)wgs), block(256);
+#define X266_TR(L) do { if (d_offsets) hipLaunchKernelGGL((tr_fwd_small_kernel<L, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
+                        else           hipLaunchKernelGGL((tr_fwd_small_kernel<L, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
+    if (log2n == 2) X266_TR(2); else if (log2n == 3) X266_TR(3); else if (log2n == 4) X266_TR(4); else return hipErrorInvalidValue;
+#undef X266_TR
+    return hipGetLastError();
+}
+
+}  // namespace x266

@@ -1,0 +1,116 @@
+// x266_mfma_blocks.hpp -- device-side building blocks shared by the transform kernels:
+// byte-plane split / re-pack around v_mfma_i32_32x32x32_i8 and the two-pass forward
+// transform of one 32x32 tile held in registers (see dct32_kernels.hip for the derivation).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "x266_device.hpp"
+#include "x266_tables.hpp"
+
+namespace x266 {
+
+// ---- byte-plane helpers ----------------------------------------------------
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {hi_src, lo_src}
+// (indices 0-3 = lo_src, 4-7 = hi_src).
+__device__ __forceinline__ uint32_t bperm(uint32_t hi_src, uint32_t lo_src, uint32_t sel)
+{
+    return __builtin_amdgcn_perm(hi_src, lo_src, sel);
+}
+
+// 8 dwords of int16 pairs -> 4 dwords of low bytes (offset to signed) + 4 of high bytes
+__device__ __forceinline__ void split_planes(const v4i &w0, const v4i &w1, v4i &lo, v4i &hi)
+{
+    const uint32_t w[8] = {(uint32_t)w0[0], (uint32_t)w0[1], (uint32_t)w0[2], (uint32_t)w0[3],
+                           (uint32_t)w1[0], (uint32_t)w1[1], (uint32_t)w1[2], (uint32_t)w1[3]};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        lo[p] = (int)(bperm(w[2 * p + 1], w[2 * p], 0x06040200u) ^ 0x80808080u);
+        hi[p] = (int)bperm(w[2 * p + 1], w[2 * p], 0x07050301u);
+    }
+}
+
+// 16 int32 whose bytes 0/1 hold the wanted low/high byte -> byte planes
+__device__ __forceinline__ void pack_planes(const v16i &s, v4i &lo, v4i &hi)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t t01 = bperm((uint32_t)s[4 * q + 1], (uint32_t)s[4 * q + 0], 0x05010400u);
+        const uint32_t t23 = bperm((uint32_t)s[4 * q + 3], (uint32_t)s[4 * q + 2], 0x05010400u);
+        lo[q] = (int)(bperm(t23, t01, 0x05040100u) ^ 0x80808080u);
+        hi[q] = (int)bperm(t23, t01, 0x07060302u);
+    }
+}
+
+// 16 int32 holding one signed byte value each (byte 0) -> one plane of 4 dwords
+__device__ __forceinline__ v4i pack_bytes(const v16i &s)
+{
+    v4i r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t t01 = bperm((uint32_t)s[4 * q + 1], (uint32_t)s[4 * q + 0], 0x0c0c0400u);
+        const uint32_t t23 = bperm((uint32_t)s[4 * q + 3], (uint32_t)s[4 * q + 2], 0x0c0c0400u);
+        r[q] = (int)bperm(t23, t01, 0x05040100u);
+    }
+    return r;
+}
+
+__device__ __forceinline__ v16i mfma(const v4i &a, const v4i &b, const v16i &c)
+{
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+}
+
+struct LaneConsts {
+    v4i p1, p2, tr;
+    int c1, c2;
+};
+
+__device__ __forceinline__ LaneConsts load_consts(const DctOps *ops, int lane)
+{
+    LaneConsts k;
+    const DctLaneOps *r = &ops->lane[lane];
+    k.p1 = *reinterpret_cast<const v4i *>(r->p1);
+    k.p2 = *reinterpret_cast<const v4i *>(r->p2);
+    k.tr = *reinterpret_cast<const v4i *>(r->tr);
+    k.c1 = r->c1;
+    k.c2 = r->c2;
+    return k;
+}
+
+// ---- forward: one block held as (w0, w1) -> (o0, o1) ------------------------
+template <int S1, int S2>
+__device__ __forceinline__ void fwd_block(const v4i &w0, const v4i &w1, const LaneConsts &k,
+                                          v4i &o0, v4i &o1)
+{
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v4i lo, hi;
+    split_planes(w0, w1, lo, hi);
+
+    // pass 1 (rows): data = A, coefficients = B
+    v16i acc = mfma(hi, k.p1, zero);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)k.c1);
+    acc = mfma(lo, k.p1, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc[r] >> S1;        // bytes 0/1 = int16 result
+    v4i ylo, yhi;
+    pack_planes(acc, ylo, yhi);
+
+    // pass 2 (columns): data = A (pass-1 accumulators re-packed), coefficients = B
+    acc = mfma(yhi, k.p2, zero);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)k.c2);
+    acc = mfma(ylo, k.p2, acc);
+
+    // (acc >> S2) truncated to int16, pairs packed into dwords
+    uint32_t z[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        z[m] = bperm((uint32_t)(acc[2 * m + 1] >> S2), (uint32_t)(acc[2 * m] >> S2), 0x05040100u);
+    o0 = v4i{(int)z[0], (int)z[1], (int)z[2], (int)z[3]};
+    o1 = v4i{(int)z[4], (int)z[5], (int)z[6], (int)z[7]};
+}
+
+}  // namespace x266

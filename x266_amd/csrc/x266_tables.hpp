@@ -135,4 +135,102 @@ inline void build_inv_ops(DctOps &o)
     }
 }
 
+// ---------------------------------------------------------------------------
+// The VVC transform set beyond DCT-II 32 (BASELINE configs[3]; parity UNPINNED
+// upstream -- DESIGN.md section 10).
+//  * DCT-II N = 4, 8, 16: rows 0, 32/N, 2*32/N, ... of g_t32 restricted to the
+//    first N columns (the taps mkDct32Core re-uses, src/mkDct32.bsv:132-141).
+//  * DST-VII N = 4, 8, 16: round(64*sqrt(N)*sqrt(4/(2N+1))*sin(pi(2k+1)(n+1)/(2N+1)));
+//    for N = 4 this is the VVC table {29,55,74,84,...}.  Stored as literals so
+//    that no floating point runs in the product.
+// A group of (32/N)^2 small blocks is transformed as ONE 32x32 tile with the
+// block-diagonal matrix diag(M_N, ..., M_N) on both sides, which yields every
+// small block's own 2-D transform -- so the 32x32 MFMA pipeline is reused as is.
+// ---------------------------------------------------------------------------
+constexpr int8_t kDst7_4[16] = {
+     29,  55,  74,  84,
+     74,  74,   0, -74,
+     84, -29, -74,  55,
+     55, -84,  74, -29,
+};
+constexpr int8_t kDst7_8[64] = {
+     16,  32,  46,  59,  70,  79,  84,  87,
+     46,  79,  87,  70,  32, -16, -59, -84,
+     70,  84,  32, -46, -87, -59,  16,  79,
+     84,  46, -59, -79,  16,  87,  32, -70,
+     87, -16, -84,  32,  79, -46, -70,  59,
+     79, -70, -16,  84, -59, -32,  87, -46,
+     59, -87,  70, -16, -46,  84, -79,  32,
+     32, -59,  79, -87,  84, -70,  46, -16,
+};
+constexpr int8_t kDst7_16[256] = {
+      8,  17,  25,  33,  41,  48,  55,  62,  67,  73,  77,  81,  84,  87,  88,  89,
+     25,  48,  67,  81,  88,  88,  81,  67,  48,  25,   0, -25, -48, -67, -81, -88,
+     41,  73,  88,  84,  62,  25, -17, -55, -81, -89, -77, -48,  -8,  33,  67,  87,
+     55,  87,  81,  41, -17, -67, -89, -73, -25,  33,  77,  88,  62,   8, -48, -84,
+     67,  88,  48, -25, -81, -81, -25,  48,  88,  67,   0, -67, -88, -48,  25,  81,
+     77,  77,   0, -77, -77,   0,  77,  77,   0, -77, -77,   0,  77,  77,   0, -77,
+     84,  55, -48, -87,  -8,  81,  62, -41, -88, -17,  77,  67, -33, -89, -25,  73,
+     88,  25, -81, -48,  67,  67, -48, -81,  25,  88,   0, -88, -25,  81,  48, -67,
+     89,  -8, -88,  17,  87, -25, -84,  33,  81, -41, -77,  48,  73, -55, -67,  62,
+     87, -41, -67,  73,  33, -88,   8,  84, -48, -62,  77,  25, -89,  17,  81, -55,
+     81, -67, -25,  88, -48, -48,  88, -25, -67,  81,   0, -81,  67,  25, -88,  48,
+     73, -84,  25,  55, -89,  48,  33, -87,  67,   8, -77,  81, -17, -62,  88, -41,
+     62, -89,  67,  -8, -55,  88, -73,  17,  48, -87,  77, -25, -41,  84, -81,  33,
+     48, -81,  88, -67,  25,  25, -67,  88, -81,  48,   0, -48,  81, -88,  67, -25,
+     33, -62,  81, -89,  84, -67,  41,  -8, -25,  55, -77,  88, -87,  73, -48,  17,
+     17, -33,  48, -62,  73, -81,  87, -89,  88, -84,  77, -67,  55, -41,  25,  -8,
+};
+
+enum TransformType { kTrDct2 = 0, kTrDst7 = 1 };
+
+struct Matrix32 { int8_t v[32][32]; };
+
+// block-diagonal 32x32 matrix of the N-point transform `type`; N = 32 is g_t32 itself
+inline Matrix32 make_transform_matrix(int type, int n)
+{
+    constexpr Table32 g = make_table32();
+    Matrix32 m{};
+    for (int k = 0; k < 32; ++k)
+        for (int c = 0; c < 32; ++c) {
+            int v = 0;
+            if (k / n == c / n) {
+                const int kk = k % n, cc = c % n;
+                if (type == kTrDct2) v = g.v[kk * (32 / n)][cc];
+                else v = n == 4 ? kDst7_4[kk * 4 + cc] : (n == 8 ? kDst7_8[kk * 8 + cc] : kDst7_16[kk * 16 + cc]);
+            }
+            m.v[k][c] = static_cast<int8_t>(v);
+        }
+    return m;
+}
+
+// Forward operand images for an arbitrary 32x32 int8 matrix and shift pair
+// (same construction as build_fwd_ops; the byte-plane offset fix uses the row sums).
+inline void build_fwd_ops_general(DctOps &o, const Matrix32 &m, int shift1, int shift2)
+{
+    int rowsum[32] = {};
+    for (int k = 0; k < 32; ++k)
+        for (int c = 0; c < 32; ++c) rowsum[k] += m.v[k][c];
+    for (int l = 0; l < 64; ++l) {
+        const int c = l & 31, h = l >> 5;
+        int8_t b1[16], b2[16];
+        for (int t = 0; t < 16; ++t) {
+            b1[t] = m.v[kappa(c)][16 * h + t];
+            b2[t] = m.v[c][acc_row(t, h)];
+        }
+        for (int q = 0; q < 4; ++q) {
+            o.lane[l].p1[q] = pack4(b1 + 4 * q);
+            o.lane[l].p2[q] = pack4(b2 + 4 * q);
+            o.lane[l].tr[q] = 0;
+        }
+        o.lane[l].c1 = (1 << (shift1 - 1)) + 128 * rowsum[kappa(c)];
+        o.lane[l].c2 = (1 << (shift2 - 1)) + 128 * rowsum[c];
+        o.lane[l].pad[0] = o.lane[l].pad[1] = 0;
+        for (int r = 0; r < 16; ++r) o.c2r[l][r] = o.lane[l].c2;
+    }
+}
+
+constexpr int transform_shift1(int n) { return (n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5) - 1; }   // log2N - 1  (8-bit video)
+constexpr int transform_shift2(int n) { return (n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5) + 6; }   // log2N + 6
+
 }  // namespace x266

@@ -24,6 +24,7 @@ struct x266hip_ctx {
     hipDeviceProp_t prop{};
     DctOps *d_fwd = nullptr;
     DctOps *d_inv = nullptr;
+    DctOps *d_tr[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // [type][log2N - 2], N = 4, 8, 16
     // options
     int wgs_per_cu_dct = 8;
     int wgs_per_cu_inv = 5;
@@ -144,6 +145,13 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
         build_inv_ops(*h);
         ok = hipMemcpy(ctx->d_inv, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
     }
+    for (int type = 0; type < 2 && ok; ++type)
+        for (int l = 0; l < 3 && ok; ++l) {
+            const int n = 4 << l;
+            build_fwd_ops_general(*h, make_transform_matrix(type, n), transform_shift1(n), transform_shift2(n));
+            ok = hipMalloc((void **)&ctx->d_tr[type][l], sizeof(DctOps)) == hipSuccess &&
+                 hipMemcpy(ctx->d_tr[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
+        }
     delete h;
     if (!ok) {
         xHipCodecFree(ctx);
@@ -162,6 +170,9 @@ void xHipCodecFree(x266hip_ctx *ctx)
         if (ctx->d_stage_out[i]) (void)hipFree(ctx->d_stage_out[i]);
         if (ctx->stage_stream[i]) (void)hipStreamDestroy(ctx->stage_stream[i]);
     }
+    for (int type = 0; type < 2; ++type)
+        for (int l = 0; l < 3; ++l)
+            if (ctx->d_tr[type][l]) (void)hipFree(ctx->d_tr[type][l]);
     if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
     if (ctx->d_inv) (void)hipFree(ctx->d_inv);
@@ -264,6 +275,28 @@ int xFillResidualDev(x266hip_ctx *ctx, int16_t *d_dst, size_t n_samples, uint64_
     return X266HIP_OK;
 }
 
+int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d_in, int16_t *d_out, size_t n,
+                          const uint32_t *d_offsets, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (type != X266_TR_DCT2 && type != X266_TR_DST7) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: unknown transform type");
+    if (size != 4 && size != 8 && size != 16 && !(size == 32 && type == X266_TR_DCT2))
+        return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: size must be 4, 8, 16 (or 32 for DCT-II)");
+    if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: NULL or unaligned buffer");
+    if (n && ((uintptr_t)d_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: unaligned offset table");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    if (size == 32) {
+        if (d_offsets) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: offset tables are for N < 32");
+        return launch_op(ctx, 0, d_in, d_out, n, (hipStream_t)stream);
+    }
+    const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
+    LaunchCfg cfg = cfg_for(ctx, 0);
+    cfg.units_per_wave = 2;
+    hipError_t e = launch_transform_small(l + 2, d_in, d_out, n, ctx->d_tr[type][l], d_offsets, cfg, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "transform launch", e);
+    return X266HIP_OK;
+}
+
 int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride, const uint8_t *d_ref,
                       intptr_t ref_stride, int width, int height, int range, x266_me_result_t *d_best,
                       uint32_t *d_costs, void *stream)
@@ -278,7 +311,10 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
     const size_t need = (size_t)(width / 8) * (size_t)(height / 8) * 128;
     if (ctx->me_variant == 2 && need > ctx->me_coef_bytes) {          // grow-only scratch (not stream-ordered: sync first)
         X_HIP(ctx, hipDeviceSynchronize());
-        if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
+        for (int type = 0; type < 2; ++type)
+        for (int l = 0; l < 3; ++l)
+            if (ctx->d_tr[type][l]) (void)hipFree(ctx->d_tr[type][l]);
+    if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
         ctx->d_me_coef = nullptr; ctx->me_coef_bytes = 0;
         if (hipMalloc((void **)&ctx->d_me_coef, need) != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "ME coefficient scratch");
         ctx->me_coef_bytes = need;
