@@ -147,19 +147,21 @@ def test_argument_errors(codec):
     assert b"" != L.xHipLastError(codec.ctx)
 
 
-@pytest.mark.parametrize("variant,nt,tpb,per_wave,wgs", [
-    (0, 0, 64, 1, 8), (0, 1, 256, 3, 8), (0, 0, 128, 16, 8), (0, 0, 192, 7, 8),
-    (1, 0, 256, 1, 1), (1, 1, 64, 1, 3), (1, 0, 256, 1, 8)])
-def test_launch_geometry_options_do_not_change_results(codec, oracle, variant, nt, tpb, per_wave, wgs):
+@pytest.mark.parametrize("variant,nt,tpb,per_wave,wgs,stage", [
+    (0, 0, 64, 1, 8, 0), (0, 1, 256, 3, 8, 0), (0, 0, 128, 16, 8, 0), (0, 0, 192, 7, 8, 0),
+    (0, 0, 64, 1, 8, 1), (0, 0, 256, 3, 8, 1), (0, 0, 128, 16, 8, 1), (0, 0, 192, 7, 8, 1),
+    (1, 0, 256, 1, 1, 0), (1, 1, 64, 1, 3, 0), (1, 0, 256, 1, 8, 1)])
+def test_launch_geometry_options_do_not_change_results(codec, oracle, variant, nt, tpb, per_wave, wgs, stage):
     x = residual_np(3001 * 1024, 0x266).reshape(-1, 1024)
     d = x.reshape(-1, 64)[:100003]
-    keys = ("nontemporal", "wg_threads", "dct32_variant", "satd_variant", "dct32_blocks_per_wave",
+    keys = ("nontemporal", "wg_threads", "dct32_lds_stage", "dct32_variant", "satd_variant", "dct32_blocks_per_wave",
             "dct32_inv_blocks_per_wave", "satd_groups_per_wave", "dct32_wgs_per_cu", "dct32_inv_wgs_per_cu",
             "satd_wgs_per_cu")
     saved = {k: codec.get_option(k) for k in keys}
     try:
         codec.set_option("nontemporal", nt)
         codec.set_option("wg_threads", tpb)
+        codec.set_option("dct32_lds_stage", stage)
         for k in ("dct32_variant", "satd_variant"):
             codec.set_option(k, variant)
         for k in ("dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "satd_groups_per_wave"):

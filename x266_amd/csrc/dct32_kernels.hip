@@ -166,6 +166,80 @@ __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ 
     }
 }
 
+// ---- LDS-staged variant -------------------------------------------------------
+// Same arithmetic; the difference is what the memory system sees.  A row-per-lane
+// fragment load touches only 16 bytes of every 32 per instruction; measured on this
+// chip, load/store instructions that cover whole 128-byte lines run ~9 % faster
+// (DCT-II 8x8 tiles, whose fragment loads are line-dense, reach 6.0 TB/s where the
+// 32x32 fragment pattern reaches 5.4-5.5 on the same box).  So each wave moves its
+// tile with fully linear 1 KiB instructions and turns it into fragment order through
+// a private 2 KiB LDS slot: linear global load -> ds_write -> ds_read (row-per-lane)
+// -> transform -> ds_write (row-per-lane) -> ds_read (linear) -> linear global store.
+// Chunk (row r, quarter q) lives at r*64 + ((q ^ ((r >> 2) & 3)) << 4): every one of
+// the four DS accesses is bank-conflict-free.  Waves never share a slot, so there is
+// no barrier, only the in-order LDS queue of the wave itself.
+__device__ __forceinline__ unsigned lds_slot(unsigned row, unsigned quarter)
+{
+    return row * 64u + ((quarter ^ ((row >> 2) & 3u)) << 4);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restrict__ in,
+                                                        int16_t *__restrict__ out, size_t n_blocks,
+                                                        const DctOps *__restrict__ ops,
+                                                        unsigned blocks_per_wave)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 2048];
+    const int lane = threadIdx.x & 63;
+    unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    size_t b = wave * blocks_per_wave;
+    const size_t end = b + blocks_per_wave < n_blocks ? b + blocks_per_wave : n_blocks;
+    if (b >= end) return;
+
+    const unsigned c = lane & 31, h = lane >> 5;
+    // this lane's two linear chunks (16 B each) and its two fragment chunks
+    const unsigned lin0 = lds_slot(lane >> 2, lane & 3), lin1 = lds_slot(16 + (lane >> 2), lane & 3);
+    const unsigned frag0 = lds_slot(c, 2 * h), frag1 = lds_slot(c, 2 * h + 1);
+    const char *src = reinterpret_cast<const char *>(in) + lane * 16;
+    char *dst = reinterpret_cast<char *>(out) + lane * 16;
+
+    v4i g0 = load16<false>(src + b * 2048), g1 = load16<false>(src + b * 2048 + 1024);
+    const LaneConsts k = load_consts(ops, lane);
+    v16i c2r;
+    if (MODE == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c2r[r] = ops->c2r[lane][r];
+    }
+    while (true) {
+        const size_t nb = b + 1;
+        *reinterpret_cast<v4i *>(slot + lin0) = g0;
+        *reinterpret_cast<v4i *>(slot + lin1) = g1;
+        if (nb < end) {                                        // next tile's loads fly under this tile's arithmetic
+            g0 = load16<false>(src + nb * 2048);
+            g1 = load16<false>(src + nb * 2048 + 1024);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const v4i a0 = *reinterpret_cast<const v4i *>(slot + frag0);
+        const v4i a1 = *reinterpret_cast<const v4i *>(slot + frag1);
+        v4i o0, o1;
+        if (MODE == 1)      inv_block(a0, a1, k, c2r, o0, o1);
+        else if (MODE == 0) fwd_block<4, 11>(a0, a1, k, o0, o1);
+        else                { o0 = a0 ^ k.p1; o1 = a1 ^ k.p2; }
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<v4i *>(slot + frag0) = o0;
+        *reinterpret_cast<v4i *>(slot + frag1) = o1;
+        __builtin_amdgcn_wave_barrier();
+        const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
+        const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
+        __builtin_amdgcn_wave_barrier();
+        store16<false>(dst + b * 2048, s0);
+        store16<false>(dst + b * 2048 + 1024, s1);
+        if (nb >= end) break;
+        b = nb;
+    }
+}
+
 }  // namespace
 
 // ---- launchers ---------------------------------------------------------------
@@ -189,6 +263,12 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs), block(tpb);
     const int mode = cfg.passthrough ? 2 : (inverse ? 1 : 0);
+    if (cfg.lds_stage && cfg.variant == 0) {                   // line-dense global traffic through a private LDS slot
+        if (mode == 0)      hipLaunchKernelGGL((dct32_lds_kernel<0>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else if (mode == 1) hipLaunchKernelGGL((dct32_lds_kernel<1>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else                hipLaunchKernelGGL((dct32_lds_kernel<2>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        return hipGetLastError();
+    }
 #define X266_LAUNCH(MODE, NT) hipLaunchKernelGGL((dct32_kernel<MODE, NT>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_in, d_out, n_blocks, d_ops, bpw)
     if (cfg.nontemporal) { if (mode == 0) X266_LAUNCH(0, true); else if (mode == 1) X266_LAUNCH(1, true); else X266_LAUNCH(2, true); }
     else                 { if (mode == 0) X266_LAUNCH(0, false); else if (mode == 1) X266_LAUNCH(1, false); else X266_LAUNCH(2, false); }

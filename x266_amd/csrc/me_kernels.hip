@@ -488,6 +488,10 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
         const int groups = (n_blocks + 31) / 32;
         hipLaunchKernelGGL(me_coef_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, stream, d_cur, cur_stride,
                            P.blocks_x, n_blocks, d_coef_scratch);
+        {
+            const hipError_t e0 = hipGetLastError();
+            if (e0 != hipSuccess) return e0;
+        }
         const int U = row_pairs == 1 ? 1 : (row_pairs == 3 ? 3 : 2);
         const size_t lds = 128 + (size_t)(P.n_rows + 7 + 2 * U) * P.pitch;   // the last strip may be partly empty
         const uint32_t *cf = d_coef_scratch;

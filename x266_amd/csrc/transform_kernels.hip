@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void tr_fwd_small_kernel(const int16_t *__rest
 {
     constexpr int N = 1 << LOGN;
     constexpr int PER = 32 / N;                 // small blocks per tile edge
-    constexpr int PIECES = 16 / N;              // small-block rows per lane (a lane holds 16 samples of a tile row)
+    constexpr int PIECES = N >= 16 ? 1 : 16 / N;   // small-block rows per lane (a lane holds 16 samples of a tile row)
     constexpr int NSB = PER * PER;              // small blocks per tile
     constexpr int S1 = LOGN - 1, S2 = LOGN + 6;
 
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void tr_fwd_small_kernel(const int16_t *__rest
     const int row = c & (N - 1), tile_row = c >> LOGN;
 
     for (; t < t_end; ++t) {
-        const size_t first = t * NSB + (size_t)tile_row * PER + (size_t)h * PIECES;
+        const size_t first = N == 32 ? t : t * NSB + (size_t)tile_row * PER + (size_t)h * PIECES;
         uint32_t w[8];
         size_t off[PIECES];
         bool live[PIECES];
@@ -57,9 +57,9 @@ __global__ __launch_bounds__(256) void tr_fwd_small_kernel(const int16_t *__rest
             live[q] = blk < n_blocks;
             if (!live[q]) blk = n_blocks - 1;                              // ragged tail: re-read the last block
             const size_t base = INDEXED ? (size_t)offsets[blk] : blk * (size_t)(N * N);
-            off[q] = (base + (size_t)row * N) * 2;                         // bytes
+            off[q] = (base + (size_t)row * N + (N == 32 ? 16 * h : 0)) * 2;   // bytes
             const char *p = reinterpret_cast<const char *>(in) + off[q];
-            if (N == 16) {
+            if (N >= 16) {
                 const v4i a = *reinterpret_cast<const v4i *>(p), b = *reinterpret_cast<const v4i *>(p + 16);
                 w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = b[0]; w[5] = b[1]; w[6] = b[2]; w[7] = b[3];
             } else if (N == 8) {
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void tr_fwd_small_kernel(const int16_t *__rest
         for (int q = 0; q < PIECES; ++q) {
             if (!live[q]) continue;
             char *p = reinterpret_cast<char *>(out) + off[q];
-            if (N == 16) {
+            if (N >= 16) {
                 *reinterpret_cast<v4i *>(p) = o0;
                 *reinterpret_cast<v4i *>(p + 16) = o1;
             } else if (N == 8) {
@@ -105,7 +105,8 @@ hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out
     dim3 grid((unsigned)wgs), block(256);
 #define X266_TR(L) do { if (d_offsets) hipLaunchKernelGGL((tr_fwd_small_kernel<L, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
                         else           hipLaunchKernelGGL((tr_fwd_small_kernel<L, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
-    if (log2n == 2) X266_TR(2); else if (log2n == 3) X266_TR(3); else if (log2n == 4) X266_TR(4); else return hipErrorInvalidValue;
+    if (log2n == 2) X266_TR(2); else if (log2n == 3) X266_TR(3); else if (log2n == 4) X266_TR(4); else if (log2n == 5) X266_TR(5);
+    else return hipErrorInvalidValue;
 #undef X266_TR
     return hipGetLastError();
 }

@@ -32,7 +32,7 @@ struct x266hip_ctx {
     int nontemporal = 0;
     int dct_variant = 0, satd_variant = 0;          // 0 streaming launch, 1 persistent
     // streaming launch: consecutive units per wave (measured optimum on MI355X, profiles/r01_sweep.txt)
-    int dct_blocks_per_wave = 2, dct_inv_blocks_per_wave = 8, satd_groups_per_wave = 1;
+    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 1;
     int wg_threads = 256;
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
     int me_tile_rows = 4;                           // block rows per ME tile (1, 2 or 4)
@@ -40,6 +40,9 @@ struct x266hip_ctx {
     int me_variant = 2;                             // 1 = LDS coefficients, 2 = scalar coefficients (me_kernels.hip)
     uint32_t *d_me_coef = nullptr;                  // variant 2 scratch: 128 B per 8x8 block of the current frame
     size_t me_coef_bytes = 0;
+    int tr_tiles_per_wave = 2;                      // transform set: 32x32 tiles per wave
+    int tr32_simple = 0;                            // diagnostic: run DCT-II 32 through the transform-set kernel
+    int dct_lds_stage = 1;                          // see dct32_kernels.hip: dct32_lds_kernel
     int passthrough = 0;                            // diagnostic, see x266_device.hpp
     // host-pointer staging (lazily allocated)
     static constexpr int kSlots = 2;
@@ -80,6 +83,7 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
     c.units_per_wave = op == 2 ? ctx->satd_groups_per_wave : (op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave);
     c.wg_threads = ctx->wg_threads;
     c.passthrough = ctx->passthrough;
+    c.lds_stage = ctx->dct_lds_stage;
     c.lds_pad_bytes = op == 2 ? ctx->lds_pad_satd : (op == 1 ? ctx->lds_pad_inv : ctx->lds_pad_dct);
     return c;
 }
@@ -209,6 +213,9 @@ static int *option_slot(x266hip_ctx *ctx, const char *key)
     if (!std::strcmp(key, "wg_threads")) return &ctx->wg_threads;
     if (!std::strcmp(key, "diag_passthrough")) return &ctx->passthrough;
     if (!std::strcmp(key, "me_tile_rows")) return &ctx->me_tile_rows;
+    if (!std::strcmp(key, "dct32_lds_stage")) return &ctx->dct_lds_stage;
+    if (!std::strcmp(key, "tr_tiles_per_wave")) return &ctx->tr_tiles_per_wave;
+    if (!std::strcmp(key, "diag_tr32_simple")) return &ctx->tr32_simple;
     if (!std::strcmp(key, "me_variant")) return &ctx->me_variant;
     if (!std::strcmp(key, "me_row_pairs")) return &ctx->me_row_pairs;
     if (!std::strcmp(key, "dct32_lds_pad_bytes")) return &ctx->lds_pad_dct;
@@ -222,6 +229,7 @@ int xHipSetOption(x266hip_ctx *ctx, const char *key, int value)
     int *slot = option_slot(ctx, key);
     if (!slot) return X266HIP_EINVAL;
     if (std::strstr(key, "wgs_per_cu") && (value < 1 || value > 64)) return fail(ctx, X266HIP_EINVAL, "wgs_per_cu out of range");
+    if (!std::strcmp(key, "tr_tiles_per_wave") && (value < 1 || value > 64)) return fail(ctx, X266HIP_EINVAL, "tiles per wave out of range");
     if (std::strstr(key, "_per_wave") && (value < 1 || value > 4096)) return fail(ctx, X266HIP_EINVAL, "units per wave out of range");
     if (std::strstr(key, "lds_pad_bytes") && (value < 0 || value > 160 * 1024)) return fail(ctx, X266HIP_EINVAL, "lds pad out of range");
     if (!std::strcmp(key, "wg_threads") && (value < 64 || value > 256 || value % 64)) return fail(ctx, X266HIP_EINVAL, "wg_threads must be 64, 128, 192 or 256");
@@ -286,12 +294,16 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
     if (n && ((uintptr_t)d_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: unaligned offset table");
     X_HIP(ctx, hipSetDevice(ctx->device));
     if (size == 32) {
-        if (d_offsets) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: offset tables are for N < 32");
-        return launch_op(ctx, 0, d_in, d_out, n, (hipStream_t)stream);
+        if (!d_offsets && !ctx->tr32_simple) return launch_op(ctx, 0, d_in, d_out, n, (hipStream_t)stream);
+        LaunchCfg cfg32 = cfg_for(ctx, 0);
+        cfg32.units_per_wave = ctx->tr_tiles_per_wave;
+        hipError_t e32 = launch_transform_small(5, d_in, d_out, n, ctx->d_fwd, d_offsets, cfg32, (hipStream_t)stream);
+        if (e32 != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "transform launch", e32);
+        return X266HIP_OK;
     }
     const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
     LaunchCfg cfg = cfg_for(ctx, 0);
-    cfg.units_per_wave = 2;
+    cfg.units_per_wave = ctx->tr_tiles_per_wave;
     hipError_t e = launch_transform_small(l + 2, d_in, d_out, n, ctx->d_tr[type][l], d_offsets, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "transform launch", e);
     return X266HIP_OK;
@@ -311,14 +323,13 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
     const size_t need = (size_t)(width / 8) * (size_t)(height / 8) * 128;
     if (ctx->me_variant == 2 && need > ctx->me_coef_bytes) {          // grow-only scratch (not stream-ordered: sync first)
         X_HIP(ctx, hipDeviceSynchronize());
-        for (int type = 0; type < 2; ++type)
-        for (int l = 0; l < 3; ++l)
-            if (ctx->d_tr[type][l]) (void)hipFree(ctx->d_tr[type][l]);
-    if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
-        ctx->d_me_coef = nullptr; ctx->me_coef_bytes = 0;
+        if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
+        ctx->d_me_coef = nullptr;
+        ctx->me_coef_bytes = 0;
         if (hipMalloc((void **)&ctx->d_me_coef, need) != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "ME coefficient scratch");
         ctx->me_coef_bytes = need;
     }
+    (void)hipGetLastError();
     hipError_t e = launch_satd_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
                                       d_best, d_costs, ctx->me_tile_rows, ctx->me_variant, ctx->me_row_pairs, ctx->d_me_coef, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "search launch", e);
