@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--satd-blocks", type=int, default=SATD_BLOCKS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the inverse / SATD legs")
+    ap.add_argument("--no-me", action="store_true", help="skip the motion-search leg")
+    ap.add_argument("--no-transform-set", action="store_true", help="skip the transform-set leg")
     return ap.parse_args()
 
 
@@ -131,6 +133,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     codec = x266_amd.Codec(local_rank)
+    info_cu = codec.device_info()["cu_count"]
     stream = torch.cuda.current_stream().cuda_stream           # the stream every launch and event uses
     n_dct, n_satd = args.dct_blocks, args.satd_blocks
 
@@ -241,6 +244,69 @@ def main():
                 "sample": "first %d blocks of the GPU batch" % ns,
                 "gpu_output_bit_exact_vs_cpu": bool(np.array_equal(ref_s.astype(np.int32), s[:ns].cpu().numpy()))}
         del d, s
+
+        # ---- BASELINE configs[2]: full-search SATD motion estimation, one 3840x2160 luma frame, window +-64
+        if not args.no_me:
+            w, h, rng = 3840, 2160, 64
+            pad = rng
+            g = torch.Generator(device="cuda")
+            g.manual_seed(0x266 + rank)
+            big = torch.randint(0, 256, (h + 2 * pad + 16, w + 2 * pad + 16), generator=g, device="cuda", dtype=torch.int32)
+            # 5x5 box low-pass so that motion is findable (pooling, not conv: no MIOpen kernel search)
+            sm = torch.nn.functional.avg_pool2d(big.float()[None, None], 5, stride=1, padding=2, count_include_pad=False)[0, 0]
+            sm = ((sm - 128.0) * 3.0 + 128.0).clamp(0, 255).to(torch.uint8)
+            cur = sm[pad + 8:pad + 8 + h, pad + 8:pad + 8 + w].contiguous()
+            refp = sm[8 + 3:8 + 3 + h + 2 * pad, 8 - 5:8 - 5 + w + 2 * pad].contiguous()      # planted motion (5, -3)
+            nb = (w // 8) * (h // 8)
+            best = torch.empty(nb * 2, dtype=torch.int32, device="cuda")
+            origin = refp.data_ptr() + pad * refp.stride(0) + pad
+
+            def me(_a, _b, _n, st):
+                codec.satd_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, st)
+
+            me_steps, me_warm = max(2, args.steps // 10), 2
+            for _ in range(me_warm):
+                me(0, 0, 0, stream)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(me_steps):
+                me(0, 0, 0, stream)
+            barrier()
+            wall_m = max_over_ranks(time.perf_counter() - t0)
+            ncand = nb * (2 * rng + 1) ** 2
+            mv = best.view(torch.int16).view(nb, 4)[:, :2]
+            found = float(((mv[:, 0] == 5) & (mv[:, 1] == -3)).float().mean().item())
+            # VALU floor: 32 x v_sad_u16 (4 cycles per wave64 instruction, tools/alubench) per 64 candidates
+            floor_s = ncand / 64 * 32 * 4 / (4 * info_cu * 2.4e9)
+            also["satd8x8_me_search"] = {
+                "value": world * ncand * me_steps / wall_m, "unit": "SATD/s", "ms_per_frame": wall_m / me_steps * 1e3,
+                "frame": "%dx%d luma, 8x8 blocks, window +-%d (%d candidates per block)" % (w, h, rng, (2 * rng + 1) ** 2),
+                "bound": "VALU issue (v_sad_u16), not HBM: ~18 MB of compulsory traffic per frame",
+                "frac_of_v_sad_u16_floor": floor_s / (wall_m / me_steps),
+                "planted_mv_found_fraction": found,
+                "parity": "per-candidate cost pinned by satd8x8 (src_tb/satd.c); harness (order, tie-break, padding) unpinned"}
+            del big, sm, cur, refp, best
+
+        # ---- BASELINE configs[3]: the VVC transform set, 2 GiB of residual per class
+        if not args.no_transform_set:
+            ts = {}
+            for ttype, tname in ((0, "dct2"), (1, "dst7")):
+                for n in (4, 8, 16):
+                    nblk = (n_dct * 1024) // (n * n)
+                    fn = lambda a, b, cnt, st, tt=ttype, nn=n: codec.transform_fwd_dev(tt, nn, a, b, cnt, 0, st)
+                    for _ in range(3):
+                        fn(x.data_ptr(), z.data_ptr(), nblk, stream)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        fn(x.data_ptr(), z.data_ptr(), nblk, stream)
+                    barrier()
+                    wall_t = max_over_ranks(time.perf_counter() - t0)
+                    ts["%s_%dx%d" % (tname, n, n)] = {
+                        "value": world * nblk * args.steps / wall_t, "unit": "blocks/s",
+                        "hbm_frac": 4.0 * n * n * nblk / (wall_t / args.steps) / HBM_PEAK_BYTES_PER_S}
+            also["transform_set"] = {"classes": ts, "parity": "unpinned upstream except DCT-II 32; bit-exact vs this repo's oracle",
+                                     "note": "wall-clock rates (launch gaps included); 4*N*N algorithmic bytes per block"}
         result["also"] = also
 
     # ---- CPU baseline for the headline leg (rank 0, N = 1 only) ------------------------------------
