@@ -65,6 +65,57 @@ __device__ __forceinline__ uint32_t abs_sum16(const v16i &hi, const v16i &lo, ui
     return sum;
 }
 
+// One 32-block group (held as the lane's 64-byte half of its block) -> 32 costs.
+struct SatdOperands { v4i h00, h01, h10, h11; v16i dcfix; };
+
+__device__ __forceinline__ SatdOperands make_satd_operands(int lane)
+{
+    // The four +-1 operand images (tile x K-step) of H64[m][s] = (-1)^popcount(m & s) are built
+    // in registers (~25 VALU) instead of being fetched: with one 4 KiB group per wave a table would
+    // double the wave's load instructions.  m = 32*tile + blk, s = 32*half + 16*step + t:
+    //   popcount parity splits over disjoint bit ranges, so
+    //   sign = [bits 0-1 of m vs t] ^ [bits 2-3 of m vs t>>2] ^ [bit 4 of m & step] ^ [tile & half]
+    // and negating a +-1 byte is an XOR with 0xFE.
+    const uint32_t NEG = 0xFEFEFEFEu;
+    const uint32_t m = (uint32_t)lane & 31u, half = (uint32_t)lane >> 5;
+    const uint32_t inner = (m & 1) ? ((m & 2) ? 0x01FFFF01u : 0xFF01FF01u)     // bytes j = 0..3: (-1)^popcount(m & 3 & j)
+                                   : ((m & 2) ? 0xFFFF0101u : 0x01010101u);
+    const uint32_t f2 = (m & 4) ? NEG : 0u, f3 = (m & 8) ? NEG : 0u;          // dword q flips on popcount((m >> 2) & q)
+    const uint32_t f4 = (m & 16) ? NEG : 0u, fh = half ? NEG : 0u;
+    const uint32_t b0 = inner, b1 = inner ^ f2, b2 = inner ^ f3, b3 = inner ^ f2 ^ f3;
+    SatdOperands o;
+    o.h00 = v4i{(int)b0, (int)b1, (int)b2, (int)b3};                             // tile 0, step 0
+    o.h01 = v4i{(int)(b0 ^ f4), (int)(b1 ^ f4), (int)(b2 ^ f4), (int)(b3 ^ f4)}; // tile 0, step 1: m bit 4 & step
+    o.h10 = v4i{(int)(b0 ^ fh), (int)(b1 ^ fh), (int)(b2 ^ fh), (int)(b3 ^ fh)}; // tile 1, step 0: m bit 5 & s bit 5
+    o.h11 = o.h01 ^ v4i{(int)fh, (int)fh, (int)fh, (int)fh};
+    // DC fix for the byte-plane offset: coefficient m = 0 lives in tile 0, reg 0, half 0
+    o.dcfix = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    o.dcfix[0] = half == 0 ? 128 * 64 : 0;
+    return o;
+}
+
+__device__ __forceinline__ uint32_t satd_group(const SatdOperands &H, const v4i &w0, const v4i &w1, const v4i &w2, const v4i &w3)
+{
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v4i lo0, hi0, lo1, hi1;
+    split_planes(w0, w1, lo0, hi0);                     // K-step 0: samples 32*half + 0..15
+    split_planes(w2, w3, lo1, hi1);                     // K-step 1: samples 32*half + 16..31
+    uint32_t sum = 0;
+    {   // coefficients 0..31
+        v16i ah = mfma(H.h00, hi0, zero);     ah = mfma(H.h01, hi1, ah);
+        v16i al = mfma(H.h00, lo0, H.dcfix);  al = mfma(H.h01, lo1, al);
+        sum = abs_sum16(ah, al, sum);
+    }
+    {   // coefficients 32..63
+        v16i ah = mfma(H.h10, hi0, zero);     ah = mfma(H.h11, hi1, ah);
+        v16i al = mfma(H.h10, lo0, zero);     al = mfma(H.h11, lo1, al);
+        sum = abs_sum16(ah, al, sum);
+    }
+    // the other half of the coefficient rows sits in lane ^ 32
+    sum += (uint32_t)__shfl_xor((int)sum, 32);
+    return (sum + 2) >> 2;
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict__ diff,
                                                       uint32_t *__restrict__ out, size_t n_blocks,
@@ -84,33 +135,8 @@ __global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict_
         end = n_groups;
     }
     if (g >= end) return;
-
     const int blk = lane & 31, half = lane >> 5;
-
-    // The four +-1 operand images (tile x K-step) of H64[m][s] = (-1)^popcount(m & s) are built
-    // in registers (~25 VALU) instead of being fetched: with one 4 KiB group per wave that would
-    // double the wave's load instructions.  m = 32*tile + blk, s = 32*half + 16*step + t:
-    //   popcount parity splits over disjoint bit ranges, so
-    //   sign = [bits 0-1 of m vs t] ^ [bits 2-3 of m vs t>>2] ^ [bit 4 of m & step] ^ [tile & half]
-    // and negating a +-1 byte is an XOR with 0xFE.
-    v4i h00, h01, h10, h11;
-    {
-        const uint32_t NEG = 0xFEFEFEFEu;
-        const uint32_t m = (uint32_t)blk;
-        const uint32_t inner = (m & 1) ? ((m & 2) ? 0x01FFFF01u : 0xFF01FF01u)     // bytes j = 0..3: (-1)^popcount(m & 3 & j)
-                                       : ((m & 2) ? 0xFFFF0101u : 0x01010101u);
-        const uint32_t f2 = (m & 4) ? NEG : 0u, f3 = (m & 8) ? NEG : 0u;          // dword q flips on popcount((m >> 2) & q)
-        const uint32_t f4 = (m & 16) ? NEG : 0u, fh = half ? NEG : 0u;
-        const uint32_t b0 = inner, b1 = inner ^ f2, b2 = inner ^ f3, b3 = inner ^ f2 ^ f3;
-        h00 = v4i{(int)b0, (int)b1, (int)b2, (int)b3};                             // tile 0, step 0
-        h01 = v4i{(int)(b0 ^ f4), (int)(b1 ^ f4), (int)(b2 ^ f4), (int)(b3 ^ f4)}; // tile 0, step 1: m bit 4 & step
-        h10 = v4i{(int)(b0 ^ fh), (int)(b1 ^ fh), (int)(b2 ^ fh), (int)(b3 ^ fh)}; // tile 1, step 0: m bit 5 & s bit 5
-        h11 = h01 ^ v4i{(int)fh, (int)fh, (int)fh, (int)fh};
-    }
-    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // DC fix for the byte-plane offset: coefficient m = 0 lives in tile 0, reg 0, half 0
-    v16i dcfix = zero;
-    dcfix[0] = half == 0 ? 128 * 64 : 0;
+    const SatdOperands H = make_satd_operands(lane);
 
     for (; g < end; g += stride) {
         size_t b = g * 32 + blk;
@@ -119,25 +145,56 @@ __global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict_
         const char *p = reinterpret_cast<const char *>(diff) + b * 128 + (size_t)half * 64;
         const v4i w0 = load16<NT>(p), w1 = load16<NT>(p + 16);
         const v4i w2 = load16<NT>(p + 32), w3 = load16<NT>(p + 48);
+        const uint32_t cost = satd_group(H, w0, w1, w2, w3);
+        if (live && half == 0) out[b] = cost;
+    }
+}
 
-        v4i lo0, hi0, lo1, hi1;
-        split_planes(w0, w1, lo0, hi0);                     // K-step 0: samples 32*half + 0..15
-        split_planes(w2, w3, lo1, hi1);                     // K-step 1: samples 32*half + 16..31
+// LDS-staged variant: the group's 4 KiB are fetched with four fully linear 1 KiB instructions
+// (whole 128-byte lines per instruction, see dct32_kernels.hip) and turned into block-per-lane
+// order through a wave-private LDS slot.  Chunk (block n, row j) lives at
+// n*128 + ((j ^ ((n >> 1) & 7)) << 4): linear writes and fragment reads are conflict-free.
+__global__ __launch_bounds__(256) void satd8x8_lds_kernel(const int16_t *__restrict__ diff,
+                                                          uint32_t *__restrict__ out, size_t n_blocks,
+                                                          unsigned groups_per_wave)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 4096];
+    const int lane = threadIdx.x & 63;
+    unsigned char *slot = stage + (threadIdx.x >> 6) * 4096;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_groups = (n_blocks + 31) >> 5;
+    size_t g = wave * groups_per_wave;
+    const size_t end = g + groups_per_wave < n_groups ? g + groups_per_wave : n_groups;
+    if (g >= end) return;
+    const int blk = lane & 31, half = lane >> 5;
+    const SatdOperands H = make_satd_operands(lane);
+    const size_t total_bytes = n_blocks * 128;
 
-        uint32_t sum = 0;
-        {   // coefficients 0..31
-            v16i ah = mfma(h00, hi0, zero);   ah = mfma(h01, hi1, ah);
-            v16i al = mfma(h00, lo0, dcfix);  al = mfma(h01, lo1, al);
-            sum = abs_sum16(ah, al, sum);
+    unsigned lin[4], frag[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned chunk = lane + 64 * i, n = chunk >> 3, j = chunk & 7;
+        lin[i] = n * 128 + ((j ^ ((n >> 1) & 7)) << 4);
+        frag[i] = blk * 128 + ((((unsigned)(4 * half + i)) ^ (((unsigned)blk >> 1) & 7)) << 4);
+    }
+    for (; g < end; ++g) {
+        const size_t base = g * 4096;
+        v4i v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            size_t off = base + (size_t)lane * 16 + 1024 * (size_t)i;
+            if (off + 16 > total_bytes) off = total_bytes - 16;       // ragged tail: stay inside the buffer
+            v[i] = load16<false>(reinterpret_cast<const char *>(diff) + off);
         }
-        {   // coefficients 32..63
-            v16i ah = mfma(h10, hi0, zero);   ah = mfma(h11, hi1, ah);
-            v16i al = mfma(h10, lo0, zero);   al = mfma(h11, lo1, al);
-            sum = abs_sum16(ah, al, sum);
-        }
-        // the other half of the coefficient rows sits in lane ^ 32
-        sum += (uint32_t)__shfl_xor((int)sum, 32);
-        if (live && half == 0) out[b] = (sum + 2) >> 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<v4i *>(slot + lin[i]) = v[i];
+        __builtin_amdgcn_wave_barrier();
+        const v4i w0 = *reinterpret_cast<const v4i *>(slot + frag[0]), w1 = *reinterpret_cast<const v4i *>(slot + frag[1]);
+        const v4i w2 = *reinterpret_cast<const v4i *>(slot + frag[2]), w3 = *reinterpret_cast<const v4i *>(slot + frag[3]);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t cost = satd_group(H, w0, w1, w2, w3);
+        const size_t b = g * 32 + blk;
+        if (b < n_blocks && half == 0) out[b] = cost;
     }
 }
 
@@ -197,6 +254,10 @@ hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_block
     }
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs), block(tpb);
+    if (cfg.lds_stage && cfg.variant == 0) {
+        hipLaunchKernelGGL(satd8x8_lds_kernel, grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
+        return hipGetLastError();
+    }
     if (cfg.nontemporal) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
     else                 hipLaunchKernelGGL((satd8x8_kernel<false>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
     return hipGetLastError();

@@ -90,6 +90,88 @@ __global__ __launch_bounds__(256) void tr_fwd_small_kernel(const int16_t *__rest
     }
 }
 
+// LDS-staged variant for contiguous batches: a tile's (32/N)^2 blocks are 2 KiB of consecutive
+// memory, moved with linear 1 KiB instructions (whole 128-byte lines per instruction, see
+// dct32_kernels.hip section "LDS-staged variant") and re-read from a wave-private LDS slot in
+// fragment order.  N = 8 does not need it: its fragment loads are line-dense already.
+template <int LOGN>
+__global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
+                                                               size_t n_blocks, const DctOps *__restrict__ ops,
+                                                               unsigned tiles_per_wave)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int PER = 32 / N, PIECES = N >= 16 ? 1 : 16 / N, NSB = PER * PER;
+    constexpr int S1 = LOGN - 1, S2 = LOGN + 6;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 2048];
+    unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_tiles = (n_blocks + NSB - 1) / NSB;
+    size_t t = wave * tiles_per_wave;
+    const size_t t_end = t + tiles_per_wave < n_tiles ? t + tiles_per_wave : n_tiles;
+    if (t >= t_end) return;
+    const LaneConsts k = load_consts(ops, lane);
+    const int row = c & (N - 1), tile_row = c >> LOGN;
+    const size_t total_bytes = n_blocks * (size_t)(N * N * 2);
+
+    // byte offsets inside the 2 KiB tile of this lane's fragment pieces (block-major tile layout)
+    unsigned frag[PIECES];
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const unsigned sb = N == 32 ? 0u : (unsigned)(tile_row * PER + h * PIECES + q);
+        frag[q] = (sb * (unsigned)(N * N) + (unsigned)row * N + (N == 32 ? 16u * h : 0u)) * 2u;
+    }
+    for (; t < t_end; ++t) {
+        const size_t base = t * 2048;
+        size_t o0 = base + (size_t)lane * 16, o1 = o0 + 1024;
+        const bool live0 = o0 + 16 <= total_bytes, live1 = o1 + 16 <= total_bytes;
+        if (!live0) o0 = total_bytes - 16;                               // ragged tail: stay inside the buffer
+        if (!live1) o1 = total_bytes - 16;
+        const v4i g0 = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(in) + o0);
+        const v4i g1 = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(in) + o1);
+        *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
+        *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t w[8];
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            if (N >= 16) {
+                const v4i a = *reinterpret_cast<const v4i *>(slot + frag[q]), b = *reinterpret_cast<const v4i *>(slot + frag[q] + 16);
+                w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = b[0]; w[5] = b[1]; w[6] = b[2]; w[7] = b[3];
+            } else if (N == 8) {
+                const v4i a = *reinterpret_cast<const v4i *>(slot + frag[q]);
+                w[4 * q] = a[0]; w[4 * q + 1] = a[1]; w[4 * q + 2] = a[2]; w[4 * q + 3] = a[3];
+            } else {
+                const uint2 a = *reinterpret_cast<const uint2 *>(slot + frag[q]);
+                w[2 * q] = a.x; w[2 * q + 1] = a.y;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        v4i r0, r1;
+        fwd_block<S1, S2>(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, k, r0, r1);
+        const uint32_t z[8] = {(uint32_t)r0[0], (uint32_t)r0[1], (uint32_t)r0[2], (uint32_t)r0[3],
+                               (uint32_t)r1[0], (uint32_t)r1[1], (uint32_t)r1[2], (uint32_t)r1[3]};
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            if (N >= 16) {
+                *reinterpret_cast<v4i *>(slot + frag[q]) = r0;
+                *reinterpret_cast<v4i *>(slot + frag[q] + 16) = r1;
+            } else if (N == 8) {
+                *reinterpret_cast<v4i *>(slot + frag[q]) = v4i{(int)z[4 * q], (int)z[4 * q + 1], (int)z[4 * q + 2], (int)z[4 * q + 3]};
+            } else {
+                *reinterpret_cast<uint2 *>(slot + frag[q]) = make_uint2(z[2 * q], z[2 * q + 1]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
+        const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
+        __builtin_amdgcn_wave_barrier();
+        if (live0) *reinterpret_cast<v4i *>(reinterpret_cast<char *>(out) + o0) = s0;
+        if (live1) *reinterpret_cast<v4i *>(reinterpret_cast<char *>(out) + o1) = s1;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
@@ -103,6 +185,14 @@ hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out
     const size_t wgs = (waves + 3) / 4;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs), block(256);
+    if (!d_offsets && cfg.lds_stage) {                           // contiguous batch: line-dense traffic through LDS
+        if (log2n == 2)      hipLaunchKernelGGL((tr_fwd_small_lds_kernel<2>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, tpw);
+        else if (log2n == 3) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<3>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, tpw);
+        else if (log2n == 4) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<4>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, tpw);
+        else if (log2n == 5) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<5>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, tpw);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
 #define X266_TR(L) do { if (d_offsets) hipLaunchKernelGGL((tr_fwd_small_kernel<L, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
                         else           hipLaunchKernelGGL((tr_fwd_small_kernel<L, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
     if (log2n == 2) X266_TR(2); else if (log2n == 3) X266_TR(3); else if (log2n == 4) X266_TR(4); else if (log2n == 5) X266_TR(5);

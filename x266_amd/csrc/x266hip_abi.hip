@@ -40,8 +40,10 @@ struct x266hip_ctx {
     int me_variant = 2;                             // 1 = LDS coefficients, 2 = scalar coefficients (me_kernels.hip)
     uint32_t *d_me_coef = nullptr;                  // variant 2 scratch: 128 B per 8x8 block of the current frame
     size_t me_coef_bytes = 0;
-    int tr_tiles_per_wave = 2;                      // transform set: 32x32 tiles per wave
+    int tr_lds_stage = 1;                           // transform set, contiguous batches: stage tiles through LDS
+    int tr_tiles_per_wave = 1;                      // transform set: 32x32 tiles per wave
     int tr32_simple = 0;                            // diagnostic: run DCT-II 32 through the transform-set kernel
+    int satd_lds_stage = 0;                         // measured: no gain for the read-dominated SATD batch (6.2-6.3 TB/s either way)
     int dct_lds_stage = 1;                          // see dct32_kernels.hip: dct32_lds_kernel
     int passthrough = 0;                            // diagnostic, see x266_device.hpp
     // host-pointer staging (lazily allocated)
@@ -83,7 +85,7 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
     c.units_per_wave = op == 2 ? ctx->satd_groups_per_wave : (op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave);
     c.wg_threads = ctx->wg_threads;
     c.passthrough = ctx->passthrough;
-    c.lds_stage = ctx->dct_lds_stage;
+    c.lds_stage = op == 2 ? ctx->satd_lds_stage : ctx->dct_lds_stage;
     c.lds_pad_bytes = op == 2 ? ctx->lds_pad_satd : (op == 1 ? ctx->lds_pad_inv : ctx->lds_pad_dct);
     return c;
 }
@@ -214,7 +216,9 @@ static int *option_slot(x266hip_ctx *ctx, const char *key)
     if (!std::strcmp(key, "diag_passthrough")) return &ctx->passthrough;
     if (!std::strcmp(key, "me_tile_rows")) return &ctx->me_tile_rows;
     if (!std::strcmp(key, "dct32_lds_stage")) return &ctx->dct_lds_stage;
+    if (!std::strcmp(key, "satd_lds_stage")) return &ctx->satd_lds_stage;
     if (!std::strcmp(key, "tr_tiles_per_wave")) return &ctx->tr_tiles_per_wave;
+    if (!std::strcmp(key, "tr_lds_stage")) return &ctx->tr_lds_stage;
     if (!std::strcmp(key, "diag_tr32_simple")) return &ctx->tr32_simple;
     if (!std::strcmp(key, "me_variant")) return &ctx->me_variant;
     if (!std::strcmp(key, "me_row_pairs")) return &ctx->me_row_pairs;
@@ -297,6 +301,7 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
         if (!d_offsets && !ctx->tr32_simple) return launch_op(ctx, 0, d_in, d_out, n, (hipStream_t)stream);
         LaunchCfg cfg32 = cfg_for(ctx, 0);
         cfg32.units_per_wave = ctx->tr_tiles_per_wave;
+        cfg32.lds_stage = ctx->tr_lds_stage;
         hipError_t e32 = launch_transform_small(5, d_in, d_out, n, ctx->d_fwd, d_offsets, cfg32, (hipStream_t)stream);
         if (e32 != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "transform launch", e32);
         return X266HIP_OK;
@@ -304,6 +309,7 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
     const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
     LaunchCfg cfg = cfg_for(ctx, 0);
     cfg.units_per_wave = ctx->tr_tiles_per_wave;
+    cfg.lds_stage = ctx->tr_lds_stage && size != 8;       // 8x8 fragment loads are line-dense already
     hipError_t e = launch_transform_small(l + 2, d_in, d_out, n, ctx->d_tr[type][l], d_offsets, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "transform launch", e);
     return X266HIP_OK;
