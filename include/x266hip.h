@@ -126,6 +126,12 @@ typedef struct x266_me_result_t {
 int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride,
                       const uint8_t *d_ref, intptr_t ref_stride, int width, int height,
                       int range, x266_me_result_t *d_best, uint32_t *d_costs, void *stream);
+/* Sum of absolute differences of n_blocks pairs of edge x edge 8-bit blocks (edge in
+ * {4, 8, 16, 32, 64}; each block edge*edge contiguous bytes, row-major; buffers 16-byte
+ * aligned): d_out[b] = sum |a - b|, exactly sad() of
+ * riscv/programs/benchmarks/sad/sad.c:28-39 (whose 64 x 64 known answer 344807 the tests replay). */
+int xSadBatchDev(x266hip_ctx *ctx, int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out,
+                 size_t n_blocks, void *stream);
 /* Synthetic residual stream with the reference's stimulus distribution
  * ((rand()&0xFF)-(rand()&0xFF), src_tb/dct32.c:191-193) from a counter-based
  * SplitMix64: sample i = lo8(r) - lo8(r>>8), r = mix(seed+(first_index+i+1)*phi). */

@@ -1,0 +1,41 @@
+"""GPU (-m gpu): batched SAD -- the reference's own known answer
+(64x64 -> 344807, riscv/programs/benchmarks/sad) and random batches against numpy."""
+import os
+
+import numpy as np
+import pytest
+
+from _util import GOLDEN_DIR, splitmix64
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_known_answer(codec):
+    g = np.load(os.path.join(GOLDEN_DIR, "sad64.npz"))
+    assert int(g["sad"][0]) == 344807
+    assert codec.sad(64, g["a"], g["b"]).tolist() == [344807]
+    # the same data cut into smaller blocks must add up to the same total
+    for edge in (4, 8, 16, 32):
+        a = g["a"].reshape(64 // edge, edge, 64 // edge, edge).transpose(0, 2, 1, 3).reshape(-1, edge * edge)
+        b = g["b"].reshape(64 // edge, edge, 64 // edge, edge).transpose(0, 2, 1, 3).reshape(-1, edge * edge)
+        assert int(codec.sad(edge, a, b).sum()) == 344807
+
+
+@pytest.mark.parametrize("edge", [4, 8, 16, 32, 64])
+@pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 63, 64, 65, 1000, 4097])
+def test_random_batches(codec, edge, n):
+    r = splitmix64(edge * 1000 + n, 0, 2 * n * edge * edge)
+    a = (r[: n * edge * edge] & np.uint64(0xFF)).astype(np.uint8).reshape(n, -1)
+    b = ((r[n * edge * edge:] >> np.uint64(17)) & np.uint64(0xFF)).astype(np.uint8).reshape(n, -1)
+    want = np.abs(a.astype(np.int32) - b.astype(np.int32)).sum(axis=1).astype(np.uint32)
+    assert np.array_equal(codec.sad(edge, a, b), want)
+
+
+def test_extremes_and_errors(codec):
+    a = np.zeros((5, 4096), np.uint8)
+    b = np.full((5, 4096), 255, np.uint8)
+    assert codec.sad(64, a, b).tolist() == [255 * 4096] * 5
+    buf = codec.alloc(8192)
+    assert codec.L.xSadBatchDev(codec.ctx, 12, buf.ptr, buf.ptr, buf.ptr, 1, None) < 0
+    assert codec.L.xSadBatchDev(codec.ctx, 8, None, buf.ptr, buf.ptr, 1, None) < 0
+    assert codec.L.xSadBatchDev(codec.ctx, 8, None, None, None, 0, None) == 0

@@ -78,3 +78,10 @@ def test_bdpi_satd_sequence(oracle):
     assert np.array_equal(oracle.satd8x8(g["blocks"]), g["satd"])
     words = g["blocks"].astype(np.int16).view(np.uint32).reshape(-1, 8, 4)
     assert np.array_equal(words, g["diff_words"])
+
+
+def test_sad_known_answer_fixture():
+    """The reference's only stored known answer: 64x64 SAD = 344807
+    (riscv/programs/benchmarks/sad/dataset1.h:423-426, checked by sad.c:57)."""
+    g = _load("sad64.npz")
+    assert int(np.abs(g["a"].astype(np.int32) - g["b"].astype(np.int32)).sum()) == int(g["sad"][0]) == 344807

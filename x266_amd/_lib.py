@@ -57,6 +57,7 @@ def load_library():
         getattr(L, name).argtypes = [_P, _P, _P, _SZ, _P]
     L.xFillResidualDev.argtypes = [_P, _P, _SZ, _U64, _U64, _P]
     L.xTransformFwdBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
+    L.xSadBatchDev.argtypes = [_P, ctypes.c_int, _P, _P, _P, _SZ, _P]
     L.xSatd8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, _P, _P, _P]
     for name in ("xDct32FwdBatch", "xDct32InvBatch", "xSatd8x8Batch"):
@@ -222,6 +223,20 @@ class Codec:
         self.transform_fwd_dev(ttype, size, din.ptr, dout.ptr, offsets.size, doff.ptr)
         self.stream_sync()
         return dout.download(np.int16, x.size)
+
+    def sad_dev(self, edge, d_a, d_b, d_out, n_blocks, stream=0):
+        self._check(self.L.xSadBatchDev(self.ctx, edge, d_a, d_b, d_out, n_blocks, stream), "xSadBatchDev")
+
+    def sad(self, edge, a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, edge * edge)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, edge * edge)
+        n = a.shape[0]
+        da, db, do = self.alloc(max(a.nbytes, 16)), self.alloc(max(b.nbytes, 16)), self.alloc(max(4 * n, 16))
+        da.upload(a)
+        db.upload(b)
+        self.sad_dev(edge, da.ptr, db.ptr, do.ptr, n)
+        self.stream_sync()
+        return do.download(np.uint32, n)
 
     def satd_search_dev(self, d_cur, cur_stride, d_ref_origin, ref_stride, width, height, rng, d_best, d_costs=0,
                         stream=0):

@@ -315,6 +315,18 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
     return X266HIP_OK;
 }
 
+int xSadBatchDev(x266hip_ctx *ctx, int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out, size_t n, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (edge != 4 && edge != 8 && edge != 16 && edge != 32 && edge != 64) return fail(ctx, X266HIP_EINVAL, "xSadBatchDev: edge must be 4, 8, 16, 32 or 64");
+    if (n && (!d_a || !d_b || !d_out || (((uintptr_t)d_a | (uintptr_t)d_b) & 15u) || ((uintptr_t)d_out & 3u)))
+        return fail(ctx, X266HIP_EINVAL, "xSadBatchDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_sad(edge, d_a, d_b, d_out, n, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "sad launch", e);
+    return X266HIP_OK;
+}
+
 int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride, const uint8_t *d_ref,
                       intptr_t ref_stride, int width, int height, int range, x266_me_result_t *d_best,
                       uint32_t *d_costs, void *stream)
