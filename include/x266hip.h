@@ -126,6 +126,27 @@ typedef struct x266_me_result_t {
 int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride,
                       const uint8_t *d_ref, intptr_t ref_stride, int width, int height,
                       int range, x266_me_result_t *d_best, uint32_t *d_costs, void *stream);
+/* Frame container of the codec skeleton: ref_block_t, src/x266.cpp:56-63 -- a frame is a
+ * raster of 512-byte tiles (16x16 luma, 8 rows of interleaved U,V pairs, 128 info bytes). */
+typedef struct x266_ref_block_t {
+    uint8_t m_Y[16 * 16];
+    uint8_t m_C[2 * 8 * 8];
+    uint8_t m_I[128];
+} x266_ref_block_t;
+/* xConvInputFmt (src/x266.cpp:415-453) on the device: planar YUV 4:2:0 -> tiles.  width and
+ * height multiples of 16; chroma stride = strdY / 2 as upstream; rows 16-byte (luma) and
+ * 8-byte (chroma) aligned.  m_I is left untouched, as upstream leaves it. */
+int xConvInputFmtDev(x266hip_ctx *ctx, x266_ref_block_t *d_tiles, const uint8_t *d_y, const uint8_t *d_u,
+                     const uint8_t *d_v, intptr_t strdY, int width, int height, void *stream);
+/* xConvOutput420 (src/x266.cpp:455-492) on the device: tiles -> planar YUV 4:2:0. */
+int xConvOutput420Dev(x266hip_ctx *ctx, const x266_ref_block_t *d_tiles, uint8_t *d_y, intptr_t strdY,
+                      uint8_t *d_u, uint8_t *d_v, intptr_t strdC, int width, int height, void *stream);
+/* Residual formation (no upstream counterpart: upstream stops before the residual stage):
+ * luma of two tiled frames, residual = cur - pred as int16, emitted as row-major blocks in
+ * raster order of blocks -- block_edge 32 feeds xDct32FwdBatchDev (width, height multiples
+ * of 32), block_edge 8 feeds xSatd8x8BatchDev (multiples of 16). */
+int xResidualLumaDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred,
+                     int width, int height, int block_edge, int16_t *d_residual, void *stream);
 /* Sum of absolute differences of n_blocks pairs of edge x edge 8-bit blocks (edge in
  * {4, 8, 16, 32, 64}; each block edge*edge contiguous bytes, row-major; buffers 16-byte
  * aligned): d_out[b] = sum |a - b|, exactly sad() of

@@ -66,6 +66,14 @@ void orc_satd8x8_search(const uint8_t *cur, ptrdiff_t cur_stride, const uint8_t 
                         int width, int height, int range, int16_t *best_mv, uint32_t *best_cost,
                         uint32_t *costs /* NULL or [blocks][(2R+1)^2] */, int threads);
 
+/* ---- frame container (src/x266.cpp:56-63, 415-492) -------- restated, not executed; residual UNPINNED */
+void orc_conv_input_fmt(uint8_t *tiles, const uint8_t *y, const uint8_t *u, const uint8_t *v,
+                        ptrdiff_t strd_y, int width, int height);
+void orc_conv_output_420(const uint8_t *tiles, uint8_t *y, ptrdiff_t strd_y, uint8_t *u, uint8_t *v,
+                         ptrdiff_t strd_c, int width, int height);
+void orc_residual_luma(const uint8_t *cur_tiles, const uint8_t *pred_tiles, int width, int height, int edge,
+                       int16_t *res);
+
 /* ---- BDPI word packing (src_tb/dct32.c:205-246, satd.c:143-147) ---- PINNED */
 void     orc_pack_diff_rows(const int16_t *mat, int first_row, uint32_t res[32]);
 uint64_t orc_pack_dct_word(const int16_t *dct, int idx);

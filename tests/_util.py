@@ -66,6 +66,33 @@ class Oracle:
         self.lib.orc_satd8x8_batch_mt(_P(d.ctypes.data), _P(out.ctypes.data), _SZ(d.shape[0]), threads)
         return out
 
+    def conv_input_fmt(self, y, u, v):
+        y = np.ascontiguousarray(y, np.uint8)
+        u = np.ascontiguousarray(u, np.uint8)
+        v = np.ascontiguousarray(v, np.uint8)
+        h, w = y.shape
+        tiles = np.zeros((h // 16) * (w // 16) * 512, np.uint8)
+        assert u.strides[0] == y.strides[0] // 2 and v.strides[0] == u.strides[0]
+        self.lib.orc_conv_input_fmt(_P(tiles.ctypes.data), _P(y.ctypes.data), _P(u.ctypes.data), _P(v.ctypes.data),
+                                    ctypes.c_ssize_t(y.strides[0]), w, h)
+        return tiles
+
+    def conv_output_420(self, tiles, w, h):
+        tiles = np.ascontiguousarray(tiles, np.uint8)
+        y = np.zeros((h, w), np.uint8)
+        u = np.zeros((h // 2, w // 2), np.uint8)
+        v = np.zeros((h // 2, w // 2), np.uint8)
+        self.lib.orc_conv_output_420(_P(tiles.ctypes.data), _P(y.ctypes.data), ctypes.c_ssize_t(w), _P(u.ctypes.data),
+                                     _P(v.ctypes.data), ctypes.c_ssize_t(w // 2), w, h)
+        return y, u, v
+
+    def residual_luma(self, cur_tiles, pred_tiles, w, h, edge):
+        cur_tiles = np.ascontiguousarray(cur_tiles, np.uint8)
+        pred_tiles = np.ascontiguousarray(pred_tiles, np.uint8)
+        res = np.empty(w * h, np.int16)
+        self.lib.orc_residual_luma(_P(cur_tiles.ctypes.data), _P(pred_tiles.ctypes.data), w, h, edge, _P(res.ctypes.data))
+        return res
+
     def transform_matrix(self, ttype, n):
         m = np.empty((n, n), np.int16)
         assert self.lib.orc_transform_matrix(ttype, n, _P(m.ctypes.data)) == 0

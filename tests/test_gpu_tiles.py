@@ -1,0 +1,89 @@
+"""GPU (-m gpu): frame container conversion (xConvInputFmt / xConvOutput420 of src/x266.cpp on
+the device) and residual formation, against the oracle; plus the chain tiles -> residual ->
+DCT32 / SATD that an encoder would run."""
+import numpy as np
+import pytest
+
+from _util import splitmix64
+
+pytestmark = pytest.mark.gpu
+
+
+def _yuv(w, h, seed, strd=None):
+    strd = strd or w
+    r = splitmix64(seed, 0, strd * h * 3 // 2 + 64)
+    b = (r & np.uint64(0xFF)).astype(np.uint8)
+    y = b[:strd * h].reshape(h, strd)
+    u = b[strd * h:strd * h + strd * h // 4].reshape(h // 2, strd // 2)
+    v = b[strd * h + strd * h // 4:strd * h + strd * h // 2].reshape(h // 2, strd // 2)
+    return y, u, v
+
+
+def _pack(codec, y, u, v, w, h):
+    dy, du, dv = codec.alloc(y.nbytes), codec.alloc(u.nbytes), codec.alloc(v.nbytes)
+    dy.upload(y); du.upload(u); dv.upload(v)
+    nt = (w // 16) * (h // 16)
+    dt = codec.alloc(nt * 512)
+    dt.upload(np.full(nt * 512, 0xEE, np.uint8))                      # m_I must survive untouched
+    codec.conv_input_fmt_dev(dt.ptr, dy.ptr, du.ptr, dv.ptr, y.strides[0], w, h)
+    codec.stream_sync()
+    return dt, nt
+
+
+@pytest.mark.parametrize("w,h,strd", [(16, 16, 16), (64, 48, 64), (320, 240, 320), (128, 64, 160), (3840, 2160, 3840)])
+def test_pack_and_unpack(codec, oracle, w, h, strd):
+    y, u, v = _yuv(w, h, 11 + w, strd)
+    dt, nt = _pack(codec, y, u, v, w, h)
+    tiles = dt.download(np.uint8, nt * 512).reshape(nt, 512)
+    if strd == w:
+        want = oracle.conv_input_fmt(y, u, v).reshape(nt, 512)
+        assert np.array_equal(tiles[:, :384], want[:, :384])
+    assert np.all(tiles[:, 384:] == 0xEE)
+    # layout, independent of the oracle
+    t0 = tiles[0]
+    assert np.array_equal(t0[:256].reshape(16, 16), y[:16, :16])
+    assert np.array_equal(t0[256:384].reshape(8, 8, 2)[:, :, 0], u[:8, :8]) and np.array_equal(t0[256:384].reshape(8, 8, 2)[:, :, 1], v[:8, :8])
+    # unpack into fresh planes
+    oy, ou, ov = codec.alloc(w * h), codec.alloc(w * h // 4), codec.alloc(w * h // 4)
+    codec.conv_output_420_dev(dt.ptr, oy.ptr, w, ou.ptr, ov.ptr, w // 2, w, h)
+    codec.stream_sync()
+    assert np.array_equal(oy.download(np.uint8, w * h).reshape(h, w), y[:, :w])
+    assert np.array_equal(ou.download(np.uint8, w * h // 4).reshape(h // 2, w // 2), u[:, :w // 2])
+    assert np.array_equal(ov.download(np.uint8, w * h // 4).reshape(h // 2, w // 2), v[:, :w // 2])
+
+
+@pytest.mark.parametrize("w,h", [(32, 32), (64, 96), (1920, 1088)])
+def test_residual_then_transform_and_cost(codec, oracle, w, h):
+    yc, uc, vc = _yuv(w, h, 21 + w)
+    yp, up, vp = _yuv(w, h, 22 + w)
+    dc, nt = _pack(codec, yc, uc, vc, w, h)
+    dp, _ = _pack(codec, yp, up, vp, w, h)
+    tc, tp = dc.download(np.uint8, nt * 512), dp.download(np.uint8, nt * 512)
+    for edge in (32, 8):
+        dres = codec.alloc(w * h * 2)
+        codec.residual_luma_dev(dc.ptr, dp.ptr, w, h, edge, dres.ptr)
+        codec.stream_sync()
+        res = dres.download(np.int16, w * h)
+        assert np.array_equal(res, oracle.residual_luma(tc, tp, w, h, edge))
+        d = yc.astype(np.int16) - yp.astype(np.int16)
+        assert np.array_equal(res, d.reshape(h // edge, edge, w // edge, edge).transpose(0, 2, 1, 3).reshape(-1))
+        n = w * h // (edge * edge)
+        if edge == 32:                                                 # ... straight into the transform
+            dz = codec.alloc(w * h * 2)
+            codec.dct32_fwd_dev(dres.ptr, dz.ptr, n)
+            codec.stream_sync()
+            assert np.array_equal(dz.download(np.int16, w * h).reshape(n, 1024), oracle.dct32_fwd(res, threads=8))
+        else:                                                          # ... straight into the cost
+            ds = codec.alloc(n * 4)
+            codec.satd8x8_dev(dres.ptr, ds.ptr, n)
+            codec.stream_sync()
+            assert np.array_equal(ds.download(np.uint32, n), oracle.satd8x8(res, threads=8))
+
+
+def test_argument_errors(codec):
+    L = codec.L
+    buf = codec.alloc(1 << 16)
+    assert L.xConvInputFmtDev(codec.ctx, buf.ptr, buf.ptr, buf.ptr, buf.ptr, 24, 24, 16, None) < 0         # width % 16
+    assert L.xConvInputFmtDev(codec.ctx, buf.ptr, None, buf.ptr, buf.ptr, 32, 32, 16, None) < 0
+    assert L.xResidualLumaDev(codec.ctx, buf.ptr, buf.ptr, 48, 32, 32, buf.ptr, None) < 0                  # 48 % 32
+    assert L.xResidualLumaDev(codec.ctx, buf.ptr, buf.ptr, 32, 32, 16, buf.ptr, None) < 0                  # edge

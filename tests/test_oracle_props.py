@@ -123,3 +123,37 @@ def test_transform_set_matches_numpy(oracle):
                 y = ((np.einsum("kc,jc->kj", m, x[b].astype(np.int64)) + (1 << (s1 - 1))) >> s1).astype(np.int16)
                 z = ((np.einsum("vj,kj->vk", m, y.astype(np.int64)) + (1 << (s2 - 1))) >> s2).astype(np.int16)
                 assert np.array_equal(out[b], z)
+
+
+# ---- frame container (src/x266.cpp:56-63, 415-492) ---------------------------------------
+def _yuv(w, h, seed):
+    r = splitmix64(seed, 0, w * h * 3 // 2)
+    b = (r & np.uint64(0xFF)).astype(np.uint8)
+    return b[:w * h].reshape(h, w), b[w * h:w * h + w * h // 4].reshape(h // 2, w // 2), b[w * h + w * h // 4:].reshape(h // 2, w // 2)
+
+
+def test_tile_layout_and_round_trip(oracle):
+    w, h = 64, 48
+    y, u, v = _yuv(w, h, 5)
+    tiles = oracle.conv_input_fmt(y, u, v).reshape(h // 16, w // 16, 512)
+    for ty in range(h // 16):
+        for tx in range(w // 16):
+            t = tiles[ty, tx]
+            assert np.array_equal(t[:256].reshape(16, 16), y[16 * ty:16 * ty + 16, 16 * tx:16 * tx + 16])
+            c = t[256:384].reshape(8, 8, 2)                                    # 8 rows of interleaved U,V pairs
+            assert np.array_equal(c[:, :, 0], u[8 * ty:8 * ty + 8, 8 * tx:8 * tx + 8])
+            assert np.array_equal(c[:, :, 1], v[8 * ty:8 * ty + 8, 8 * tx:8 * tx + 8])
+            assert not t[384:].any()                                           # m_I is never written
+    y2, u2, v2 = oracle.conv_output_420(tiles, w, h)
+    assert np.array_equal(y2, y) and np.array_equal(u2, u) and np.array_equal(v2, v)
+
+
+def test_residual_blocks_definition(oracle):
+    w, h = 64, 64
+    yc, uc, vc = _yuv(w, h, 6)
+    yp, up, vp = _yuv(w, h, 7)
+    tc, tp = oracle.conv_input_fmt(yc, uc, vc), oracle.conv_input_fmt(yp, up, vp)
+    d = yc.astype(np.int16) - yp.astype(np.int16)
+    for edge in (8, 32):
+        want = d.reshape(h // edge, edge, w // edge, edge).transpose(0, 2, 1, 3).reshape(-1)
+        assert np.array_equal(oracle.residual_luma(tc, tp, w, h, edge), want)

@@ -57,6 +57,9 @@ def load_library():
         getattr(L, name).argtypes = [_P, _P, _P, _SZ, _P]
     L.xFillResidualDev.argtypes = [_P, _P, _SZ, _U64, _U64, _P]
     L.xTransformFwdBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
+    L.xConvInputFmtDev.argtypes = [_P, _P, _P, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
+    L.xConvOutput420Dev.argtypes = [_P, _P, _P, ctypes.c_ssize_t, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
+    L.xResidualLumaDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]
     L.xSadBatchDev.argtypes = [_P, ctypes.c_int, _P, _P, _P, _SZ, _P]
     L.xSatd8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, _P, _P, _P]
@@ -223,6 +226,15 @@ class Codec:
         self.transform_fwd_dev(ttype, size, din.ptr, dout.ptr, offsets.size, doff.ptr)
         self.stream_sync()
         return dout.download(np.int16, x.size)
+
+    def conv_input_fmt_dev(self, d_tiles, d_y, d_u, d_v, strd_y, w, h, stream=0):
+        self._check(self.L.xConvInputFmtDev(self.ctx, d_tiles, d_y, d_u, d_v, strd_y, w, h, stream), "xConvInputFmtDev")
+
+    def conv_output_420_dev(self, d_tiles, d_y, strd_y, d_u, d_v, strd_c, w, h, stream=0):
+        self._check(self.L.xConvOutput420Dev(self.ctx, d_tiles, d_y, strd_y, d_u, d_v, strd_c, w, h, stream), "xConvOutput420Dev")
+
+    def residual_luma_dev(self, d_cur, d_pred, w, h, edge, d_res, stream=0):
+        self._check(self.L.xResidualLumaDev(self.ctx, d_cur, d_pred, w, h, edge, d_res, stream), "xResidualLumaDev")
 
     def sad_dev(self, edge, d_a, d_b, d_out, n_blocks, stream=0):
         self._check(self.L.xSadBatchDev(self.ctx, edge, d_a, d_b, d_out, n_blocks, stream), "xSadBatchDev")

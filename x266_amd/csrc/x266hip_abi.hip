@@ -315,6 +315,52 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
     return X266HIP_OK;
 }
 
+int xConvInputFmtDev(x266hip_ctx *ctx, x266_ref_block_t *d_tiles, const uint8_t *d_y, const uint8_t *d_u, const uint8_t *d_v,
+                     intptr_t strdY, int width, int height, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (width <= 0 || height <= 0 || (width & 15) || (height & 15)) return fail(ctx, X266HIP_EINVAL, "xConvInputFmtDev: width/height must be multiples of 16");
+    if (!d_tiles || !d_y || !d_u || !d_v) return fail(ctx, X266HIP_EINVAL, "xConvInputFmtDev: NULL buffer");
+    if (strdY < width || (strdY & 15) || (((uintptr_t)d_y | (uintptr_t)d_tiles) & 15u) || (((uintptr_t)d_u | (uintptr_t)d_v) & 7u))
+        return fail(ctx, X266HIP_EINVAL, "xConvInputFmtDev: stride / alignment");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_tile_convert(true, d_tiles, const_cast<uint8_t *>(d_y), const_cast<uint8_t *>(d_u), const_cast<uint8_t *>(d_v),
+                                       (long long)strdY, (long long)(strdY >> 1), width, height, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "tile pack launch", e);
+    return X266HIP_OK;
+}
+
+int xConvOutput420Dev(x266hip_ctx *ctx, const x266_ref_block_t *d_tiles, uint8_t *d_y, intptr_t strdY, uint8_t *d_u, uint8_t *d_v,
+                      intptr_t strdC, int width, int height, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (width <= 0 || height <= 0 || (width & 15) || (height & 15)) return fail(ctx, X266HIP_EINVAL, "xConvOutput420Dev: width/height must be multiples of 16");
+    if (!d_tiles || !d_y || !d_u || !d_v) return fail(ctx, X266HIP_EINVAL, "xConvOutput420Dev: NULL buffer");
+    if (strdY < width || strdC < width / 2 || (strdY & 15) || (strdC & 7) || (((uintptr_t)d_y | (uintptr_t)d_tiles) & 15u) ||
+        (((uintptr_t)d_u | (uintptr_t)d_v) & 7u))
+        return fail(ctx, X266HIP_EINVAL, "xConvOutput420Dev: stride / alignment");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_tile_convert(false, const_cast<x266_ref_block_t *>(d_tiles), d_y, d_u, d_v, (long long)strdY, (long long)strdC,
+                                       width, height, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "tile unpack launch", e);
+    return X266HIP_OK;
+}
+
+int xResidualLumaDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int width, int height,
+                     int block_edge, int16_t *d_residual, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (block_edge != 8 && block_edge != 32) return fail(ctx, X266HIP_EINVAL, "xResidualLumaDev: block_edge must be 8 or 32");
+    const int mask = block_edge == 32 ? 31 : 15;
+    if (width <= 0 || height <= 0 || (width & mask) || (height & mask)) return fail(ctx, X266HIP_EINVAL, "xResidualLumaDev: frame size");
+    if (!d_cur || !d_pred || !d_residual || ((((uintptr_t)d_cur | (uintptr_t)d_pred | (uintptr_t)d_residual)) & 15u))
+        return fail(ctx, X266HIP_EINVAL, "xResidualLumaDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_residual_luma(block_edge, d_cur, d_pred, d_residual, width, height, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "residual launch", e);
+    return X266HIP_OK;
+}
+
 int xSadBatchDev(x266hip_ctx *ctx, int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out, size_t n, void *stream)
 {
     if (!ctx) return X266HIP_EINVAL;
