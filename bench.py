@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--satd-blocks", type=int, default=SATD_BLOCKS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the inverse / SATD legs")
+    ap.add_argument("--stream8k", type=int, default=0, metavar="FRAMES",
+                    help="also time BASELINE configs[4]: 7680x4320 frames, DCT32+SATD batches scattered from rank 0 and gathered back")
     ap.add_argument("--no-me", action="store_true", help="skip the motion-search leg")
     ap.add_argument("--no-transform-set", action="store_true", help="skip the transform-set leg")
     return ap.parse_args()
@@ -307,6 +309,38 @@ def main():
                         "hbm_frac": 4.0 * n * n * nblk / (wall_t / args.steps) / HBM_PEAK_BYTES_PER_S}
             also["transform_set"] = {"classes": ts, "parity": "unpinned upstream except DCT-II 32; bit-exact vs this repo's oracle",
                                      "note": "wall-clock rates (launch gaps included); 4*N*N algorithmic bytes per block"}
+        # ---- BASELINE configs[4] (on request): 8K frame stream, scatter -> kernels -> gather over RCCL
+        if args.stream8k > 0:
+            from x266_amd.stream import FrameGeometry, ShardedFrameStream
+            geo = FrameGeometry(7680, 4320)
+            dev = torch.device("cuda", local_rank)
+            st8 = ShardedFrameStream(
+                geo, dev,
+                lambda tin, tout, nblk: codec.dct32_fwd_dev(tin.data_ptr(), tout.data_ptr(), nblk, stream),
+                lambda tin, tout, nblk: codec.satd8x8_dev(tin.data_ptr(), tout.data_ptr(), nblk, stream),
+                dist=dist)
+            fd = fs = None
+            if rank == 0:
+                fd = torch.empty(geo.dct_blocks * 1024, dtype=torch.int16, device=dev)
+                fs = torch.empty(geo.satd_blocks * 64, dtype=torch.int16, device=dev)
+                codec.fill_residual_dev(fd.data_ptr(), fd.numel(), DCT_SEED, 0, stream)
+                codec.fill_residual_dev(fs.data_ptr(), fs.numel(), SATD_SEED, 0, stream)
+            for _ in range(2):
+                st8.process(fd, fs)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.stream8k):
+                coef8, cost8 = st8.process(fd, fs)
+            barrier()
+            wall8 = max_over_ranks(time.perf_counter() - t0)
+            also["stream8k"] = {
+                "frames_per_s": args.stream8k / wall8, "ms_per_frame": wall8 / args.stream8k * 1e3,
+                "frame": "7680x4320: %d DCT32 blocks (66.4 MB) + %d SATD blocks (66.4 MB)" % (geo.dct_blocks, geo.satd_blocks),
+                "path": "rank 0 scatters the two batches, every rank transforms its shard, rank 0 gathers coefficients and costs"
+                        if world > 1 else "single rank: device copies + kernels, no collective",
+                "link_bound": "one xGMI link ~153 GB/s => <= 7.5e7 DCT32 input blocks/s per peer (SURVEY.md 8e)"}
+            if rank == 0:
+                also["stream8k"]["output_checksum"] = int(coef8.to(torch.int64).sum().item()) + int(cost8.to(torch.int64).sum().item())
         result["also"] = also
 
     # ---- CPU baseline for the headline leg (rank 0, N = 1 only) ------------------------------------
