@@ -189,7 +189,9 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
                                                         const DctOps *__restrict__ ops,
                                                         unsigned blocks_per_wave)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 2048];
+    // dynamic LDS: one 2 KiB slot per wave, plus whatever the launcher adds to cap the number of
+    // resident waves per CU (fewer, smaller workgroups stream better: profiles/r01_wg_occupancy.txt)
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
     const int lane = threadIdx.x & 63;
     unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -264,9 +266,11 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
     dim3 grid((unsigned)wgs), block(tpb);
     const int mode = cfg.passthrough ? 2 : (inverse ? 1 : 0);
     if (cfg.lds_stage && cfg.variant == 0) {                   // line-dense global traffic through a private LDS slot
-        if (mode == 0)      hipLaunchKernelGGL((dct32_lds_kernel<0>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_in, d_out, n_blocks, d_ops, bpw);
-        else if (mode == 1) hipLaunchKernelGGL((dct32_lds_kernel<1>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_in, d_out, n_blocks, d_ops, bpw);
-        else                hipLaunchKernelGGL((dct32_lds_kernel<2>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        const size_t per_wave = cfg.lds_bytes_per_wave < 2048 ? 2048 : (size_t)cfg.lds_bytes_per_wave;
+        const size_t lds = waves_per_wg * per_wave + (size_t)cfg.lds_pad_bytes;
+        if (mode == 0)      hipLaunchKernelGGL((dct32_lds_kernel<0>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else if (mode == 1) hipLaunchKernelGGL((dct32_lds_kernel<1>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else                hipLaunchKernelGGL((dct32_lds_kernel<2>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
         return hipGetLastError();
     }
 #define X266_LAUNCH(MODE, NT) hipLaunchKernelGGL((dct32_kernel<MODE, NT>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_in, d_out, n_blocks, d_ops, bpw)

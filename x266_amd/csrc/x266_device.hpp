@@ -38,6 +38,7 @@ struct LaunchCfg {
     int units_per_wave;  // streaming launch: consecutive units (DCT blocks / 32-block SATD groups) per wave
     int wg_threads;      // workgroup size, multiple of 64
     int lds_pad_bytes;   // unused dynamic LDS per workgroup: caps resident waves per CU (fewer bytes in flight)
+    int lds_bytes_per_wave;   // staged kernels: LDS charged per wave (>= 2048); 160 KiB / this = resident waves per CU
     int lds_stage;       // DCT32: move tiles with linear 1 KiB instructions through a private LDS slot
     int passthrough;     // diagnostic: skip the arithmetic (timing of the memory pattern only)
 };

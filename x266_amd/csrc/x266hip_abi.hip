@@ -44,6 +44,10 @@ struct x266hip_ctx {
     int tr_tiles_per_wave = 1;                      // transform set: 32x32 tiles per wave
     int tr32_simple = 0;                            // diagnostic: run DCT-II 32 through the transform-set kernel
     int satd_lds_stage = 0;                         // measured: no gain for the read-dominated SATD batch (6.2-6.3 TB/s either way)
+    // staged DCT32 launch shape, measured optimum (profiles/r01_wg_occupancy.txt): forward one-wave workgroups
+    // capped at 20 resident waves per CU (160 KiB / 8 KiB), inverse 256-thread workgroups at 26 waves per CU
+    int dct_lds_per_wave = 8192, dct_inv_lds_per_wave = 6144;
+    int dct_wg_threads = 64, dct_inv_wg_threads = 256;
     int dct_lds_stage = 1;                          // see dct32_kernels.hip: dct32_lds_kernel
     int passthrough = 0;                            // diagnostic, see x266_device.hpp
     // host-pointer staging (lazily allocated)
@@ -86,6 +90,8 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
     c.wg_threads = ctx->wg_threads;
     c.passthrough = ctx->passthrough;
     c.lds_stage = op == 2 ? ctx->satd_lds_stage : ctx->dct_lds_stage;
+    c.lds_bytes_per_wave = op == 1 ? ctx->dct_inv_lds_per_wave : ctx->dct_lds_per_wave;
+    if (op != 2 && ctx->dct_lds_stage && ctx->dct_variant == 0) c.wg_threads = op == 1 ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
     c.lds_pad_bytes = op == 2 ? ctx->lds_pad_satd : (op == 1 ? ctx->lds_pad_inv : ctx->lds_pad_dct);
     return c;
 }
@@ -216,6 +222,10 @@ static int *option_slot(x266hip_ctx *ctx, const char *key)
     if (!std::strcmp(key, "diag_passthrough")) return &ctx->passthrough;
     if (!std::strcmp(key, "me_tile_rows")) return &ctx->me_tile_rows;
     if (!std::strcmp(key, "dct32_lds_stage")) return &ctx->dct_lds_stage;
+    if (!std::strcmp(key, "dct32_lds_bytes_per_wave")) return &ctx->dct_lds_per_wave;
+    if (!std::strcmp(key, "dct32_inv_lds_bytes_per_wave")) return &ctx->dct_inv_lds_per_wave;
+    if (!std::strcmp(key, "dct32_wg_threads")) return &ctx->dct_wg_threads;
+    if (!std::strcmp(key, "dct32_inv_wg_threads")) return &ctx->dct_inv_wg_threads;
     if (!std::strcmp(key, "satd_lds_stage")) return &ctx->satd_lds_stage;
     if (!std::strcmp(key, "tr_tiles_per_wave")) return &ctx->tr_tiles_per_wave;
     if (!std::strcmp(key, "tr_lds_stage")) return &ctx->tr_lds_stage;
@@ -234,8 +244,10 @@ int xHipSetOption(x266hip_ctx *ctx, const char *key, int value)
     if (!slot) return X266HIP_EINVAL;
     if (std::strstr(key, "wgs_per_cu") && (value < 1 || value > 64)) return fail(ctx, X266HIP_EINVAL, "wgs_per_cu out of range");
     if (!std::strcmp(key, "tr_tiles_per_wave") && (value < 1 || value > 64)) return fail(ctx, X266HIP_EINVAL, "tiles per wave out of range");
-    if (std::strstr(key, "_per_wave") && (value < 1 || value > 4096)) return fail(ctx, X266HIP_EINVAL, "units per wave out of range");
+    if (std::strstr(key, "_per_wave") && !std::strstr(key, "lds_bytes") && std::strcmp(key, "tr_tiles_per_wave") && (value < 1 || value > 4096)) return fail(ctx, X266HIP_EINVAL, "units per wave out of range");
     if (std::strstr(key, "lds_pad_bytes") && (value < 0 || value > 160 * 1024)) return fail(ctx, X266HIP_EINVAL, "lds pad out of range");
+    if (std::strstr(key, "lds_bytes_per_wave") && (value < 2048 || value > 40960)) return fail(ctx, X266HIP_EINVAL, "lds bytes per wave out of range");
+    if (std::strstr(key, "_wg_threads") && (value < 64 || value > 256 || value % 64)) return fail(ctx, X266HIP_EINVAL, "wg_threads must be 64, 128, 192 or 256");
     if (!std::strcmp(key, "wg_threads") && (value < 64 || value > 256 || value % 64)) return fail(ctx, X266HIP_EINVAL, "wg_threads must be 64, 128, 192 or 256");
     *slot = value;
     return X266HIP_OK;
