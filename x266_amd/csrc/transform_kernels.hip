@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
     constexpr int N = 1 << LOGN;
     constexpr int PER = 32 / N, PIECES = N >= 16 ? 1 : 16 / N, NSB = PER * PER;
     constexpr int S1 = LOGN - 1, S2 = LOGN + 6;
-    __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 2048];
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 2 KiB per wave (+ occupancy padding)
     unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
 
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
@@ -182,17 +182,22 @@ hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out
     const size_t tiles = (n_blocks + per_tile - 1) / per_tile;
     const unsigned tpw = cfg.units_per_wave < 1 ? 1u : (unsigned)cfg.units_per_wave;
     const size_t waves = (tiles + tpw - 1) / tpw;
-    const size_t wgs = (waves + 3) / 4;
-    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    dim3 grid((unsigned)wgs), block(256);
     if (!d_offsets && cfg.lds_stage) {                           // contiguous batch: line-dense traffic through LDS
-        if (log2n == 2)      hipLaunchKernelGGL((tr_fwd_small_lds_kernel<2>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, tpw);
-        else if (log2n == 3) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<3>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, tpw);
-        else if (log2n == 4) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<4>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, tpw);
-        else if (log2n == 5) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<5>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, tpw);
+        const unsigned tpb = (unsigned)cfg.wg_threads;            // same launch shape as the staged DCT32 kernel
+        const size_t wpw = tpb / 64, swgs = (waves + wpw - 1) / wpw;
+        if (swgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
+        dim3 sgrid((unsigned)swgs), sblock(tpb);
+        if (log2n == 2)      hipLaunchKernelGGL((tr_fwd_small_lds_kernel<2>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
+        else if (log2n == 3) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<3>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
+        else if (log2n == 4) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<4>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
+        else if (log2n == 5) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<5>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
+    const size_t wgs = (waves + 3) / 4;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)wgs), block(256);
 #define X266_TR(L) do { if (d_offsets) hipLaunchKernelGGL((tr_fwd_small_kernel<L, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
                         else           hipLaunchKernelGGL((tr_fwd_small_kernel<L, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
     if (log2n == 2) X266_TR(2); else if (log2n == 3) X266_TR(3); else if (log2n == 4) X266_TR(4); else if (log2n == 5) X266_TR(5);

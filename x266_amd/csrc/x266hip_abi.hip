@@ -314,6 +314,8 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
         LaunchCfg cfg32 = cfg_for(ctx, 0);
         cfg32.units_per_wave = ctx->tr_tiles_per_wave;
         cfg32.lds_stage = ctx->tr_lds_stage;
+        cfg32.wg_threads = ctx->dct_wg_threads;
+        cfg32.lds_bytes_per_wave = ctx->dct_lds_per_wave;
         hipError_t e32 = launch_transform_small(5, d_in, d_out, n, ctx->d_fwd, d_offsets, cfg32, (hipStream_t)stream);
         if (e32 != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "transform launch", e32);
         return X266HIP_OK;
@@ -321,7 +323,9 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
     const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
     LaunchCfg cfg = cfg_for(ctx, 0);
     cfg.units_per_wave = ctx->tr_tiles_per_wave;
-    cfg.lds_stage = ctx->tr_lds_stage && size != 8;       // 8x8 fragment loads are line-dense already
+    cfg.lds_stage = ctx->tr_lds_stage;
+    cfg.wg_threads = ctx->dct_wg_threads;
+    cfg.lds_bytes_per_wave = ctx->dct_lds_per_wave;
     hipError_t e = launch_transform_small(l + 2, d_in, d_out, n, ctx->d_tr[type][l], d_offsets, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "transform launch", e);
     return X266HIP_OK;
