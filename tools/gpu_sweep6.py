@@ -14,7 +14,7 @@ def t(op):
     return min(cd.time_kernel(op, din.ptr, dout.ptr, N, 20) for _ in range(4))
 for tpb in (64, 128, 256):
     cd.set_option("dct32_wg_threads", tpb); cd.set_option("dct32_inv_wg_threads", tpb)
-    for per in (2048, 5120, 6144, 7168, 8192, 10240, 13312, 20480):
+    for per in (2048, 6144, 8192, 10240):
         cd.set_option("dct32_lds_bytes_per_wave", per); cd.set_option("dct32_inv_lds_bytes_per_wave", per)
         row = "tpb=%3d lds/wave=%5d (<=%2d waves/CU) |" % (tpb, per, min(32, 163840 // per))
         for bpw in (1, 2):

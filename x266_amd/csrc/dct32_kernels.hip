@@ -51,19 +51,11 @@ __device__ __forceinline__ int clamp16(int v)
     return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);   // folds to v_med3_i32
 }
 
-__device__ __forceinline__ void inv_block(const v4i &w0, const v4i &w1, const LaneConsts &k,
-                                          const v16i &c2r, v4i &o0, v4i &o1)
+// passes A and B on column data: zlo / zhi = byte planes of 16 samples of ONE COLUMN per lane
+__device__ __forceinline__ void inv_passes(const v4i &zlo, const v4i &zhi, const LaneConsts &k,
+                                           const v16i &c2r, v4i &o0, v4i &o1)
 {
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    v4i lo, hi;
-    split_planes(w0, w1, lo, hi);
-
-    // transpose both planes (values stay single bytes: no carries between planes)
-    const v16i thi = mfma(hi, k.tr, zero);
-    const v16i tlo = mfma(lo, k.tr, zero);
-    const v4i zhi = pack_bytes(thi);
-    const v4i zlo = pack_bytes(tlo);
-
     // pass A (columns): data = A, coefficients = B, per-lane constant
     v16i acc = mfma(zhi, k.p1, zero);
 #pragma unroll
@@ -88,6 +80,19 @@ __device__ __forceinline__ void inv_block(const v4i &w0, const v4i &w1, const La
     }
     o0 = v4i{(int)z[0], (int)z[1], (int)z[2], (int)z[3]};
     o1 = v4i{(int)z[4], (int)z[5], (int)z[6], (int)z[7]};
+}
+
+// row-per-lane input (no LDS): transpose both planes on the matrix core first
+__device__ __forceinline__ void inv_block(const v4i &w0, const v4i &w1, const LaneConsts &k,
+                                          const v16i &c2r, v4i &o0, v4i &o1)
+{
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v4i lo, hi;
+    split_planes(w0, w1, lo, hi);
+    // values stay single bytes: no carries between planes
+    const v16i thi = mfma(hi, k.tr, zero);
+    const v16i tlo = mfma(lo, k.tr, zero);
+    inv_passes(pack_bytes(tlo), pack_bytes(thi), k, c2r, o0, o1);
 }
 
 // ---- kernel ----------------------------------------------------------------
@@ -203,6 +208,13 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
     // this lane's two linear chunks (16 B each) and its two fragment chunks
     const unsigned lin0 = lds_slot(lane >> 2, lane & 3), lin1 = lds_slot(16 + (lane >> 2), lane & 3);
     const unsigned frag0 = lds_slot(c, 2 * h), frag1 = lds_slot(c, 2 * h + 1);
+    // inverse: byte offset of element (row 16h + t, column u) is col_base[(t >> 2) & 3] + 64 t, u = kappa(c)
+    unsigned col_base[4];
+    {
+        const unsigned u = (unsigned)kappa((int)c);
+#pragma unroll
+        for (unsigned j = 0; j < 4; ++j) col_base[j] = 16u * h * 64u + ((((u >> 3) ^ j) & 3u) << 4) + (u & 7u) * 2u;
+    }
     const char *src = reinterpret_cast<const char *>(in) + lane * 16;
     char *dst = reinterpret_cast<char *>(out) + lane * 16;
 
@@ -210,8 +222,11 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
     const LaneConsts k = load_consts(ops, lane);
     v16i c2r;
     if (MODE == 1) {
+        // the pass-B constants depend on (half, register) only: two scalar loads (wave-uniform
+        // addresses) and a per-lane select instead of 64 bytes of vector loads per lane and wave
+        const int *__restrict__ s0 = ops->c2r[0], *__restrict__ s1 = ops->c2r[32];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c2r[r] = ops->c2r[lane][r];
+        for (int r = 0; r < 16; ++r) c2r[r] = h ? s1[r] : s0[r];
     }
     while (true) {
         const size_t nb = b + 1;
@@ -222,12 +237,27 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
             g1 = load16<false>(src + nb * 2048 + 1024);
         }
         __builtin_amdgcn_wave_barrier();
-        const v4i a0 = *reinterpret_cast<const v4i *>(slot + frag0);
-        const v4i a1 = *reinterpret_cast<const v4i *>(slot + frag1);
         v4i o0, o1;
-        if (MODE == 1)      inv_block(a0, a1, k, c2r, o0, o1);
-        else if (MODE == 0) fwd_block<4, 11>(a0, a1, k, o0, o1);
-        else                { o0 = a0 ^ k.p1; o1 = a1 ^ k.p2; }
+        if (MODE == 1) {
+            // The inverse contracts over the block's ROW index first: with the tile in LDS the lane
+            // simply reads its COLUMN (16 x ds_read_u16) -- the matrix-core transpose of the direct
+            // kernel (2 MFMA + 24 v_perm) is not needed.  Lane (c, h): column kappa(c), rows 16h..16h+15.
+            uint32_t w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const uint32_t e0 = *reinterpret_cast<const uint16_t *>(slot + col_base[((2 * m) >> 2) & 3] + (2 * m) * 64);
+                const uint32_t e1 = *reinterpret_cast<const uint16_t *>(slot + col_base[((2 * m + 1) >> 2) & 3] + (2 * m + 1) * 64);
+                w[m] = e0 | (e1 << 16);
+            }
+            v4i lo, hi;
+            split_planes(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, lo, hi);
+            inv_passes(lo, hi, k, c2r, o0, o1);
+        } else {
+            const v4i a0 = *reinterpret_cast<const v4i *>(slot + frag0);
+            const v4i a1 = *reinterpret_cast<const v4i *>(slot + frag1);
+            if (MODE == 0) fwd_block<4, 11>(a0, a1, k, o0, o1);
+            else           { o0 = a0 ^ k.p1; o1 = a1 ^ k.p2; }
+        }
         __builtin_amdgcn_wave_barrier();
         *reinterpret_cast<v4i *>(slot + frag0) = o0;
         *reinterpret_cast<v4i *>(slot + frag1) = o1;
@@ -246,7 +276,7 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
 
 // ---- launchers ---------------------------------------------------------------
 hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_blocks,
-                        const DctOps *d_ops, const LaunchCfg &cfg, hipStream_t stream)
+                        const DctOps *d_ops, const DctOps *d_ops_lds_inv, const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
     const unsigned tpb = cfg.wg_threads;                       // 64 .. 256, multiple of 64
@@ -269,7 +299,7 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
         const size_t per_wave = cfg.lds_bytes_per_wave < 2048 ? 2048 : (size_t)cfg.lds_bytes_per_wave;
         const size_t lds = waves_per_wg * per_wave + (size_t)cfg.lds_pad_bytes;
         if (mode == 0)      hipLaunchKernelGGL((dct32_lds_kernel<0>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
-        else if (mode == 1) hipLaunchKernelGGL((dct32_lds_kernel<1>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else if (mode == 1) hipLaunchKernelGGL((dct32_lds_kernel<1>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops_lds_inv, bpw);
         else                hipLaunchKernelGGL((dct32_lds_kernel<2>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
         return hipGetLastError();
     }

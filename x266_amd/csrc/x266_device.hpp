@@ -46,7 +46,7 @@ struct LaunchCfg {
 struct DctOps;
 
 hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_blocks,
-                        const DctOps *d_ops, const LaunchCfg &cfg, hipStream_t stream);
+                        const DctOps *d_ops, const DctOps *d_ops_lds_inv, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
                                   const uint32_t *d_offsets, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks,

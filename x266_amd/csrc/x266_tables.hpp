@@ -109,7 +109,9 @@ inline void build_fwd_ops(DctOps &o)
 //   pass B:    Db[i][y] = sum_u g[u][kappa(i)] * T[u][y]        const = A, data = B
 //              slot (h,t) <-> u = 16h + t; constant depends on x = 16h + r
 // Offset fix: 128 * sum_k g[k][n] (a COLUMN sum here, non-zero for every n).
-inline void build_inv_ops(DctOps &o)
+// natural_rows: the data operand of pass A holds rows v = 16h + t (a column read from LDS)
+// instead of the accumulator order acc_row(t, h) left by the matrix-core transpose.
+inline void build_inv_ops(DctOps &o, bool natural_rows = false)
 {
     constexpr Table32 g = make_table32();
     int colsum[32] = {};
@@ -119,7 +121,7 @@ inline void build_inv_ops(DctOps &o)
         const int c = l & 31, h = l >> 5;
         int8_t ba[16], ab[16], id[16];
         for (int t = 0; t < 16; ++t) {
-            ba[t] = static_cast<int8_t>(g.v[acc_row(t, h)][c]);        // pass A: g[v][y=c]
+            ba[t] = static_cast<int8_t>(g.v[natural_rows ? 16 * h + t : acc_row(t, h)][c]);   // pass A: g[v][y=c]
             ab[t] = static_cast<int8_t>(g.v[16 * h + t][kappa(c)]);    // pass B: g[u][x=kappa(c)]
             id[t] = static_cast<int8_t>((16 * h + t) == kappa(c) ? 1 : 0);
         }

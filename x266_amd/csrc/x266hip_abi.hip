@@ -24,6 +24,7 @@ struct x266hip_ctx {
     hipDeviceProp_t prop{};
     DctOps *d_fwd = nullptr;
     DctOps *d_inv = nullptr;
+    DctOps *d_inv_lds = nullptr;                    // inverse operand images for the LDS-staged kernel (column reads)
     DctOps *d_tr[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // [type][log2N - 2], N = 4, 8, 16
     // options
     int wgs_per_cu_dct = 8;
@@ -45,9 +46,9 @@ struct x266hip_ctx {
     int tr32_simple = 0;                            // diagnostic: run DCT-II 32 through the transform-set kernel
     int satd_lds_stage = 0;                         // measured: no gain for the read-dominated SATD batch (6.2-6.3 TB/s either way)
     // staged DCT32 launch shape, measured optimum (profiles/r01_wg_occupancy.txt): forward one-wave workgroups
-    // capped at 20 resident waves per CU (160 KiB / 8 KiB), inverse 256-thread workgroups at 26 waves per CU
-    int dct_lds_per_wave = 8192, dct_inv_lds_per_wave = 6144;
-    int dct_wg_threads = 64, dct_inv_wg_threads = 256;
+    // capped at 20 resident waves per CU (160 KiB / 8 KiB), 1 block per wave forward, 2 inverse
+    int dct_lds_per_wave = 8192, dct_inv_lds_per_wave = 8192;
+    int dct_wg_threads = 64, dct_inv_wg_threads = 64;
     int dct_lds_stage = 1;                          // see dct32_kernels.hip: dct32_lds_kernel
     int passthrough = 0;                            // diagnostic, see x266_device.hpp
     // host-pointer staging (lazily allocated)
@@ -100,8 +101,8 @@ int launch_op(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n,
 {
     hipError_t e;
     switch (op) {
-    case 0: e = launch_dct32(false, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_fwd, cfg_for(ctx, 0), s); break;
-    case 1: e = launch_dct32(true, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_inv, cfg_for(ctx, 1), s); break;
+    case 0: e = launch_dct32(false, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_fwd, nullptr, cfg_for(ctx, 0), s); break;
+    case 1: e = launch_dct32(true, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_inv, ctx->d_inv_lds, cfg_for(ctx, 1), s); break;
     case 2: e = launch_satd8x8((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s); break;
     default: return fail(ctx, X266HIP_EINVAL, "unknown op");
     }
@@ -157,6 +158,11 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
         build_inv_ops(*h);
         ok = hipMemcpy(ctx->d_inv, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
     }
+    if (ok) {
+        build_inv_ops(*h, true);
+        ok = hipMalloc((void **)&ctx->d_inv_lds, sizeof(DctOps)) == hipSuccess &&
+             hipMemcpy(ctx->d_inv_lds, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
+    }
     for (int type = 0; type < 2 && ok; ++type)
         for (int l = 0; l < 3 && ok; ++l) {
             const int n = 4 << l;
@@ -188,6 +194,7 @@ void xHipCodecFree(x266hip_ctx *ctx)
     if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
     if (ctx->d_inv) (void)hipFree(ctx->d_inv);
+    if (ctx->d_inv_lds) (void)hipFree(ctx->d_inv_lds);
     delete ctx;
 }
 
