@@ -266,3 +266,45 @@ def test_bdpi_in_process(codec):
         assert np.array_equal(np.frombuffer(res, np.uint32), g["diff_words"][0, i])
     words = [L.dct32_getDct() for _ in range(256)]
     assert words == [int(w) for w in g["dct_words"][0]]
+
+
+def test_offsets_beyond_4_gib(codec, oracle):
+    """Maximum sizes: 2.6 Mi blocks = 5.2 GiB per buffer, so byte offsets exceed 32 bits.
+    Blocks sampled from the head, the 4 GiB boundary and the tail must match the oracle."""
+    n = (5 << 30) // 2048 + 100_003
+    din, dout = codec.alloc(n * 2048), codec.alloc(n * 2048)
+    codec.fill_residual_dev(din.ptr, n * 1024, 0x266)
+    codec.dct32_fwd_dev(din.ptr, dout.ptr, n)
+    codec.stream_sync()
+    edge = (4 << 30) // 2048
+    for first in (0, edge - 3, edge + 1, n - 7):
+        cnt = 6
+        x = np.empty(cnt * 1024, np.int16)
+        z = np.empty(cnt * 1024, np.int16)
+        codec._check(codec.L.xHipMemcpyD2H(codec.ctx, x.ctypes.data, din.ptr + first * 2048, x.nbytes), "D2H")
+        codec._check(codec.L.xHipMemcpyD2H(codec.ctx, z.ctypes.data, dout.ptr + first * 2048, z.nbytes), "D2H")
+        assert np.array_equal(x, residual_np(cnt * 1024, 0x266, first * 1024))
+        assert np.array_equal(z.reshape(cnt, 1024), oracle.dct32_fwd(x))
+    # SATD over the same bytes viewed as 8x8 blocks (16x as many units)
+    ns = n * 16
+    dsat = codec.alloc(ns * 4)
+    codec.satd8x8_dev(din.ptr, dsat.ptr, ns)
+    codec.stream_sync()
+    for first in (0, (4 << 30) // 128 - 5, ns - 40):
+        cnt = 37
+        d = np.empty(cnt * 64, np.int16)
+        s = np.empty(cnt, np.uint32)
+        codec._check(codec.L.xHipMemcpyD2H(codec.ctx, d.ctypes.data, din.ptr + first * 128, d.nbytes), "D2H")
+        codec._check(codec.L.xHipMemcpyD2H(codec.ctx, s.ctypes.data, dsat.ptr + first * 4, s.nbytes), "D2H")
+        assert np.array_equal(s, oracle.satd8x8(d))
+
+
+def test_plain_c_host_example():
+    """host/batch_example.c: a C host with no HIP headers drives the batch API and cross-checks the
+    BDPI surface against it."""
+    exe = os.path.join(ROOT, "host", "batch_example")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "--no-print-directory"])
+    out = subprocess.run([exe, "5000"], timeout=300, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "agree on the rand() block" in out.stdout
