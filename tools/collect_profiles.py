@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copy the rocprofv3 summaries of a bench run from gpurun_out/ into profiles/ (tracked).
-usage: collect_profiles.py <round-tag> <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <bench_json> [pytest_log]"""
+usage: collect_profiles.py <round-tag> <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <bench_json> [pytest_log [pmc_sq_dir pmc_lds_dir]]"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +21,42 @@ def short(n):
     if "satd8x8_kernel" in n: return "satd8x8_kernel"
     if "fill_residual" in n: return "fill_residual_kernel"
     return None
+
+
+def kname(n):
+    import re
+    m = re.search(r"::(\w+(?:<[^>]*>)?)\(", n.replace("(anonymous namespace)::", ""))
+    return m.group(1) if m else n[:40]
+
+
+def sq_summary(tag, sq_dir, lds_dir):
+    """SQ / LDS counters -> profiles/<tag>_pmc_sq_counters.csv plus derived per-SIMD utilisations."""
+    out = ["# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU SQ_WAVE_CYCLES "
+           "SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE   and a second pass   --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS "
+           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY   -- python bench.py --no-cpu-baseline --steps 5 --warmup 2",
+           "# mean per dispatch, summed over the chip as rocprofv3 reports it", "kernel,counter,dispatches,mean"]
+    tab = collections.defaultdict(dict)
+    for d in (sq_dir, lds_dir):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(one(os.path.join(d, "**", "*_counter_collection.csv")))):
+            if "x266" in r["Kernel_Name"]:
+                acc[(kname(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in sorted(acc.items()):
+            out.append("%s,%s,%d,%.6g" % (k, c, len(v), sum(v) / len(v)))
+            tab[k][c] = sum(v) / len(v)
+    out.append("# derived: cycles = GRBM_GUI_ACTIVE / 8 XCDs; per-SIMD busy = counter / (1024 SIMDs * cycles); "
+               "SQ_ACTIVE_INST_VALU counts quad-cycles; LDS per CU (256)")
+    out.append("kernel,mfma_busy_frac,valu_busy_frac,lds_busy_frac,cycles_per_mfma,wave_wait_frac")
+    for k, v in sorted(tab.items()):
+        if "GRBM_GUI_ACTIVE" not in v:
+            continue
+        cyc = v["GRBM_GUI_ACTIVE"] / 8
+        out.append("%s,%.3f,%.3f,%.3f,%.1f,%.2f" % (
+            k, v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc),
+            v.get("SQ_LDS_IDX_ACTIVE", 0) / (256 * cyc), v["SQ_VALU_MFMA_BUSY_CYCLES"] / max(v["SQ_INSTS_VALU_MFMA_I8"], 1),
+            v.get("SQ_WAIT_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 1), 1)))
+    open(os.path.join(P, tag + "_pmc_sq_counters.csv"), "w").write("\n".join(out) + "\n")
+    print("\n".join(out[-12:]))
 
 
 def main():
@@ -59,6 +95,8 @@ def main():
     shutil.copy(bench, os.path.join(P, tag + "_bench.json"))
     if len(sys.argv) > 6:
         shutil.copy(sys.argv[6], os.path.join(P, tag + "_pytest_gpu.txt"))
+    if len(sys.argv) > 8:
+        sq_summary(tag, sys.argv[7], sys.argv[8])
     print(open(os.path.join(P, tag + "_pmc_hbm_traffic.csv")).read())
     for r in rows[:4]:
         print(r["Name"][:70], r["Calls"], "avg_ns", r["AverageNs"])
