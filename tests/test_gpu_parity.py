@@ -154,13 +154,14 @@ def test_argument_errors(codec):
 def test_launch_geometry_options_do_not_change_results(codec, oracle, variant, nt, tpb, per_wave, wgs, stage):
     x = residual_np(3001 * 1024, 0x266).reshape(-1, 1024)
     d = x.reshape(-1, 64)[:100003]
-    keys = ("nontemporal", "wg_threads", "dct32_lds_stage", "satd_lds_stage", "dct32_variant", "satd_variant", "dct32_blocks_per_wave",
+    keys = ("nontemporal", "wg_threads", "satd_wg_threads", "dct32_wg_threads", "dct32_inv_wg_threads", "dct32_lds_stage", "satd_lds_stage", "dct32_variant", "satd_variant", "dct32_blocks_per_wave",
             "dct32_inv_blocks_per_wave", "satd_groups_per_wave", "dct32_wgs_per_cu", "dct32_inv_wgs_per_cu",
             "satd_wgs_per_cu")
     saved = {k: codec.get_option(k) for k in keys}
     try:
         codec.set_option("nontemporal", nt)
-        codec.set_option("wg_threads", tpb)
+        for k in ("wg_threads", "satd_wg_threads", "dct32_wg_threads", "dct32_inv_wg_threads"):
+            codec.set_option(k, tpb)
         codec.set_option("dct32_lds_stage", stage)
         codec.set_option("satd_lds_stage", stage)
         for k in ("dct32_variant", "satd_variant"):

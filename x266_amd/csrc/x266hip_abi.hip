@@ -33,8 +33,9 @@ struct x266hip_ctx {
     int nontemporal = 0;
     int dct_variant = 0, satd_variant = 0;          // 0 streaming launch, 1 persistent
     // streaming launch: consecutive units per wave (measured optimum on MI355X, profiles/r01_sweep.txt)
-    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 1;
+    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 2;
     int wg_threads = 256;
+    int satd_wg_threads = 64;                       // SATD batch: one-wave workgroups (profiles/r01_satd_launch_shape.txt)
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
     int me_tile_rows = 4;                           // block rows per ME tile (1, 2 or 4)
     int me_row_pairs = 1;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
@@ -88,7 +89,7 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
     c.nontemporal = ctx->nontemporal;
     c.variant = op == 2 ? ctx->satd_variant : ctx->dct_variant;
     c.units_per_wave = op == 2 ? ctx->satd_groups_per_wave : (op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave);
-    c.wg_threads = ctx->wg_threads;
+    c.wg_threads = op == 2 ? ctx->satd_wg_threads : ctx->wg_threads;
     c.passthrough = ctx->passthrough;
     c.lds_stage = op == 2 ? ctx->satd_lds_stage : ctx->dct_lds_stage;
     c.lds_bytes_per_wave = op == 1 ? ctx->dct_inv_lds_per_wave : ctx->dct_lds_per_wave;
@@ -226,6 +227,7 @@ static int *option_slot(x266hip_ctx *ctx, const char *key)
     if (!std::strcmp(key, "dct32_inv_blocks_per_wave")) return &ctx->dct_inv_blocks_per_wave;
     if (!std::strcmp(key, "satd_groups_per_wave")) return &ctx->satd_groups_per_wave;
     if (!std::strcmp(key, "wg_threads")) return &ctx->wg_threads;
+    if (!std::strcmp(key, "satd_wg_threads")) return &ctx->satd_wg_threads;
     if (!std::strcmp(key, "diag_passthrough")) return &ctx->passthrough;
     if (!std::strcmp(key, "me_tile_rows")) return &ctx->me_tile_rows;
     if (!std::strcmp(key, "dct32_lds_stage")) return &ctx->dct_lds_stage;
