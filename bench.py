@@ -311,6 +311,46 @@ def main():
             del zt
             also["transform_set"] = {"classes": ts, "parity": "unpinned upstream except DCT-II 32; bit-exact vs this repo's oracle",
                                      "note": "wall-clock rates (launch gaps included); 4*N*N algorithmic bytes per block"}
+        # ---- fused front end: tiled cur/pred frames -> coefficients / costs, residual never in HBM
+        if not args.no_transform_set:
+            fw, fh = 16384, 16384
+            ntile = (fw // 16) * (fh // 16)
+            gq = torch.Generator(device="cuda")
+            gq.manual_seed(0x266)
+            tcur = torch.randint(0, 256, (ntile * 512,), generator=gq, device="cuda", dtype=torch.uint8)
+            tpred = torch.randint(0, 256, (ntile * 512,), generator=gq, device="cuda", dtype=torch.uint8)
+            fcoef = torch.empty(fw * fh, dtype=torch.int16, device="cuda")
+            fcost = torch.empty(fw * fh // 64, dtype=torch.int32, device="cuda")
+            fres = torch.empty(fw * fh, dtype=torch.int16, device="cuda")
+            fused = {}
+            legs = (
+                ("dct32_from_tiles", fw * fh // 1024, 4096,
+                 lambda: codec.dct32_fwd_from_tiles_dev(tcur.data_ptr(), tpred.data_ptr(), fw, fh, fcoef.data_ptr(), stream)),
+                ("dct32_residual_then_transform", fw * fh // 1024, None,
+                 lambda: (codec.residual_luma_dev(tcur.data_ptr(), tpred.data_ptr(), fw, fh, 32, fres.data_ptr(), stream),
+                          codec.dct32_fwd_dev(fres.data_ptr(), fcoef.data_ptr(), fw * fh // 1024, stream))),
+                ("satd8x8_from_tiles", fw * fh // 64, 132,
+                 lambda: codec.satd8x8_from_tiles_dev(tcur.data_ptr(), tpred.data_ptr(), fw, fh, fcost.data_ptr(), stream)),
+                ("satd8x8_residual_then_cost", fw * fh // 64, None,
+                 lambda: (codec.residual_luma_dev(tcur.data_ptr(), tpred.data_ptr(), fw, fh, 8, fres.data_ptr(), stream),
+                          codec.satd8x8_dev(fres.data_ptr(), fcost.data_ptr(), fw * fh // 64, stream))))
+            for name, units, bytes_per_unit, fn in legs:
+                for _ in range(3):
+                    fn()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    fn()
+                barrier()
+                wall_f = max_over_ranks(time.perf_counter() - t0)
+                fused[name] = {"value": world * units * args.steps / wall_f, "unit": "blocks/s"}
+                if bytes_per_unit:
+                    fused[name]["hbm_frac"] = bytes_per_unit * units / (wall_f / args.steps) / HBM_PEAK_BYTES_PER_S
+            fused["note"] = ("%dx%d tiled frame pair (x266.cpp ref_block_t); fused kernels are bit-identical to the two-kernel paths "
+                             "listed next to them (tests/test_gpu_tiles.py)" % (fw, fh))
+            also["fused_from_tiles"] = fused
+            del tcur, tpred, fcoef, fcost, fres
+
         # ---- BASELINE configs[4] (on request): 8K frame stream, scatter -> kernels -> gather over RCCL
         if args.stream8k > 0:
             from x266_amd.stream import FrameGeometry, ShardedFrameStream

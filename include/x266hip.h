@@ -147,6 +147,16 @@ int xConvOutput420Dev(x266hip_ctx *ctx, const x266_ref_block_t *d_tiles, uint8_t
  * of 32), block_edge 8 feeds xSatd8x8BatchDev (multiples of 16). */
 int xResidualLumaDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred,
                      int width, int height, int block_edge, int16_t *d_residual, void *stream);
+/* Fused residual formation + forward DCT32: d_coef[block] = DCT32(cur - pred) for every 32x32 luma
+ * block of two tiled frames, blocks in raster order -- bit-identical to xResidualLumaDev(.., 32, ..)
+ * followed by xDct32FwdBatchDev, without the residual ever touching HBM (half the traffic). */
+int xDct32FwdFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred,
+                          int width, int height, int16_t *d_coef, void *stream);
+/* Fused residual formation + SATD: d_out[block] = satd8x8(cur - pred) for every 8x8 luma block of
+ * two tiled frames (raster order of blocks) -- bit-identical to xResidualLumaDev(.., 8, ..) followed
+ * by xSatd8x8BatchDev.  width, height multiples of 16. */
+int xSatd8x8FromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred,
+                         int width, int height, uint32_t *d_out, void *stream);
 /* Sum of absolute differences of n_blocks pairs of edge x edge 8-bit blocks (edge in
  * {4, 8, 16, 32, 64}; each block edge*edge contiguous bytes, row-major; buffers 16-byte
  * aligned): d_out[b] = sum |a - b|, exactly sad() of

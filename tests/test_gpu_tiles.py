@@ -52,7 +52,7 @@ def test_pack_and_unpack(codec, oracle, w, h, strd):
     assert np.array_equal(ov.download(np.uint8, w * h // 4).reshape(h // 2, w // 2), v[:, :w // 2])
 
 
-@pytest.mark.parametrize("w,h", [(32, 32), (64, 96), (1920, 1088)])
+@pytest.mark.parametrize("w,h", [(32, 32), (64, 96), (160, 96), (1920, 1088)])
 def test_residual_then_transform_and_cost(codec, oracle, w, h):
     yc, uc, vc = _yuv(w, h, 21 + w)
     yp, up, vp = _yuv(w, h, 22 + w)
@@ -72,17 +72,49 @@ def test_residual_then_transform_and_cost(codec, oracle, w, h):
             dz = codec.alloc(w * h * 2)
             codec.dct32_fwd_dev(dres.ptr, dz.ptr, n)
             codec.stream_sync()
-            assert np.array_equal(dz.download(np.int16, w * h).reshape(n, 1024), oracle.dct32_fwd(res, threads=8))
+            want = oracle.dct32_fwd(res, threads=8)
+            assert np.array_equal(dz.download(np.int16, w * h).reshape(n, 1024), want)
+            dz2 = codec.alloc(w * h * 2)                               # fused: tiles -> coefficients in one kernel
+            codec.dct32_fwd_from_tiles_dev(dc.ptr, dp.ptr, w, h, dz2.ptr)
+            codec.stream_sync()
+            assert np.array_equal(dz2.download(np.int16, w * h).reshape(n, 1024), want)
         else:                                                          # ... straight into the cost
             ds = codec.alloc(n * 4)
             codec.satd8x8_dev(dres.ptr, ds.ptr, n)
             codec.stream_sync()
-            assert np.array_equal(ds.download(np.uint32, n), oracle.satd8x8(res, threads=8))
+            want = oracle.satd8x8(res, threads=8)
+            assert np.array_equal(ds.download(np.uint32, n), want)
+            ds2 = codec.alloc(n * 4)                                   # fused: tiles -> costs in one kernel
+            codec.satd8x8_from_tiles_dev(dc.ptr, dp.ptr, w, h, ds2.ptr)
+            codec.stream_sync()
+            assert np.array_equal(ds2.download(np.uint32, n), want)
+
+
+def test_fused_transform_extreme_pixels(codec, oracle):
+    """0 / 255 pixels drive the differences to +-255, the edge of the single-byte-plane path."""
+    w, h = 64, 64
+    r = splitmix64(99, 0, 2 * w * h)
+    yc = np.where(r[: w * h] & np.uint64(1), 255, 0).astype(np.uint8).reshape(h, w)
+    yp = np.where(r[w * h:] & np.uint64(2), 255, 0).astype(np.uint8).reshape(h, w)
+    z = np.zeros((h // 2, w // 2), np.uint8)
+    dc, nt = _pack(codec, yc, z, z, w, h)
+    dp, _ = _pack(codec, yp, z, z, w, h)
+    dz = codec.alloc(w * h * 2)
+    codec.dct32_fwd_from_tiles_dev(dc.ptr, dp.ptr, w, h, dz.ptr)
+    codec.stream_sync()
+    d = (yc.astype(np.int16) - yp.astype(np.int16)).reshape(h // 32, 32, w // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 1024)
+    assert np.array_equal(dz.download(np.int16, w * h).reshape(-1, 1024), oracle.dct32_fwd(d))
+    ds = codec.alloc(w * h // 64 * 4)
+    codec.satd8x8_from_tiles_dev(dc.ptr, dp.ptr, w, h, ds.ptr)
+    codec.stream_sync()
+    d8 = (yc.astype(np.int16) - yp.astype(np.int16)).reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)
+    assert np.array_equal(ds.download(np.uint32, w * h // 64), oracle.satd8x8(d8))
 
 
 def test_argument_errors(codec):
     L = codec.L
     buf = codec.alloc(1 << 16)
+    assert L.xDct32FwdFromTilesDev(codec.ctx, buf.ptr, buf.ptr, 48, 32, buf.ptr, None) < 0                 # 48 % 32
     assert L.xConvInputFmtDev(codec.ctx, buf.ptr, buf.ptr, buf.ptr, buf.ptr, 24, 24, 16, None) < 0         # width % 16
     assert L.xConvInputFmtDev(codec.ctx, buf.ptr, None, buf.ptr, buf.ptr, 32, 32, 16, None) < 0
     assert L.xResidualLumaDev(codec.ctx, buf.ptr, buf.ptr, 48, 32, 32, buf.ptr, None) < 0                  # 48 % 32

@@ -60,6 +60,8 @@ def load_library():
     L.xConvInputFmtDev.argtypes = [_P, _P, _P, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
     L.xConvOutput420Dev.argtypes = [_P, _P, _P, ctypes.c_ssize_t, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
     L.xResidualLumaDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]
+    L.xDct32FwdFromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
+    L.xSatd8x8FromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
     L.xSadBatchDev.argtypes = [_P, ctypes.c_int, _P, _P, _P, _SZ, _P]
     L.xSatd8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, _P, _P, _P]
@@ -235,6 +237,12 @@ class Codec:
 
     def residual_luma_dev(self, d_cur, d_pred, w, h, edge, d_res, stream=0):
         self._check(self.L.xResidualLumaDev(self.ctx, d_cur, d_pred, w, h, edge, d_res, stream), "xResidualLumaDev")
+
+    def dct32_fwd_from_tiles_dev(self, d_cur, d_pred, w, h, d_coef, stream=0):
+        self._check(self.L.xDct32FwdFromTilesDev(self.ctx, d_cur, d_pred, w, h, d_coef, stream), "xDct32FwdFromTilesDev")
+
+    def satd8x8_from_tiles_dev(self, d_cur, d_pred, w, h, d_out, stream=0):
+        self._check(self.L.xSatd8x8FromTilesDev(self.ctx, d_cur, d_pred, w, h, d_out, stream), "xSatd8x8FromTilesDev")
 
     def sad_dev(self, edge, d_a, d_b, d_out, n_blocks, stream=0):
         self._check(self.L.xSadBatchDev(self.ctx, edge, d_a, d_b, d_out, n_blocks, stream), "xSadBatchDev")

@@ -272,6 +272,48 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
     }
 }
 
+// ---- fused residual + forward transform -----------------------------------------------------
+// coef = DCT32(cur - pred) straight from two tiled frames (ref_block_t, src/x266.cpp:56-63),
+// without materialising the residual: 2 KiB of pixels in, 2 KiB of coefficients out per block
+// instead of 2 + 4 + 4 KiB for residual formation followed by the transform.  The transform is
+// linear before its first rounding, so pass 1 is G*cur + (-G)*pred on the 8-bit pixels as they
+// are: ONE byte plane per frame, no plane split, and the (x ^ 0x80) signed-offset trick needs no
+// correction because the +128 of both frames cancels.  The rounding constant 8 is the MFMA's
+// inline C operand.  A lane's fragment (row c, columns 16h..16h+15 of the 32x32 block) is exactly
+// one 16-byte luma row of one tile, so fragment loads are line-dense as they are; only the stores
+// go through the LDS slot (section "LDS-staged variant").
+__global__ __launch_bounds__(256) void dct32_from_tiles_kernel(const x266_ref_block_t *__restrict__ cur,
+                                                               const x266_ref_block_t *__restrict__ pred,
+                                                               int16_t *__restrict__ out, int blocks_x, int tiles_x,
+                                                               size_t n_blocks, const DctOps *__restrict__ ops)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
+    const int lane = threadIdx.x & 63;
+    unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+    const size_t blk = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (blk >= n_blocks) return;
+    const unsigned c = lane & 31, h = lane >> 5;
+    const size_t by = blk / blocks_x, bx = blk - by * blocks_x;
+    const size_t tile = (by * 2 + (c >> 4)) * (size_t)tiles_x + bx * 2 + h;
+    const v4i a = *reinterpret_cast<const v4i *>(reinterpret_cast<const unsigned char *>(cur + tile) + (c & 15) * 16);
+    const v4i b = *reinterpret_cast<const v4i *>(reinterpret_cast<const unsigned char *>(pred + tile) + (c & 15) * 16);
+    const LaneConsts k = load_consts(ops, lane);
+    const v4i bias = {(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
+    const v16i round1 = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};
+    v16i acc = mfma(a ^ bias, k.p1, round1);
+    acc = mfma(b ^ bias, k.tr, acc);                          // k.tr = -p1 in the forward tables
+    v4i o0, o1;
+    fwd_finish<4, 11>(acc, k, o0, o1);
+    *reinterpret_cast<v4i *>(slot + lds_slot(c, 2 * h)) = o0;
+    *reinterpret_cast<v4i *>(slot + lds_slot(c, 2 * h + 1)) = o1;
+    __builtin_amdgcn_wave_barrier();
+    const v4i s0 = *reinterpret_cast<const v4i *>(slot + lds_slot(lane >> 2, lane & 3));
+    const v4i s1 = *reinterpret_cast<const v4i *>(slot + lds_slot(16 + (lane >> 2), lane & 3));
+    char *dst = reinterpret_cast<char *>(out) + blk * 2048 + lane * 16;
+    *reinterpret_cast<v4i *>(dst) = s0;
+    *reinterpret_cast<v4i *>(dst + 1024) = s1;
+}
+
 }  // namespace
 
 // ---- launchers ---------------------------------------------------------------
@@ -307,6 +349,21 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
     if (cfg.nontemporal) { if (mode == 0) X266_LAUNCH(0, true); else if (mode == 1) X266_LAUNCH(1, true); else X266_LAUNCH(2, true); }
     else                 { if (mode == 0) X266_LAUNCH(0, false); else if (mode == 1) X266_LAUNCH(1, false); else X266_LAUNCH(2, false); }
 #undef X266_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_dct32_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_out,
+                                   int width, int height, const DctOps *d_fwd_ops, const LaunchCfg &cfg, hipStream_t stream)
+{
+    const int blocks_x = width / 32;
+    const size_t n_blocks = (size_t)blocks_x * (size_t)(height / 32);
+    if (n_blocks == 0) return hipSuccess;
+    const unsigned tpb = (unsigned)cfg.wg_threads;
+    const size_t wpw = tpb / 64, wgs = (n_blocks + wpw - 1) / wpw;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
+    hipLaunchKernelGGL(dct32_from_tiles_kernel, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_cur, d_pred, d_out, blocks_x,
+                       width / 16, n_blocks, d_fwd_ops);
     return hipGetLastError();
 }
 

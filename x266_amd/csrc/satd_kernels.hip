@@ -198,6 +198,63 @@ __global__ __launch_bounds__(256) void satd8x8_lds_kernel(const int16_t *__restr
     }
 }
 
+// ---- fused residual + SATD ---------------------------------------------------------------------
+// cost = satd8x8(cur - pred) for every 8x8 luma block of two tiled frames (ref_block_t,
+// src/x266.cpp:56-63), residual never materialised.  The Hadamard transform is linear and the
+// difference of two 8-bit pixels cannot wrap int16 (|coefficient| <= 64*255), so
+// H*(cur - pred) = H*cur + (-H)*pred on the pixels as they are: one byte plane per frame, the +128
+// of the signed-offset trick cancels, and negating a +-1 operand byte is an XOR with 0xFE.
+// One wave takes 8 consecutive tiles = 32 blocks (lane n: tile n/4, block n%4 of the tile), so a
+// tile's 256 luma bytes are consumed whole by one wave; costs are stored in raster order of blocks.
+__global__ __launch_bounds__(256) void satd8x8_from_tiles_kernel(const x266_ref_block_t *__restrict__ cur,
+                                                                 const x266_ref_block_t *__restrict__ pred,
+                                                                 uint32_t *__restrict__ out, int tiles_x, size_t n_tiles)
+{
+    const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+    const size_t group = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (group * 8 >= n_tiles) return;
+    size_t tile = group * 8 + (n >> 2);
+    const bool live = tile < n_tiles;
+    if (!live) tile = n_tiles - 1;
+    const int sub_y = (n >> 1) & 1, sub_x = n & 1;                      // block inside the tile
+    const unsigned off = (unsigned)((sub_y * 8 + 4 * half) * 16 + sub_x * 8);
+    const unsigned char *pa = reinterpret_cast<const unsigned char *>(cur + tile) + off;
+    const unsigned char *pb = reinterpret_cast<const unsigned char *>(pred + tile) + off;
+    uint2 a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        a[r] = *reinterpret_cast<const uint2 *>(pa + r * 16);
+        b[r] = *reinterpret_cast<const uint2 *>(pb + r * 16);
+    }
+    const SatdOperands H = make_satd_operands(lane);
+    const uint32_t S = 0x80808080u;                                     // pixels -> signed (offset cancels)
+    const v4i a0 = {(int)(a[0].x ^ S), (int)(a[0].y ^ S), (int)(a[1].x ^ S), (int)(a[1].y ^ S)};
+    const v4i a1 = {(int)(a[2].x ^ S), (int)(a[2].y ^ S), (int)(a[3].x ^ S), (int)(a[3].y ^ S)};
+    const v4i b0 = {(int)(b[0].x ^ S), (int)(b[0].y ^ S), (int)(b[1].x ^ S), (int)(b[1].y ^ S)};
+    const v4i b1 = {(int)(b[2].x ^ S), (int)(b[2].y ^ S), (int)(b[3].x ^ S), (int)(b[3].y ^ S)};
+    const v4i NEG = {(int)0xFEFEFEFEu, (int)0xFEFEFEFEu, (int)0xFEFEFEFEu, (int)0xFEFEFEFEu};
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t sum = 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const v4i h0 = t ? H.h10 : H.h00, h1 = t ? H.h11 : H.h01;
+        v16i acc = mfma(h0, a0, zero);
+        acc = mfma(h1, a1, acc);
+        acc = mfma(h0 ^ NEG, b0, acc);
+        acc = mfma(h1 ^ NEG, b1, acc);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const uint32_t pk = bperm((uint32_t)acc[2 * m + 1], (uint32_t)acc[2 * m], 0x05040100u) ^ 0x80008000u;
+            sum = __builtin_amdgcn_sad_u16(pk, 0x80008000u, sum);
+        }
+    }
+    sum += (uint32_t)__shfl_xor((int)sum, 32);
+    if (live && half == 0) {
+        const size_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        out[(ty * 2 + sub_y) * (size_t)(tiles_x * 2) + tx * 2 + sub_x] = (sum + 2) >> 2;
+    }
+}
+
 // ---- synthetic residual stream ---------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t index)
 {
@@ -260,6 +317,18 @@ hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_block
     }
     if (cfg.nontemporal) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
     else                 hipLaunchKernelGGL((satd8x8_kernel<false>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
+    return hipGetLastError();
+}
+
+hipError_t launch_satd8x8_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, uint32_t *d_out,
+                                     int width, int height, hipStream_t stream)
+{
+    const int tiles_x = width / 16;
+    const size_t n_tiles = (size_t)tiles_x * (size_t)(height / 16);
+    if (n_tiles == 0) return hipSuccess;
+    const size_t groups = (n_tiles + 7) / 8;                            // one wave per 8 tiles, one-wave workgroups
+    if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(satd8x8_from_tiles_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d_cur, d_pred, d_out, tiles_x, n_tiles);
     return hipGetLastError();
 }
 

@@ -80,19 +80,12 @@ __device__ __forceinline__ LaneConsts load_consts(const DctOps *ops, int lane)
 }
 
 // ---- forward: one block held as (w0, w1) -> (o0, o1) ------------------------
+// Second half of the forward transform: `acc` holds the pass-1 sums INCLUDING the rounding term;
+// shift, re-pack to byte planes, pass 2, final shift and int16 packing.
 template <int S1, int S2>
-__device__ __forceinline__ void fwd_block(const v4i &w0, const v4i &w1, const LaneConsts &k,
-                                          v4i &o0, v4i &o1)
+__device__ __forceinline__ void fwd_finish(v16i acc, const LaneConsts &k, v4i &o0, v4i &o1)
 {
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    v4i lo, hi;
-    split_planes(w0, w1, lo, hi);
-
-    // pass 1 (rows): data = A, coefficients = B
-    v16i acc = mfma(hi, k.p1, zero);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)k.c1);
-    acc = mfma(lo, k.p1, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = acc[r] >> S1;        // bytes 0/1 = int16 result
     v4i ylo, yhi;
@@ -111,6 +104,22 @@ __device__ __forceinline__ void fwd_block(const v4i &w0, const v4i &w1, const La
         z[m] = bperm((uint32_t)(acc[2 * m + 1] >> S2), (uint32_t)(acc[2 * m] >> S2), 0x05040100u);
     o0 = v4i{(int)z[0], (int)z[1], (int)z[2], (int)z[3]};
     o1 = v4i{(int)z[4], (int)z[5], (int)z[6], (int)z[7]};
+}
+
+template <int S1, int S2>
+__device__ __forceinline__ void fwd_block(const v4i &w0, const v4i &w1, const LaneConsts &k,
+                                          v4i &o0, v4i &o1)
+{
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v4i lo, hi;
+    split_planes(w0, w1, lo, hi);
+
+    // pass 1 (rows): data = A, coefficients = B
+    v16i acc = mfma(hi, k.p1, zero);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)k.c1);
+    acc = mfma(lo, k.p1, acc);
+    fwd_finish<S1, S2>(acc, k, o0, o1);
 }
 
 }  // namespace x266

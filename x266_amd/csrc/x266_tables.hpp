@@ -54,7 +54,7 @@ constexpr int kappa(int i) { return ((i >> 2) & 1) * 16 + (i >> 3) * 4 + (i & 3)
 struct DctLaneOps {
     uint32_t p1[4];     // constant operand of pass 1 (16 int8)
     uint32_t p2[4];     // constant operand of pass 2 (16 int8)
-    uint32_t tr[4];     // inverse only: permuted identity for the MFMA transpose
+    uint32_t tr[4];     // inverse: permuted identity for the MFMA transpose; forward: the NEGATED pass-1 operand
     int32_t  c1;        // pass-1 accumulator constant: rounding + byte-plane offset fix
     int32_t  c2;        // pass-2 accumulator constant (forward: per lane)
     int32_t  pad[2];
@@ -84,15 +84,16 @@ inline void build_fwd_ops(DctOps &o)
     constexpr Table32 g = make_table32();
     for (int l = 0; l < 64; ++l) {
         const int c = l & 31, h = l >> 5;
-        int8_t b1[16], b2[16];
+        int8_t b1[16], b2[16], b1n[16];
         for (int t = 0; t < 16; ++t) {
             b1[t] = static_cast<int8_t>(g.v[kappa(c)][16 * h + t]);
             b2[t] = static_cast<int8_t>(g.v[c][acc_row(t, h)]);
+            b1n[t] = static_cast<int8_t>(-b1[t]);                 // negated pass-1 operand: G*(a - b) = G*a + (-G)*b
         }
         for (int q = 0; q < 4; ++q) {
             o.lane[l].p1[q] = pack4(b1 + 4 * q);
             o.lane[l].p2[q] = pack4(b2 + 4 * q);
-            o.lane[l].tr[q] = 0;
+            o.lane[l].tr[q] = pack4(b1n + 4 * q);
         }
         o.lane[l].c1 = (1 << 3)  + (kappa(c) == 0 ? 128 * 2048 : 0);
         o.lane[l].c2 = (1 << 10) + (c == 0 ? 128 * 2048 : 0);

@@ -386,6 +386,35 @@ int xResidualLumaDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266
     return X266HIP_OK;
 }
 
+int xDct32FwdFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int width, int height,
+                          int16_t *d_coef, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (width <= 0 || height <= 0 || (width & 31) || (height & 31)) return fail(ctx, X266HIP_EINVAL, "xDct32FwdFromTilesDev: width/height must be multiples of 32");
+    if (!d_cur || !d_pred || !d_coef || ((((uintptr_t)d_cur | (uintptr_t)d_pred | (uintptr_t)d_coef)) & 15u))
+        return fail(ctx, X266HIP_EINVAL, "xDct32FwdFromTilesDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    LaunchCfg cfg = cfg_for(ctx, 0);
+    cfg.wg_threads = ctx->dct_wg_threads;
+    cfg.lds_bytes_per_wave = ctx->dct_lds_per_wave;
+    hipError_t e = launch_dct32_from_tiles(d_cur, d_pred, d_coef, width, height, ctx->d_fwd, cfg, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fused transform launch", e);
+    return X266HIP_OK;
+}
+
+int xSatd8x8FromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int width, int height,
+                         uint32_t *d_out, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (width <= 0 || height <= 0 || (width & 15) || (height & 15)) return fail(ctx, X266HIP_EINVAL, "xSatd8x8FromTilesDev: width/height must be multiples of 16");
+    if (!d_cur || !d_pred || !d_out || ((((uintptr_t)d_cur | (uintptr_t)d_pred)) & 15u) || ((uintptr_t)d_out & 3u))
+        return fail(ctx, X266HIP_EINVAL, "xSatd8x8FromTilesDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_satd8x8_from_tiles(d_cur, d_pred, d_out, width, height, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fused satd launch", e);
+    return X266HIP_OK;
+}
+
 int xSadBatchDev(x266hip_ctx *ctx, int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out, size_t n, void *stream)
 {
     if (!ctx) return X266HIP_EINVAL;
