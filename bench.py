@@ -293,10 +293,13 @@ def main():
         if not args.no_transform_set:
             ts = {}
             zt = torch.empty_like(x)                       # own output buffer: z still holds the headline leg's result
-            for ttype, tname in ((0, "dct2"), (1, "dst7")):
+            for ttype, tname, inverse in ((0, "dct2", False), (1, "dst7", False), (0, "dct2_inv", True), (1, "dst7_inv", True)):
                 for n in (4, 8, 16):
                     nblk = (n_dct * 1024) // (n * n)
-                    fn = lambda a, b, cnt, st, tt=ttype, nn=n: codec.transform_fwd_dev(tt, nn, a, b, cnt, 0, st)
+                    if inverse:
+                        fn = lambda a, b, cnt, st, tt=ttype, nn=n: codec.transform_inv_dev(tt, nn, a, b, cnt, st)
+                    else:
+                        fn = lambda a, b, cnt, st, tt=ttype, nn=n: codec.transform_fwd_dev(tt, nn, a, b, cnt, 0, st)
                     for _ in range(3):
                         fn(x.data_ptr(), zt.data_ptr(), nblk, stream)
                     barrier()

@@ -88,3 +88,30 @@ int orc_transform_fwd(int type, int n, const int16_t *in, int16_t *out, size_t n
     }
     return 0;
 }
+
+/* Inverse of the above (UNPINNED): columns first, dst[j*n + c] = clip16((sum_k M[k][c]*src[k*n + j]
+ * + (1 << (shift-1))) >> shift), shifts 7 then 12 (8-bit video; size independent as in HEVC/VVC).
+ * For (DCT-II, 32) this is orc_dct32_inv. */
+static int16_t tr_clip16(int v) { return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+static void tr_inv_pass(const int16_t *m, int n, const int16_t *src, int16_t *dst, int shift)
+{
+    const int rnd = 1 << (shift - 1);
+    for (int j = 0; j < n; j++)
+        for (int c = 0; c < n; c++) {
+            int acc = rnd;
+            for (int k = 0; k < n; k++) acc += m[k * n + c] * src[k * n + j];
+            dst[j * n + c] = tr_clip16(acc >> shift);
+        }
+}
+
+int orc_transform_inv(int type, int n, const int16_t *in, int16_t *out, size_t n_blocks)
+{
+    int16_t m[32 * 32], tmp[32 * 32];
+    if (orc_transform_matrix(type, n, m)) return -1;
+    for (size_t b = 0; b < n_blocks; b++) {
+        tr_inv_pass(m, n, in + b * n * n, tmp, 7);
+        tr_inv_pass(m, n, tmp, out + b * n * n, 12);
+    }
+    return 0;
+}

@@ -58,6 +58,7 @@ void orc_satd8x8_batch_mt(const int16_t *diff, uint32_t *out, size_t n_blocks, i
 #define ORC_TR_DST7 1
 int orc_transform_matrix(int type, int n, int16_t *m /* n*n, row = frequency */);
 int orc_transform_fwd(int type, int n, const int16_t *in, int16_t *out, size_t n_blocks);
+int orc_transform_inv(int type, int n, const int16_t *in, int16_t *out, size_t n_blocks);   /* UNPINNED */
 
 /* ---- full-search harness around satd8x8 (BASELINE configs[2]) ---- cost PINNED, harness UNPINNED */
 /* ref points at pixel (0,0) of a frame padded by >= range; candidates in raster

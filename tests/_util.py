@@ -104,6 +104,12 @@ class Oracle:
         assert self.lib.orc_transform_fwd(ttype, n, _P(x.ctypes.data), _P(out.ctypes.data), _SZ(x.shape[0])) == 0
         return out
 
+    def transform_inv(self, ttype, n, x):
+        x = np.ascontiguousarray(x, np.int16).reshape(-1, n * n)
+        out = np.empty_like(x)
+        assert self.lib.orc_transform_inv(ttype, n, _P(x.ctypes.data), _P(out.ctypes.data), _SZ(x.shape[0])) == 0
+        return out
+
     def satd_search(self, cur, ref_padded, pad, rng, threads=1, want_costs=False):
         """cur [H,W] uint8; ref_padded [H+2*pad, W+2*pad] uint8 with pad >= rng."""
         cur = np.ascontiguousarray(cur, np.uint8)

@@ -33,6 +33,19 @@ def test_ragged_counts(codec, oracle, ttype, n, count, staging):
     assert np.array_equal(codec.transform_fwd(ttype, n, x), oracle.transform_fwd(ttype, n, x))
 
 
+@pytest.mark.parametrize("ttype,n", CLASSES)
+def test_inverse_transforms(codec, oracle, ttype, n):
+    per = n * n
+    r = residual_np(2003 * per, 70 + n).reshape(-1, per)
+    z = oracle.transform_fwd(ttype, n, r)
+    x = np.concatenate([z, fullrange_np(1000 * per, 71 + n).reshape(-1, per), extremes_np(300 * per, 72 + n).reshape(-1, per)])
+    assert np.array_equal(codec.transform_inv(ttype, n, x), oracle.transform_inv(ttype, n, x))
+    for count in (1, 2, 3, 15, 17, 63, 65, 129):
+        assert np.array_equal(codec.transform_inv(ttype, n, x[:count]), oracle.transform_inv(ttype, n, x[:count]))
+    rt = codec.transform_inv(ttype, n, codec.transform_fwd(ttype, n, r))         # round trip on the device
+    assert np.abs(rt.astype(np.int32) - r.astype(np.int32)).max() <= 6
+
+
 def test_edge_blocks(codec, oracle):
     for ttype, n in CLASSES:
         per = n * n

@@ -157,3 +157,20 @@ def test_residual_blocks_definition(oracle):
     for edge in (8, 32):
         want = d.reshape(h // edge, edge, w // edge, edge).transpose(0, 2, 1, 3).reshape(-1)
         assert np.array_equal(oracle.residual_luma(tc, tp, w, h, edge), want)
+
+
+def test_transform_set_inverse_definition(oracle):
+    x = np.concatenate([residual_np(30 * 1024, 81), fullrange_np(30 * 1024, 82)]).reshape(-1, 1024)
+    assert np.array_equal(oracle.transform_inv(0, 32, x), oracle.dct32_inv(x))            # overlaps the DCT32 inverse
+    for ttype in (0, 1):
+        for n in (4, 8, 16):
+            m = oracle.transform_matrix(ttype, n).astype(np.int64)
+            z = fullrange_np(5 * n * n, 90 + n).reshape(5, n, n)
+            out = oracle.transform_inv(ttype, n, z).reshape(5, n, n)
+            for b in range(5):
+                t = np.clip((np.einsum("kc,kj->jc", m, z[b].astype(np.int64)) + 64) >> 7, -32768, 32767)
+                r = np.clip((np.einsum("kc,kj->jc", m, t) + 2048) >> 12, -32768, 32767)
+                assert np.array_equal(out[b], r.astype(np.int16))
+            r9 = residual_np(400 * n * n, 95 + n).reshape(-1, n * n)
+            rt = oracle.transform_inv(ttype, n, oracle.transform_fwd(ttype, n, r9))
+            assert np.abs(rt.astype(np.int32) - r9.astype(np.int32)).max() <= 6

@@ -63,6 +63,7 @@ def load_library():
     L.xDct32FwdFromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
     L.xSatd8x8FromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
     L.xSadBatchDev.argtypes = [_P, ctypes.c_int, _P, _P, _P, _SZ, _P]
+    L.xTransformInvBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P]
     L.xSatd8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, _P, _P, _P]
     for name in ("xDct32FwdBatch", "xDct32InvBatch", "xSatd8x8Batch"):
@@ -257,6 +258,18 @@ class Codec:
         self.sad_dev(edge, da.ptr, db.ptr, do.ptr, n)
         self.stream_sync()
         return do.download(np.uint32, n)
+
+    def transform_inv_dev(self, ttype, size, d_in, d_out, n_blocks, stream=0):
+        self._check(self.L.xTransformInvBatchDev(self.ctx, ttype, size, d_in, d_out, n_blocks, stream), "xTransformInvBatchDev")
+
+    def transform_inv(self, ttype, size, x):
+        x = np.ascontiguousarray(x, np.int16)
+        n = x.size // (size * size)
+        din, dout = self.alloc(max(x.nbytes, 16)), self.alloc(max(x.nbytes, 16))
+        din.upload(x)
+        self.transform_inv_dev(ttype, size, din.ptr, dout.ptr, n)
+        self.stream_sync()
+        return dout.download(np.int16, x.size).reshape(n, size * size)
 
     def satd_search_dev(self, d_cur, cur_stride, d_ref_origin, ref_stride, width, height, rng, d_best, d_costs=0,
                         stream=0):

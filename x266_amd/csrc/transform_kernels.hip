@@ -172,6 +172,92 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
     }
 }
 
+// Inverse transforms of the set (UNPINNED upstream; columns first, shifts 7 and 12, int16 clipping
+// after each pass -- DESIGN.md section 10), contiguous batches, same block-diagonal tile idea.  The
+// first contraction runs over the tile's ROW index, so each lane reads its COLUMN out of the staged
+// tile (16 x ds_read_u16), exactly as the staged DCT32 inverse does.
+template <int LOGN>
+__global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
+                                                               size_t n_blocks, const DctOps *__restrict__ ops,
+                                                               unsigned tiles_per_wave)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int PER = 32 / N, PIECES = N >= 16 ? 1 : 16 / N, NSB = PER * PER;
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
+    unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_tiles = (n_blocks + NSB - 1) / NSB;
+    size_t t = wave * tiles_per_wave;
+    const size_t t_end = t + tiles_per_wave < n_tiles ? t + tiles_per_wave : n_tiles;
+    if (t >= t_end) return;
+    const LaneConsts k = load_consts(ops, lane);
+    v16i c2r;
+    {
+        const int *__restrict__ s0 = ops->c2r[0], *__restrict__ s1 = ops->c2r[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c2r[r] = h ? s1[r] : s0[r];
+    }
+    const int row = c & (N - 1), tile_row = c >> LOGN;
+    const size_t total_bytes = n_blocks * (size_t)(N * N * 2);
+    unsigned frag[PIECES];                                              // output fragment pieces (as in the forward kernel)
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const unsigned sb = N == 32 ? 0u : (unsigned)(tile_row * PER + h * PIECES + q);
+        frag[q] = (sb * (unsigned)(N * N) + (unsigned)row * N + (N == 32 ? 16u * h : 0u)) * 2u;
+    }
+    // input column u = kappa(c), rows v = 16h + t: byte offset = col_base + ((t / N) * 64 * N + (t % N) * 2 * N)
+    const unsigned u = (unsigned)kappa(c);
+    const unsigned col_base = ((u >> LOGN) * (unsigned)(N * N) + (u & (N - 1))) * 2u + (unsigned)h * 1024u;
+
+    for (; t < t_end; ++t) {
+        const size_t base = t * 2048;
+        size_t o0 = base + (size_t)lane * 16, o1 = o0 + 1024;
+        const bool live0 = o0 + 16 <= total_bytes, live1 = o1 + 16 <= total_bytes;
+        if (!live0) o0 = total_bytes - 16;
+        if (!live1) o1 = total_bytes - 16;
+        const v4i g0 = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(in) + o0);
+        const v4i g1 = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(in) + o1);
+        *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
+        *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t w[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int t0 = 2 * m, t1 = 2 * m + 1;
+            const unsigned c0 = (unsigned)((t0 >> LOGN) * 64 * N + (t0 & (N - 1)) * 2 * N);
+            const unsigned c1 = (unsigned)((t1 >> LOGN) * 64 * N + (t1 & (N - 1)) * 2 * N);
+            const uint32_t e0 = *reinterpret_cast<const uint16_t *>(slot + col_base + c0);
+            const uint32_t e1 = *reinterpret_cast<const uint16_t *>(slot + col_base + c1);
+            w[m] = e0 | (e1 << 16);
+        }
+        __builtin_amdgcn_wave_barrier();
+        v4i lo, hi, r0, r1;
+        split_planes(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, lo, hi);
+        inv_passes(lo, hi, k, c2r, r0, r1);
+        const uint32_t z[8] = {(uint32_t)r0[0], (uint32_t)r0[1], (uint32_t)r0[2], (uint32_t)r0[3],
+                               (uint32_t)r1[0], (uint32_t)r1[1], (uint32_t)r1[2], (uint32_t)r1[3]};
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            if (N >= 16) {
+                *reinterpret_cast<v4i *>(slot + frag[q]) = r0;
+                *reinterpret_cast<v4i *>(slot + frag[q] + 16) = r1;
+            } else if (N == 8) {
+                *reinterpret_cast<v4i *>(slot + frag[q]) = v4i{(int)z[4 * q], (int)z[4 * q + 1], (int)z[4 * q + 2], (int)z[4 * q + 3]};
+            } else {
+                *reinterpret_cast<uint2 *>(slot + frag[q]) = make_uint2(z[2 * q], z[2 * q + 1]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
+        const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
+        __builtin_amdgcn_wave_barrier();
+        if (live0) *reinterpret_cast<v4i *>(reinterpret_cast<char *>(out) + o0) = s0;
+        if (live1) *reinterpret_cast<v4i *>(reinterpret_cast<char *>(out) + o1) = s1;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
@@ -203,6 +289,30 @@ hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out
     if (log2n == 2) X266_TR(2); else if (log2n == 3) X266_TR(3); else if (log2n == 4) X266_TR(4); else if (log2n == 5) X266_TR(5);
     else return hipErrorInvalidValue;
 #undef X266_TR
+    return hipGetLastError();
+}
+
+}  // namespace x266
+
+namespace x266 {
+
+hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
+                                      const LaunchCfg &cfg, hipStream_t stream)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const size_t per_tile = (size_t)(32 >> log2n) * (size_t)(32 >> log2n);
+    const size_t tiles = (n_blocks + per_tile - 1) / per_tile;
+    const unsigned tpw = cfg.units_per_wave < 1 ? 1u : (unsigned)cfg.units_per_wave;
+    const size_t waves = (tiles + tpw - 1) / tpw;
+    const unsigned tpb = (unsigned)cfg.wg_threads;
+    const size_t wpw = tpb / 64, wgs = (waves + wpw - 1) / wpw;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
+    dim3 grid((unsigned)wgs), block(tpb);
+    if (log2n == 2)      hipLaunchKernelGGL((tr_inv_small_lds_kernel<2>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
+    else if (log2n == 3) hipLaunchKernelGGL((tr_inv_small_lds_kernel<3>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
+    else if (log2n == 4) hipLaunchKernelGGL((tr_inv_small_lds_kernel<4>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

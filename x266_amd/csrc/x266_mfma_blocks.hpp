@@ -122,4 +122,41 @@ __device__ __forceinline__ void fwd_block(const v4i &w0, const v4i &w1, const La
     fwd_finish<S1, S2>(acc, k, o0, o1);
 }
 
+// ---- inverse passes (see dct32_kernels.hip, section "inverse") --------------------------------
+__device__ __forceinline__ int clamp16(int v)
+{
+    return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);   // folds to v_med3_i32
+}
+
+// passes A and B on column data: zlo / zhi = byte planes of 16 samples of ONE COLUMN per lane
+__device__ __forceinline__ void inv_passes(const v4i &zlo, const v4i &zhi, const LaneConsts &k,
+                                           const v16i &c2r, v4i &o0, v4i &o1)
+{
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // pass A (columns): data = A, coefficients = B, per-lane constant
+    v16i acc = mfma(zhi, k.p1, zero);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)k.c1);
+    acc = mfma(zlo, k.p1, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = clamp16(acc[r] >> 7);
+    v4i tlo2, thi2;
+    pack_planes(acc, tlo2, thi2);
+
+    // pass B (rows): coefficients = A, data = B, per-register constant
+    acc = mfma(k.p2, thi2, zero);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)c2r[r]);
+    acc = mfma(k.p2, tlo2, acc);
+
+    uint32_t z[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int a = clamp16(acc[2 * m] >> 12), b = clamp16(acc[2 * m + 1] >> 12);
+        z[m] = bperm((uint32_t)b, (uint32_t)a, 0x05040100u);
+    }
+    o0 = v4i{(int)z[0], (int)z[1], (int)z[2], (int)z[3]};
+    o1 = v4i{(int)z[4], (int)z[5], (int)z[6], (int)z[7]};
+}
+
 }  // namespace x266

@@ -233,6 +233,32 @@ inline void build_fwd_ops_general(DctOps &o, const Matrix32 &m, int shift1, int 
     }
 }
 
+// Inverse operand images for an arbitrary 32x32 int8 matrix, data operand of pass A in natural row
+// order (the staged kernel reads columns out of LDS); same construction as build_inv_ops(o, true).
+inline void build_inv_ops_general(DctOps &o, const Matrix32 &m)
+{
+    int colsum[32] = {};
+    for (int c = 0; c < 32; ++c)
+        for (int k = 0; k < 32; ++k) colsum[c] += m.v[k][c];
+    for (int l = 0; l < 64; ++l) {
+        const int c = l & 31, h = l >> 5;
+        int8_t ba[16], ab[16];
+        for (int t = 0; t < 16; ++t) {
+            ba[t] = m.v[16 * h + t][c];              // pass A: M[v][y = c]
+            ab[t] = m.v[16 * h + t][kappa(c)];       // pass B: M[u][x = kappa(c)]
+        }
+        for (int q = 0; q < 4; ++q) {
+            o.lane[l].p1[q] = pack4(ba + 4 * q);
+            o.lane[l].p2[q] = pack4(ab + 4 * q);
+            o.lane[l].tr[q] = 0;
+        }
+        o.lane[l].c1 = (1 << 6) + 128 * colsum[c];
+        o.lane[l].c2 = 0;
+        o.lane[l].pad[0] = o.lane[l].pad[1] = 0;
+        for (int r = 0; r < 16; ++r) o.c2r[l][r] = (1 << 11) + 128 * colsum[16 * h + r];
+    }
+}
+
 constexpr int transform_shift1(int n) { return (n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5) - 1; }   // log2N - 1  (8-bit video)
 constexpr int transform_shift2(int n) { return (n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5) + 6; }   // log2N + 6
 

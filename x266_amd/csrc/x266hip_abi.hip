@@ -26,6 +26,7 @@ struct x266hip_ctx {
     DctOps *d_inv = nullptr;
     DctOps *d_inv_lds = nullptr;                    // inverse operand images for the LDS-staged kernel (column reads)
     DctOps *d_tr[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // [type][log2N - 2], N = 4, 8, 16
+    DctOps *d_tr_inv[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     // options
     int wgs_per_cu_dct = 8;
     int wgs_per_cu_inv = 5;
@@ -170,6 +171,10 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
             build_fwd_ops_general(*h, make_transform_matrix(type, n), transform_shift1(n), transform_shift2(n));
             ok = hipMalloc((void **)&ctx->d_tr[type][l], sizeof(DctOps)) == hipSuccess &&
                  hipMemcpy(ctx->d_tr[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
+            if (!ok) break;
+            build_inv_ops_general(*h, make_transform_matrix(type, n));
+            ok = hipMalloc((void **)&ctx->d_tr_inv[type][l], sizeof(DctOps)) == hipSuccess &&
+                 hipMemcpy(ctx->d_tr_inv[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
         }
     delete h;
     if (!ok) {
@@ -190,8 +195,10 @@ void xHipCodecFree(x266hip_ctx *ctx)
         if (ctx->stage_stream[i]) (void)hipStreamDestroy(ctx->stage_stream[i]);
     }
     for (int type = 0; type < 2; ++type)
-        for (int l = 0; l < 3; ++l)
+        for (int l = 0; l < 3; ++l) {
             if (ctx->d_tr[type][l]) (void)hipFree(ctx->d_tr[type][l]);
+            if (ctx->d_tr_inv[type][l]) (void)hipFree(ctx->d_tr_inv[type][l]);
+        }
     if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
     if (ctx->d_inv) (void)hipFree(ctx->d_inv);
@@ -424,6 +431,25 @@ int xSadBatchDev(x266hip_ctx *ctx, int edge, const uint8_t *d_a, const uint8_t *
     X_HIP(ctx, hipSetDevice(ctx->device));
     hipError_t e = launch_sad(edge, d_a, d_b, d_out, n, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "sad launch", e);
+    return X266HIP_OK;
+}
+
+int xTransformInvBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d_in, int16_t *d_out, size_t n, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (type != X266_TR_DCT2 && type != X266_TR_DST7) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: unknown transform type");
+    if (size != 4 && size != 8 && size != 16 && !(size == 32 && type == X266_TR_DCT2))
+        return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: size must be 4, 8, 16 (or 32 for DCT-II)");
+    if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    if (size == 32) return launch_op(ctx, 1, d_in, d_out, n, (hipStream_t)stream);
+    const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
+    LaunchCfg cfg = cfg_for(ctx, 1);
+    cfg.units_per_wave = ctx->dct_inv_blocks_per_wave;
+    cfg.wg_threads = ctx->dct_inv_wg_threads;
+    cfg.lds_bytes_per_wave = ctx->dct_inv_lds_per_wave;
+    hipError_t e = launch_transform_small_inv(l + 2, d_in, d_out, n, ctx->d_tr_inv[type][l], cfg, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "inverse transform launch", e);
     return X266HIP_OK;
 }
 
