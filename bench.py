@@ -148,12 +148,23 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libx266hip has no CPU path")
+    # Test hook (never set by the driver): X266_BENCH_SHARE_GPU=1 lets several ranks share the visible
+    # GPUs with the control-plane collectives on gloo, so that the N > 1 code path -- shard offsets,
+    # max-over-ranks timing, checksum reduction -- can be exercised on a one-GPU box.
+    share = os.environ.get("X266_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
+    ctrl = "cuda"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+            ctrl = "cpu"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     codec = x266_amd.Codec(local_rank)
     info_cu = codec.device_info()["cu_count"]
@@ -169,7 +180,7 @@ def main():
     def max_over_ranks(seconds):
         if dist is None:
             return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+        t = torch.tensor([seconds], dtype=torch.float64, device=ctrl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -229,7 +240,7 @@ def main():
     # ---- checksum of the forward output across ranks (validates the sharded run) ----------------
     csum = int(z.view(torch.int16).to(torch.int64).sum().item())
     if dist is not None:
-        t = torch.tensor([csum], dtype=torch.int64, device="cuda")
+        t = torch.tensor([csum], dtype=torch.int64, device=ctrl)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         csum = int(t.item())
     result["output_checksum_sum_i16"] = csum
@@ -376,7 +387,7 @@ def main():
             del tcur, tpred, fcoef, fcost, fres
 
         # ---- BASELINE configs[4] (on request): 8K frame stream, scatter -> kernels -> gather over RCCL
-        if args.stream8k > 0:
+        if args.stream8k > 0 and ctrl == "cuda":
             from x266_amd.stream import FrameGeometry, ShardedFrameStream
             geo = FrameGeometry(7680, 4320)
             dev = torch.device("cuda", local_rank)
