@@ -348,7 +348,9 @@ def main():
                                      "note": "wall-clock rates (launch gaps included); 4*N*N algorithmic bytes per block"}
         # ---- fused front end: tiled cur/pred frames -> coefficients / costs, residual never in HBM
         if not args.no_transform_set:
-            fw, fh = 16384, 16384
+            # 32768^2 luma: exactly 2^20 DCT32 blocks and 2^24 SATD blocks, i.e. the two-kernel legs launch the
+            # headline kernels at the headline sizes (keeps rocprofv3's per-kernel averages comparable)
+            fw, fh = 32768, 32768
             ntile = (fw // 16) * (fh // 16)
             gq = torch.Generator(device="cuda")
             gq.manual_seed(0x266)
