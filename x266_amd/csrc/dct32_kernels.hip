@@ -152,7 +152,7 @@ __device__ __forceinline__ unsigned lds_slot(unsigned row, unsigned quarter)
     return row * 64u + ((quarter ^ ((row >> 2) & 3u)) << 4);
 }
 
-template <int MODE>
+template <int MODE, int NT = 0>
 __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restrict__ in,
                                                         int16_t *__restrict__ out, size_t n_blocks,
                                                         const DctOps *__restrict__ ops,
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
     const char *src = reinterpret_cast<const char *>(in) + lane * 16;
     char *dst = reinterpret_cast<char *>(out) + lane * 16;
 
-    v4i g0 = load16<false>(src + b * 2048), g1 = load16<false>(src + b * 2048 + 1024);
+    v4i g0 = load16<(NT & 1) != 0>(src + b * 2048), g1 = load16<(NT & 1) != 0>(src + b * 2048 + 1024);
     const LaneConsts k = load_consts(ops, lane);
     v16i c2r;
     if (MODE == 1) {
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
         *reinterpret_cast<v4i *>(slot + lin0) = g0;
         *reinterpret_cast<v4i *>(slot + lin1) = g1;
         if (nb < end) {                                        // next tile's loads fly under this tile's arithmetic
-            g0 = load16<false>(src + nb * 2048);
-            g1 = load16<false>(src + nb * 2048 + 1024);
+            g0 = load16<(NT & 1) != 0>(src + nb * 2048);
+            g1 = load16<(NT & 1) != 0>(src + nb * 2048 + 1024);
         }
         __builtin_amdgcn_wave_barrier();
         v4i o0, o1;
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
         __builtin_amdgcn_wave_barrier();
-        store16<false>(dst + b * 2048, s0);
-        store16<false>(dst + b * 2048 + 1024, s1);
+        store16<(NT & 2) != 0>(dst + b * 2048, s0);
+        store16<(NT & 2) != 0>(dst + b * 2048 + 1024, s1);
         if (nb >= end) break;
         b = nb;
     }
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
 // inline C operand.  A lane's fragment (row c, columns 16h..16h+15 of the 32x32 block) is exactly
 // one 16-byte luma row of one tile, so fragment loads are line-dense as they are; only the stores
 // go through the LDS slot (section "LDS-staged variant").
+template <bool NT>
 __global__ __launch_bounds__(256) void dct32_from_tiles_kernel(const x266_ref_block_t *__restrict__ cur,
                                                                const x266_ref_block_t *__restrict__ pred,
                                                                int16_t *__restrict__ out, int blocks_x, int tiles_x,
@@ -274,8 +275,8 @@ __global__ __launch_bounds__(256) void dct32_from_tiles_kernel(const x266_ref_bl
     const v4i s0 = *reinterpret_cast<const v4i *>(slot + lds_slot(lane >> 2, lane & 3));
     const v4i s1 = *reinterpret_cast<const v4i *>(slot + lds_slot(16 + (lane >> 2), lane & 3));
     char *dst = reinterpret_cast<char *>(out) + blk * 2048 + lane * 16;
-    *reinterpret_cast<v4i *>(dst) = s0;
-    *reinterpret_cast<v4i *>(dst + 1024) = s1;
+    store16<NT>(dst, s0);
+    store16<NT>(dst + 1024, s1);
 }
 
 }  // namespace
@@ -304,13 +305,17 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
     if (cfg.lds_stage && cfg.variant == 0) {                   // line-dense global traffic through a private LDS slot
         const size_t per_wave = cfg.lds_bytes_per_wave < 2048 ? 2048 : (size_t)cfg.lds_bytes_per_wave;
         const size_t lds = waves_per_wg * per_wave + (size_t)cfg.lds_pad_bytes;
-        if (mode == 0)      hipLaunchKernelGGL((dct32_lds_kernel<0>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        if (mode == 0 && (cfg.nontemporal & 3) == 1) hipLaunchKernelGGL((dct32_lds_kernel<0, 1>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else if (mode == 0 && (cfg.nontemporal & 3) == 2) hipLaunchKernelGGL((dct32_lds_kernel<0, 2>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else if (mode == 0 && (cfg.nontemporal & 3) == 3) hipLaunchKernelGGL((dct32_lds_kernel<0, 3>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else if (mode == 0) hipLaunchKernelGGL((dct32_lds_kernel<0>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else if (mode == 1 && (cfg.nontemporal & 3)) hipLaunchKernelGGL((dct32_lds_kernel<1, 3>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops_lds_inv, bpw);
         else if (mode == 1) hipLaunchKernelGGL((dct32_lds_kernel<1>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops_lds_inv, bpw);
         else                hipLaunchKernelGGL((dct32_lds_kernel<2>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
         return hipGetLastError();
     }
 #define X266_LAUNCH(MODE, NT) hipLaunchKernelGGL((dct32_kernel<MODE, NT>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_in, d_out, n_blocks, d_ops, bpw)
-    if (cfg.nontemporal) { if (mode == 0) X266_LAUNCH(0, true); else if (mode == 1) X266_LAUNCH(1, true); else X266_LAUNCH(2, true); }
+    if (cfg.nontemporal & 4) { if (mode == 0) X266_LAUNCH(0, true); else if (mode == 1) X266_LAUNCH(1, true); else X266_LAUNCH(2, true); }
     else                 { if (mode == 0) X266_LAUNCH(0, false); else if (mode == 1) X266_LAUNCH(1, false); else X266_LAUNCH(2, false); }
 #undef X266_LAUNCH
     return hipGetLastError();
@@ -326,8 +331,8 @@ hipError_t launch_dct32_from_tiles(const x266_ref_block_t *d_cur, const x266_ref
     const size_t wpw = tpb / 64, wgs = (n_blocks + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
-    hipLaunchKernelGGL(dct32_from_tiles_kernel, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_cur, d_pred, d_out, blocks_x,
-                       width / 16, n_blocks, d_fwd_ops);
+    if (cfg.nontemporal & 2) hipLaunchKernelGGL((dct32_from_tiles_kernel<true>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_cur, d_pred, d_out, blocks_x, width / 16, n_blocks, d_fwd_ops);
+    else                     hipLaunchKernelGGL((dct32_from_tiles_kernel<false>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_cur, d_pred, d_out, blocks_x, width / 16, n_blocks, d_fwd_ops);
     return hipGetLastError();
 }
 

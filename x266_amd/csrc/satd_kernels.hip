@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict_
 // (whole 128-byte lines per instruction, see dct32_kernels.hip) and turned into block-per-lane
 // order through a wave-private LDS slot.  Chunk (block n, row j) lives at
 // n*128 + ((j ^ ((n >> 1) & 7)) << 4): linear writes and fragment reads are conflict-free.
+template <bool NT>
 __global__ __launch_bounds__(256) void satd8x8_lds_kernel(const int16_t *__restrict__ diff,
                                                           uint32_t *__restrict__ out, size_t n_blocks,
                                                           unsigned groups_per_wave)
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void satd8x8_lds_kernel(const int16_t *__restr
         for (int i = 0; i < 4; ++i) {
             size_t off = base + (size_t)lane * 16 + 1024 * (size_t)i;
             if (off + 16 > total_bytes) off = total_bytes - 16;       // ragged tail: stay inside the buffer
-            v[i] = load16<false>(reinterpret_cast<const char *>(diff) + off);
+            v[i] = load16<NT>(reinterpret_cast<const char *>(diff) + off);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<v4i *>(slot + lin[i]) = v[i];
@@ -312,10 +313,11 @@ hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_block
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs), block(tpb);
     if (cfg.lds_stage && cfg.variant == 0) {
-        hipLaunchKernelGGL(satd8x8_lds_kernel, grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
+        if (cfg.nontemporal & 1) hipLaunchKernelGGL((satd8x8_lds_kernel<true>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
+        else                     hipLaunchKernelGGL((satd8x8_lds_kernel<false>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
         return hipGetLastError();
     }
-    if (cfg.nontemporal) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
+    if (cfg.nontemporal & 4) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
     else                 hipLaunchKernelGGL((satd8x8_kernel<false>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
     return hipGetLastError();
 }

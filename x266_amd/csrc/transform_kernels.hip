@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void tr_fwd_small_kernel(const int16_t *__rest
 // memory, moved with linear 1 KiB instructions (whole 128-byte lines per instruction, see
 // dct32_kernels.hip section "LDS-staged variant") and re-read from a wave-private LDS slot in
 // fragment order.  N = 8 does not need it: its fragment loads are line-dense already.
-template <int LOGN>
+template <int LOGN, bool NT>
 __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
                                                                size_t n_blocks, const DctOps *__restrict__ ops,
                                                                unsigned tiles_per_wave)
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
         const bool live0 = o0 + 16 <= total_bytes, live1 = o1 + 16 <= total_bytes;
         if (!live0) o0 = total_bytes - 16;                               // ragged tail: stay inside the buffer
         if (!live1) o1 = total_bytes - 16;
-        const v4i g0 = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(in) + o0);
-        const v4i g1 = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(in) + o1);
+        const v4i g0 = load16<NT>(reinterpret_cast<const char *>(in) + o0);
+        const v4i g1 = load16<NT>(reinterpret_cast<const char *>(in) + o1);
         *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
         *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
         __builtin_amdgcn_wave_barrier();
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
         __builtin_amdgcn_wave_barrier();
-        if (live0) *reinterpret_cast<v4i *>(reinterpret_cast<char *>(out) + o0) = s0;
-        if (live1) *reinterpret_cast<v4i *>(reinterpret_cast<char *>(out) + o1) = s1;
+        if (live0) store16<NT>(reinterpret_cast<char *>(out) + o0, s0);
+        if (live1) store16<NT>(reinterpret_cast<char *>(out) + o1, s1);
     }
 }
 
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
 // after each pass -- DESIGN.md section 10), contiguous batches, same block-diagonal tile idea.  The
 // first contraction runs over the tile's ROW index, so each lane reads its COLUMN out of the staged
 // tile (16 x ds_read_u16), exactly as the staged DCT32 inverse does.
-template <int LOGN>
+template <int LOGN, bool NT>
 __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
                                                                size_t n_blocks, const DctOps *__restrict__ ops,
                                                                unsigned tiles_per_wave)
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
         const bool live0 = o0 + 16 <= total_bytes, live1 = o1 + 16 <= total_bytes;
         if (!live0) o0 = total_bytes - 16;
         if (!live1) o1 = total_bytes - 16;
-        const v4i g0 = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(in) + o0);
-        const v4i g1 = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(in) + o1);
+        const v4i g0 = load16<NT>(reinterpret_cast<const char *>(in) + o0);
+        const v4i g1 = load16<NT>(reinterpret_cast<const char *>(in) + o1);
         *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
         *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
         __builtin_amdgcn_wave_barrier();
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
         __builtin_amdgcn_wave_barrier();
-        if (live0) *reinterpret_cast<v4i *>(reinterpret_cast<char *>(out) + o0) = s0;
-        if (live1) *reinterpret_cast<v4i *>(reinterpret_cast<char *>(out) + o1) = s1;
+        if (live0) store16<NT>(reinterpret_cast<char *>(out) + o0, s0);
+        if (live1) store16<NT>(reinterpret_cast<char *>(out) + o1, s1);
     }
 }
 
@@ -274,11 +274,11 @@ hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out
         if (swgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
         const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
         dim3 sgrid((unsigned)swgs), sblock(tpb);
-        if (log2n == 2)      hipLaunchKernelGGL((tr_fwd_small_lds_kernel<2>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
-        else if (log2n == 3) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<3>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
-        else if (log2n == 4) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<4>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
-        else if (log2n == 5) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<5>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
+#define X266_TRL(L) do { if (cfg.nontemporal & 3) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, true>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw); \
+                         else                     hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, false>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw); } while (0)
+        if (log2n == 2) X266_TRL(2); else if (log2n == 3) X266_TRL(3); else if (log2n == 4) X266_TRL(4); else if (log2n == 5) X266_TRL(5);
         else return hipErrorInvalidValue;
+#undef X266_TRL
         return hipGetLastError();
     }
     const size_t wgs = (waves + 3) / 4;
@@ -309,10 +309,11 @@ hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
     dim3 grid((unsigned)wgs), block(tpb);
-    if (log2n == 2)      hipLaunchKernelGGL((tr_inv_small_lds_kernel<2>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
-    else if (log2n == 3) hipLaunchKernelGGL((tr_inv_small_lds_kernel<3>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
-    else if (log2n == 4) hipLaunchKernelGGL((tr_inv_small_lds_kernel<4>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, tpw);
+#define X266_TRI(L) do { if (cfg.nontemporal & 3) hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, tpw); \
+                         else                     hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, false>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, tpw); } while (0)
+    if (log2n == 2) X266_TRI(2); else if (log2n == 3) X266_TRI(3); else if (log2n == 4) X266_TRI(4);
     else return hipErrorInvalidValue;
+#undef X266_TRI
     return hipGetLastError();
 }
 

@@ -33,7 +33,8 @@ __device__ __forceinline__ void store16(void *p, const v4i &v)
 struct LaunchCfg {
     int cu_count;        // compute units of the device
     int wgs_per_cu;      // persistent launch: resident workgroups per CU
-    int nontemporal;     // use streaming loads/stores
+    int nontemporal;     // bit 0: nontemporal loads, bit 1: nontemporal stores in the line-dense (LDS-staged)
+                         // kernels; bit 2: the same hints in the direct fragment-pattern kernels (harmful there)
     int variant;         // 0 = streaming launch (grid covers the batch), 1 = persistent grid-stride
     int units_per_wave;  // streaming launch: consecutive units (DCT blocks / 32-block SATD groups) per wave
     int wg_threads;      // workgroup size, multiple of 64

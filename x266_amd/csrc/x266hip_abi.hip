@@ -31,10 +31,10 @@ struct x266hip_ctx {
     int wgs_per_cu_dct = 8;
     int wgs_per_cu_inv = 5;
     int wgs_per_cu_satd = 8;
-    int nontemporal = 0;
+    int nontemporal = 3;             // see LaunchCfg: hints on for the line-dense kernels (+1.5-3.5 %), off for fragment loads
     int dct_variant = 0, satd_variant = 0;          // 0 streaming launch, 1 persistent
     // streaming launch: consecutive units per wave (measured optimum on MI355X, profiles/r01_sweep.txt)
-    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 2;
+    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 1;
     int wg_threads = 256;
     int satd_wg_threads = 64;                       // SATD batch: one-wave workgroups (profiles/r01_satd_launch_shape.txt)
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
