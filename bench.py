@@ -256,7 +256,25 @@ def main():
                              "parity": "unpinned (no inverse in the reference); bit-exact vs this repo's oracle"}
         err = (r[: 4096 * 1024].to(torch.int32) - x[: 4096 * 1024].to(torch.int32)).abs().max().item()
         also["dct32_inv"]["roundtrip_max_abs_err"] = int(err)
-        del r
+        # fused forward + inverse: coefficients and reconstruction from one pass (6144 B per block)
+        z2 = torch.empty_like(x)
+
+        def fused(d_in, d_out, n_units, st):
+            codec.dct32_fwd_inv_dev(d_in, z2.data_ptr(), d_out, n_units, st)
+        for _ in range(args.warmup):
+            fused(x.data_ptr(), r.data_ptr(), n_dct, stream)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fused(x.data_ptr(), r.data_ptr(), n_dct, stream)
+        barrier()
+        wall_f = max_over_ranks(time.perf_counter() - t0)
+        also["dct32_fwd_inv_fused"] = {"value": world * n_dct * args.steps / wall_f, "unit": "blocks/s",
+                                       "ms_per_step": wall_f / args.steps * 1e3,
+                                       "hbm_frac": 6144.0 * n_dct * args.steps / wall_f / HBM_PEAK_BYTES_PER_S,
+                                       "same_bytes_as_two_kernels": bool(torch.equal(z2, z)),
+                                       "note": "wall-clock (launch gaps included); 2 KiB in, 2 + 2 KiB out per block"}
+        del r, z2
         d = torch.empty(n_satd * 64, dtype=torch.int16, device="cuda")
         s = torch.empty(n_satd, dtype=torch.int32, device="cuda")
         codec.fill_residual_dev(d.data_ptr(), n_satd * 64, SATD_SEED, rank * n_satd * 64, stream)

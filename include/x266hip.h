@@ -90,6 +90,12 @@ int xDct32FwdBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out,
  * column pass shift 7, row pass shift 12, int16 clipping after each pass). */
 int xDct32InvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out,
                       size_t n_blocks, void *stream);
+/* Forward and inverse in one pass over the batch: d_coef = forward(d_in) (may be NULL when only
+ * the reconstruction is wanted), d_recon = inverse(forward(d_in)) -- the transform half of an
+ * encoder's reconstruction loop; SURVEY 8(d) "fused fwd+inv", 6144 bytes per block instead of
+ * 8192.  Bit-identical to xDct32FwdBatchDev followed by xDct32InvBatchDev. */
+int xDct32FwdInvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_coef, int16_t *d_recon,
+                         size_t n_blocks, void *stream);
 /* 8x8 Hadamard SATD of n residual blocks: bit-exact with satd8x8
  * (src_tb/satd.c:31-118), including its int16 wraparound.  d_out[n] uint32. */
 int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out,

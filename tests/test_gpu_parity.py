@@ -90,6 +90,33 @@ def test_dct32_roundtrip_on_device(codec):
     assert err.max() <= 6 and err.mean() < 1.0                                      # same frozen bound as the oracle
 
 
+@pytest.mark.parametrize("n,per_wave,tpb,with_coef", [(1, 1, 64, True), (3, 2, 64, True), (257, 2, 256, False), (4099, 3, 128, True), (1500, 1, 64, False)])
+def test_dct32_fused_fwd_inv(codec, oracle, n, per_wave, tpb, with_coef):
+    """xDct32FwdInvBatchDev == forward then inverse, bit for bit (coefficients and reconstruction),
+    on realistic residuals and on full-range int16 (the inverse's clipping paths)."""
+    saved = {k: codec.get_option(k) for k in ("dct32_fwdinv_blocks_per_wave", "dct32_inv_wg_threads", "adaptive_per_wave")}
+    try:
+        codec.set_option("adaptive_per_wave", 0)                                    # small batches: keep the multi-block loop
+        codec.set_option("dct32_fwdinv_blocks_per_wave", per_wave)
+        codec.set_option("dct32_inv_wg_threads", tpb)
+        for x in (_mixed(n, 1024, 900 + n), dct_edge_blocks()[0]):
+            m = x.shape[0]
+            din, dco, dre = codec.alloc(m * 2048), codec.alloc(m * 2048), codec.alloc(m * 2048)
+            din.upload(x)
+            dco.upload(np.full((m, 1024), 0x5A5A, np.int16))
+            codec.dct32_fwd_inv_dev(din.ptr, dco.ptr if with_coef else 0, dre.ptr, m)
+            codec.stream_sync()
+            z = oracle.dct32_fwd(x, threads=8)
+            if with_coef:
+                assert np.array_equal(dco.download(np.int16, m * 1024).reshape(m, 1024), z)
+            else:
+                assert (dco.download(np.int16, m * 1024) == 0x5A5A).all()             # untouched
+            assert np.array_equal(dre.download(np.int16, m * 1024).reshape(m, 1024), oracle.dct32_inv(z, threads=8))
+    finally:
+        for k, v in saved.items():
+            codec.set_option(k, v)
+
+
 # ---------------------------------------------------------------- SATD
 def test_satd_golden_and_known_answers(codec):
     g = _golden("satd8x8.npz")
@@ -154,12 +181,13 @@ def test_argument_errors(codec):
 def test_launch_geometry_options_do_not_change_results(codec, oracle, variant, nt, tpb, per_wave, wgs, stage):
     x = residual_np(3001 * 1024, 0x266).reshape(-1, 1024)
     d = x.reshape(-1, 64)[:100003]
-    keys = ("nontemporal", "wg_threads", "satd_wg_threads", "dct32_wg_threads", "dct32_inv_wg_threads", "dct32_lds_stage", "satd_lds_stage", "dct32_variant", "satd_variant", "dct32_blocks_per_wave",
+    keys = ("adaptive_per_wave", "nontemporal", "wg_threads", "satd_wg_threads", "dct32_wg_threads", "dct32_inv_wg_threads", "dct32_lds_stage", "satd_lds_stage", "dct32_variant", "satd_variant", "dct32_blocks_per_wave",
             "dct32_inv_blocks_per_wave", "satd_groups_per_wave", "dct32_wgs_per_cu", "dct32_inv_wgs_per_cu",
             "satd_wgs_per_cu")
     saved = {k: codec.get_option(k) for k in keys}
     try:
         codec.set_option("nontemporal", nt)
+        codec.set_option("adaptive_per_wave", 0)
         for k in ("wg_threads", "satd_wg_threads", "dct32_wg_threads", "dct32_inv_wg_threads"):
             codec.set_option(k, tpb)
         codec.set_option("dct32_lds_stage", stage)
@@ -174,6 +202,27 @@ def test_launch_geometry_options_do_not_change_results(codec, oracle, variant, n
         assert np.array_equal(codec.dct32_fwd(x), z)
         assert np.array_equal(codec.dct32_inv(z), oracle.dct32_inv(z, threads=8))
         assert np.array_equal(codec.satd8x8(d), oracle.satd8x8(d, threads=8))
+    finally:
+        for k, v in saved.items():
+            codec.set_option(k, v)
+
+
+def test_adaptive_per_wave_clamp_keeps_results(codec, oracle):
+    """Mid-size batches (a few frames' worth): the launcher shrinks blocks-per-wave to keep the chip
+    filled; results must not depend on it."""
+    keys = ("adaptive_per_wave", "dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "satd_groups_per_wave")
+    saved = {k: codec.get_option(k) for k in keys}
+    x = residual_np(25001 * 1024, 77).reshape(-1, 1024)
+    z = oracle.dct32_fwd(x, threads=8)
+    try:
+        for k in keys[1:]:
+            codec.set_option(k, 8)
+        for adaptive in (1, 0):
+            codec.set_option("adaptive_per_wave", adaptive)
+            assert np.array_equal(codec.dct32_fwd(x), z)
+            assert np.array_equal(codec.dct32_inv(z), oracle.dct32_inv(z, threads=8))
+            d = x.reshape(-1, 64)
+            assert np.array_equal(codec.satd8x8(d), oracle.satd8x8(d, threads=8))
     finally:
         for k, v in saved.items():
             codec.set_option(k, v)

@@ -55,6 +55,7 @@ def load_library():
     L.xHipGetOption.argtypes = [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     for name in ("xDct32FwdBatchDev", "xDct32InvBatchDev", "xSatd8x8BatchDev"):
         getattr(L, name).argtypes = [_P, _P, _P, _SZ, _P]
+    L.xDct32FwdInvBatchDev.argtypes = [_P, _P, _P, _P, _SZ, _P]
     L.xFillResidualDev.argtypes = [_P, _P, _SZ, _U64, _U64, _P]
     L.xTransformFwdBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
     L.xConvInputFmtDev.argtypes = [_P, _P, _P, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
@@ -202,6 +203,9 @@ class Codec:
 
     def dct32_inv_dev(self, d_in, d_out, n_blocks, stream=0):
         self._check(self.L.xDct32InvBatchDev(self.ctx, d_in, d_out, n_blocks, stream), "xDct32InvBatchDev")
+
+    def dct32_fwd_inv_dev(self, d_in, d_coef, d_recon, n_blocks, stream=0):
+        self._check(self.L.xDct32FwdInvBatchDev(self.ctx, d_in, d_coef or None, d_recon, n_blocks, stream), "xDct32FwdInvBatchDev")
 
     def satd8x8_dev(self, d_in, d_out, n_blocks, stream=0):
         self._check(self.L.xSatd8x8BatchDev(self.ctx, d_in, d_out, n_blocks, stream), "xSatd8x8BatchDev")

@@ -236,6 +236,103 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
     }
 }
 
+// ---- fused forward + inverse (coefficients AND reconstruction) ------------------------------
+// recon = IDCT32(DCT32(x)) with both results written: 2 KiB in, 2 + 2 KiB out per block (6144
+// algorithmic bytes) instead of 4 + 4 KiB for the two kernels back to back.  After the
+// forward passes the coefficient tile sits in the wave's LDS slot for its line-dense store anyway;
+// the inverse reads its columns from there, as the staged inverse does from a loaded tile.
+template <bool NT>
+__global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__restrict__ in,
+                                                               int16_t *__restrict__ coef_out,
+                                                               int16_t *__restrict__ recon_out, size_t n_blocks,
+                                                               const DctOps *__restrict__ fwd_ops,
+                                                               const DctOps *__restrict__ inv_ops,
+                                                               unsigned blocks_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
+    const int lane = threadIdx.x & 63;
+    unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    size_t b = wave * blocks_per_wave;
+    const size_t end = b + blocks_per_wave < n_blocks ? b + blocks_per_wave : n_blocks;
+    if (b >= end) return;
+
+    const unsigned c = lane & 31, h = lane >> 5;
+    const unsigned lin0 = lds_slot(lane >> 2, lane & 3), lin1 = lds_slot(16 + (lane >> 2), lane & 3);
+    const unsigned frag0 = lds_slot(c, 2 * h), frag1 = lds_slot(c, 2 * h + 1);
+    unsigned col_base[4];
+    {
+        const unsigned u = (unsigned)kappa((int)c);
+#pragma unroll
+        for (unsigned j = 0; j < 4; ++j) col_base[j] = 16u * h * 64u + ((((u >> 3) ^ j) & 3u) << 4) + (u & 7u) * 2u;
+    }
+    const char *src = reinterpret_cast<const char *>(in) + lane * 16;
+    const size_t lane_off = (size_t)lane * 16;
+
+    v4i g0 = load16<NT>(src + b * 2048), g1 = load16<NT>(src + b * 2048 + 1024);
+    const LaneConsts kf = load_consts(fwd_ops, lane);
+    const LaneConsts ki = load_consts(inv_ops, lane);
+    v16i c2r;
+    {
+        const int *__restrict__ s0 = inv_ops->c2r[0], *__restrict__ s1 = inv_ops->c2r[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c2r[r] = h ? s1[r] : s0[r];
+    }
+    while (true) {
+        const size_t nb = b + 1;
+        *reinterpret_cast<v4i *>(slot + lin0) = g0;
+        *reinterpret_cast<v4i *>(slot + lin1) = g1;
+        if (nb < end) {
+            g0 = load16<NT>(src + nb * 2048);
+            g1 = load16<NT>(src + nb * 2048 + 1024);
+        }
+        __builtin_amdgcn_wave_barrier();
+        v4i o0, o1;
+        {
+            const v4i a0 = *reinterpret_cast<const v4i *>(slot + frag0);
+            const v4i a1 = *reinterpret_cast<const v4i *>(slot + frag1);
+            fwd_block<4, 11>(a0, a1, kf, o0, o1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<v4i *>(slot + frag0) = o0;               // coefficient tile, row-major (swizzled)
+        *reinterpret_cast<v4i *>(slot + frag1) = o1;
+        __builtin_amdgcn_wave_barrier();
+        if (coef_out) {
+            const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
+            const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
+            char *dst = reinterpret_cast<char *>(coef_out) + b * 2048 + lane_off;
+            store16<NT>(dst, s0);
+            store16<NT>(dst + 1024, s1);
+        }
+        {
+            uint32_t w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const uint32_t e0 = *reinterpret_cast<const uint16_t *>(slot + col_base[((2 * m) >> 2) & 3] + (2 * m) * 64);
+                const uint32_t e1 = *reinterpret_cast<const uint16_t *>(slot + col_base[((2 * m + 1) >> 2) & 3] + (2 * m + 1) * 64);
+                w[m] = e0 | (e1 << 16);
+            }
+            v4i lo, hi;
+            split_planes(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, lo, hi);
+            inv_passes(lo, hi, ki, c2r, o0, o1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<v4i *>(slot + frag0) = o0;
+        *reinterpret_cast<v4i *>(slot + frag1) = o1;
+        __builtin_amdgcn_wave_barrier();
+        {
+            const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
+            const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
+            __builtin_amdgcn_wave_barrier();
+            char *dst = reinterpret_cast<char *>(recon_out) + b * 2048 + lane_off;
+            store16<NT>(dst, s0);
+            store16<NT>(dst + 1024, s1);
+        }
+        if (nb >= end) break;
+        b = nb;
+    }
+}
+
 // ---- fused residual + forward transform -----------------------------------------------------
 // coef = DCT32(cur - pred) straight from two tiled frames (ref_block_t, src/x266.cpp:56-63),
 // without materialising the residual: 2 KiB of pixels in, 2 KiB of coefficients out per block
@@ -291,7 +388,7 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
     unsigned bpw = 0;
     size_t wgs;
     if (cfg.variant == 0) {                                    // streaming launch
-        bpw = cfg.units_per_wave < 1 ? 1u : (unsigned)cfg.units_per_wave;
+        bpw = units_per_wave_for(cfg, n_blocks);
         const size_t waves = (n_blocks + bpw - 1) / bpw;
         wgs = (waves + waves_per_wg - 1) / waves_per_wg;
     } else {                                                   // persistent launch
@@ -318,6 +415,20 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
     if (cfg.nontemporal & 4) { if (mode == 0) X266_LAUNCH(0, true); else if (mode == 1) X266_LAUNCH(1, true); else X266_LAUNCH(2, true); }
     else                 { if (mode == 0) X266_LAUNCH(0, false); else if (mode == 1) X266_LAUNCH(1, false); else X266_LAUNCH(2, false); }
 #undef X266_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,
+                               const DctOps *d_fwd_ops, const DctOps *d_inv_lds_ops, const LaunchCfg &cfg, hipStream_t stream)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const unsigned tpb = (unsigned)cfg.wg_threads;
+    const unsigned bpw = units_per_wave_for(cfg, n_blocks);
+    const size_t wpw = tpb / 64, waves = (n_blocks + bpw - 1) / bpw, wgs = (waves + wpw - 1) / wpw;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
+    if (cfg.nontemporal & 3) hipLaunchKernelGGL((dct32_fwdinv_lds_kernel<true>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
+    else                     hipLaunchKernelGGL((dct32_fwdinv_lds_kernel<false>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
     return hipGetLastError();
 }
 

@@ -276,8 +276,11 @@ __global__ __launch_bounds__(256) void satd_search_kernel(const MeParams P)
 
 // Pre-pass: Hc of every 8x8 block of the current frame, 32 dwords per block in the
 // order the search kernel's lanes hold a position: [coefficient set of half 0][half 1].
+// Blocks are stored TILE-MAJOR (search tile, then block row, then block column inside the tile):
+// the search kernel addresses all blocks of its tile from one scalar base with immediate offsets.
 __global__ __launch_bounds__(256) void me_coef_kernel(const uint8_t *__restrict__ cur, long long cur_stride,
-                                                      int blocks_x, int n_blocks, uint32_t *__restrict__ coef)
+                                                      int blocks_x, int n_blocks, int tiles_x, int tby,
+                                                      uint32_t *__restrict__ coef)
 {
     const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
     const int group = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -301,7 +304,9 @@ __global__ __launch_bounds__(256) void me_coef_kernel(const uint8_t *__restrict_
     uint32_t p[16];
     hadamard_pack(H, v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, p);
     if (live) {
-        v4i *dst = reinterpret_cast<v4i *>(coef + (size_t)blk * 32 + 16 * half);
+        const size_t slot = ((size_t)(by / tby) * tiles_x + bx / kTileBlocksX) * (size_t)(kTileBlocksX * tby)
+                            + (size_t)(by % tby) * kTileBlocksX + bx % kTileBlocksX;
+        v4i *dst = reinterpret_cast<v4i *>(coef + slot * 32 + 16 * half);
 #pragma unroll
         for (int k = 0; k < 4; ++k) dst[k] = v4i{(int)p[4 * k], (int)p[4 * k + 1], (int)p[4 * k + 2], (int)p[4 * k + 3]};
     }
@@ -375,6 +380,7 @@ __global__ __launch_bounds__(256) void satd_search_kernel_v2(const MeParams P, c
     const int blocks_left_x = P.blocks_x - tx * kTileBlocksX, blocks_left_y = P.blocks_y - ty * TBY;
     // after the half exchange lanes 0-31 own the odd row of a pair, lanes 32-63 the even row
     const int lane_row = half ? 0 : 1;
+    const uint32_t *__restrict__ tile_coef = coef + (size_t)blockIdx.x * (NBLK * 32);
     const uint32_t lane_idx = (uint32_t)(lane_row * span + n);
     for (int item = wave; item < n_items; item += n_waves) {
         const int strip = item / P.n_groups, g = item - strip * P.n_groups;   // wave-uniform
@@ -405,8 +411,7 @@ __global__ __launch_bounds__(256) void satd_search_kernel_v2(const MeParams P, c
             for (int i = 0; i < kTileBlocksX; ++i) {
                 const int lo = 32 * g - 8 * i;                         // dx index of lane 0 for block i
                 if (lo + 31 < 0 || lo >= span || i >= blocks_left_x) continue;       // wave-uniform
-                const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
-                const uint32_t *__restrict__ c = coef + blk * 32;
+                const uint32_t *__restrict__ c = tile_coef + (j * kTileBlocksX + i) * 32;
                 uint32_t s[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) s[u] = 2u;                 // the "+2" of (sum + 2) >> 2
@@ -431,7 +436,10 @@ __global__ __launch_bounds__(256) void satd_search_kernel_v2(const MeParams P, c
                         key = ok ? key : 0x7FFFFFFFu;
                     }
                     best[j][i] = key < best[j][i] ? key : best[j][i];
-                    if (P.costs && ok) P.costs[blk * (size_t)(span * span) + idx] = s[u] >> 2;
+                    if (P.costs && ok) {
+                        const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
+                        P.costs[blk * (size_t)(span * span) + idx] = s[u] >> 2;
+                    }
                 }
             }
         }
@@ -487,7 +495,7 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
         const int n_blocks = P.blocks_x * P.blocks_y;
         const int groups = (n_blocks + 31) / 32;
         hipLaunchKernelGGL(me_coef_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, stream, d_cur, cur_stride,
-                           P.blocks_x, n_blocks, d_coef_scratch);
+                           P.blocks_x, n_blocks, P.tiles_x, tby, d_coef_scratch);
         {
             const hipError_t e0 = hipGetLastError();
             if (e0 != hipSuccess) return e0;

@@ -302,7 +302,7 @@ hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_block
     unsigned gpw = 0;
     size_t wgs;
     if (cfg.variant == 0) {                                    // streaming launch
-        gpw = cfg.units_per_wave < 1 ? 1u : (unsigned)cfg.units_per_wave;
+        gpw = units_per_wave_for(cfg, groups);
         const size_t waves = (groups + gpw - 1) / gpw;
         wgs = (waves + waves_per_wg - 1) / waves_per_wg;
     } else {                                                   // persistent launch

@@ -266,7 +266,7 @@ hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out
     if (n_blocks == 0) return hipSuccess;
     const size_t per_tile = (size_t)(32 >> log2n) * (size_t)(32 >> log2n);
     const size_t tiles = (n_blocks + per_tile - 1) / per_tile;
-    const unsigned tpw = cfg.units_per_wave < 1 ? 1u : (unsigned)cfg.units_per_wave;
+    const unsigned tpw = units_per_wave_for(cfg, tiles);
     const size_t waves = (tiles + tpw - 1) / tpw;
     if (!d_offsets && cfg.lds_stage) {                           // contiguous batch: line-dense traffic through LDS
         const unsigned tpb = (unsigned)cfg.wg_threads;            // same launch shape as the staged DCT32 kernel
@@ -302,7 +302,7 @@ hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d
     if (n_blocks == 0) return hipSuccess;
     const size_t per_tile = (size_t)(32 >> log2n) * (size_t)(32 >> log2n);
     const size_t tiles = (n_blocks + per_tile - 1) / per_tile;
-    const unsigned tpw = cfg.units_per_wave < 1 ? 1u : (unsigned)cfg.units_per_wave;
+    const unsigned tpw = units_per_wave_for(cfg, tiles);
     const size_t waves = (tiles + tpw - 1) / tpw;
     const unsigned tpb = (unsigned)cfg.wg_threads;
     const size_t wpw = tpb / 64, wgs = (waves + wpw - 1) / wpw;

@@ -33,6 +33,7 @@ __device__ __forceinline__ void store16(void *p, const v4i &v)
 struct LaunchCfg {
     int cu_count;        // compute units of the device
     int wgs_per_cu;      // persistent launch: resident workgroups per CU
+    int adaptive;        // shrink units_per_wave on small batches so the grid still fills the chip
     int nontemporal;     // bit 0: nontemporal loads, bit 1: nontemporal stores in the line-dense (LDS-staged)
                          // kernels; bit 2: the same hints in the direct fragment-pattern kernels (harmful there)
     int variant;         // 0 = streaming launch (grid covers the batch), 1 = persistent grid-stride
@@ -46,6 +47,21 @@ struct LaunchCfg {
 
 struct DctOps;
 
+// Units (blocks, groups, tiles) one wave loops over: the configured count, reduced on small batches
+// until the launch has at least two full rounds of resident waves (about 40 per CU).
+inline unsigned units_per_wave_for(const LaunchCfg &cfg, size_t n_units)
+{
+    unsigned u = cfg.units_per_wave < 1 ? 1u : (unsigned)cfg.units_per_wave;
+    if (cfg.adaptive) {
+        const size_t fill = (size_t)cfg.cu_count * 40u;
+        const size_t cap = n_units / fill;
+        if (cap < u) u = cap < 1 ? 1u : (unsigned)cap;
+    }
+    return u;
+}
+
+hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,
+                               const DctOps *d_fwd_ops, const DctOps *d_inv_lds_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_blocks,
                         const DctOps *d_ops, const DctOps *d_ops_lds_inv, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,

@@ -35,6 +35,8 @@ struct x266hip_ctx {
     int dct_variant = 0, satd_variant = 0;          // 0 streaming launch, 1 persistent
     // streaming launch: consecutive units per wave (measured optimum on MI355X, profiles/r01_sweep.txt)
     int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 1;
+    int dct_fwdinv_blocks_per_wave = 8;
+    int adaptive_per_wave = 1;
     int wg_threads = 256;
     int satd_wg_threads = 64;                       // SATD batch: one-wave workgroups (profiles/r01_satd_launch_shape.txt)
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
@@ -88,6 +90,7 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
     c.cu_count = ctx->prop.multiProcessorCount;
     c.wgs_per_cu = op == 0 ? ctx->wgs_per_cu_dct : (op == 1 ? ctx->wgs_per_cu_inv : ctx->wgs_per_cu_satd);
     c.nontemporal = ctx->nontemporal;
+    c.adaptive = ctx->adaptive_per_wave;
     c.variant = op == 2 ? ctx->satd_variant : ctx->dct_variant;
     c.units_per_wave = op == 2 ? ctx->satd_groups_per_wave : (op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave);
     c.wg_threads = op == 2 ? ctx->satd_wg_threads : ctx->wg_threads;
@@ -228,10 +231,12 @@ static int *option_slot(x266hip_ctx *ctx, const char *key)
     if (!std::strcmp(key, "dct32_inv_wgs_per_cu")) return &ctx->wgs_per_cu_inv;
     if (!std::strcmp(key, "satd_wgs_per_cu")) return &ctx->wgs_per_cu_satd;
     if (!std::strcmp(key, "nontemporal")) return &ctx->nontemporal;
+    if (!std::strcmp(key, "adaptive_per_wave")) return &ctx->adaptive_per_wave;
     if (!std::strcmp(key, "dct32_variant")) return &ctx->dct_variant;
     if (!std::strcmp(key, "satd_variant")) return &ctx->satd_variant;
     if (!std::strcmp(key, "dct32_blocks_per_wave")) return &ctx->dct_blocks_per_wave;
     if (!std::strcmp(key, "dct32_inv_blocks_per_wave")) return &ctx->dct_inv_blocks_per_wave;
+    if (!std::strcmp(key, "dct32_fwdinv_blocks_per_wave")) return &ctx->dct_fwdinv_blocks_per_wave;
     if (!std::strcmp(key, "satd_groups_per_wave")) return &ctx->satd_groups_per_wave;
     if (!std::strcmp(key, "wg_threads")) return &ctx->wg_threads;
     if (!std::strcmp(key, "satd_wg_threads")) return &ctx->satd_wg_threads;
@@ -260,7 +265,7 @@ int xHipSetOption(x266hip_ctx *ctx, const char *key, int value)
     if (!slot) return X266HIP_EINVAL;
     if (std::strstr(key, "wgs_per_cu") && (value < 1 || value > 64)) return fail(ctx, X266HIP_EINVAL, "wgs_per_cu out of range");
     if (!std::strcmp(key, "tr_tiles_per_wave") && (value < 1 || value > 64)) return fail(ctx, X266HIP_EINVAL, "tiles per wave out of range");
-    if (std::strstr(key, "_per_wave") && !std::strstr(key, "lds_bytes") && std::strcmp(key, "tr_tiles_per_wave") && (value < 1 || value > 4096)) return fail(ctx, X266HIP_EINVAL, "units per wave out of range");
+    if (std::strstr(key, "_per_wave") && !std::strstr(key, "lds_bytes") && std::strcmp(key, "tr_tiles_per_wave") && std::strcmp(key, "adaptive_per_wave") && (value < 1 || value > 4096)) return fail(ctx, X266HIP_EINVAL, "units per wave out of range");
     if (std::strstr(key, "lds_pad_bytes") && (value < 0 || value > 160 * 1024)) return fail(ctx, X266HIP_EINVAL, "lds pad out of range");
     if (std::strstr(key, "lds_bytes_per_wave") && (value < 2048 || value > 40960)) return fail(ctx, X266HIP_EINVAL, "lds bytes per wave out of range");
     if (std::strstr(key, "_wg_threads") && (value < 64 || value > 256 || value % 64)) return fail(ctx, X266HIP_EINVAL, "wg_threads must be 64, 128, 192 or 256");
@@ -292,6 +297,19 @@ int xDct32InvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out, siz
     if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xDct32InvBatchDev: NULL or unaligned buffer");
     X_HIP(ctx, hipSetDevice(ctx->device));
     return launch_op(ctx, 1, d_in, d_out, n, (hipStream_t)stream);
+}
+
+int xDct32FwdInvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (bad_ptrs(d_in, d_recon, n) || (n && d_coef && ((uintptr_t)d_coef & 15u)))
+        return fail(ctx, X266HIP_EINVAL, "xDct32FwdInvBatchDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    LaunchCfg cfg = cfg_for(ctx, 1);
+    cfg.units_per_wave = ctx->dct_fwdinv_blocks_per_wave;
+    hipError_t e = launch_dct32_fwdinv(d_in, d_coef, d_recon, n, ctx->d_fwd, ctx->d_inv_lds, cfg, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fwd+inv launch", e);
+    return X266HIP_OK;
 }
 
 int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out, size_t n, void *stream)
@@ -464,7 +482,8 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
     if (cur_stride < width || ref_stride < width + 2 * range) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: stride too small");
     if (((uintptr_t)d_best & 7u) || ((uintptr_t)d_costs & 3u)) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: unaligned output");
     X_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t need = (size_t)(width / 8) * (size_t)(height / 8) * 128;
+    // tile-major table: whole search tiles (8 x up to 4 blocks), partial edge tiles padded
+    const size_t need = (size_t)((width / 8 + 7) / 8) * 8 * (size_t)((height / 8 + 3) / 4) * 4 * 128;
     if (ctx->me_variant == 2 && need > ctx->me_coef_bytes) {          // grow-only scratch (not stream-ordered: sync first)
         X_HIP(ctx, hipDeviceSynchronize());
         if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
