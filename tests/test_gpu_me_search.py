@@ -17,19 +17,21 @@ pytestmark = pytest.mark.gpu
 def test_every_candidate_cost_and_winner(codec, oracle, w, h, rng, tile_rows, variant, row_pairs):
     pad = rng + 3
     cur, refp = me_frames(w, h, pad, 100 + w + h + rng, mv=(min(rng, 3), -min(rng, 2)))
+    saved = {k: codec.get_option(k) for k in ("me_tile_rows", "me_variant", "me_row_pairs")}
     codec.set_option("me_tile_rows", tile_rows)
     codec.set_option("me_variant", variant)
     codec.set_option("me_row_pairs", row_pairs)
     try:
         mv, cost, costs = codec.satd_search(cur, refp, pad, rng, want_costs=True)
+        mv2, cost2, _ = codec.satd_search(cur, refp, pad, rng)          # the search-only kernel (no cost map)
     finally:
-        codec.set_option("me_tile_rows", 4)
-        codec.set_option("me_variant", 2)
-        codec.set_option("me_row_pairs", 1)
+        for k, v in saved.items():
+            codec.set_option(k, v)
     omv, ocost, ocosts = oracle.satd_search(cur, refp, pad, rng, threads=8, want_costs=True)
     assert np.array_equal(costs, ocosts)                 # all (2R+1)^2 costs of every block
     assert np.array_equal(cost, ocost)
     assert np.array_equal(mv, omv)                       # same winner => same tie-break
+    assert np.array_equal(cost2, ocost) and np.array_equal(mv2, omv)
 
 
 def test_tie_break_is_first_in_raster_order(codec, oracle):

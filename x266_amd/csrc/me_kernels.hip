@@ -330,7 +330,9 @@ __device__ __forceinline__ void load_window(const unsigned char *win, int pitch,
 
 // U = row pairs scored per coefficient fetch (each lane then holds U positions): the scalar
 // loads of a block's 32 coefficient dwords are amortised over 32*U v_sad_u16.
-template <int TBY, int U>
+// COSTS: also write the full cost map (test / analysis path; keeps its per-block pointers out of
+// the search-only kernel's scalar registers).
+template <int TBY, int U, bool COSTS>
 __global__ __launch_bounds__(256) void satd_search_kernel_v2(const MeParams P, const uint32_t *__restrict__ coef)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256) void satd_search_kernel_v2(const MeParams P, c
                         key = ok ? key : 0x7FFFFFFFu;
                     }
                     best[j][i] = key < best[j][i] ? key : best[j][i];
-                    if (P.costs && ok) {
+                    if (COSTS && ok) {
                         const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
                         P.costs[blk * (size_t)(span * span) + idx] = s[u] >> 2;
                     }
@@ -503,7 +505,8 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
         const int U = row_pairs == 1 ? 1 : (row_pairs == 3 ? 3 : 2);
         const size_t lds = 128 + (size_t)(P.n_rows + 7 + 2 * U) * P.pitch;   // the last strip may be partly empty
         const uint32_t *cf = d_coef_scratch;
-#define X266_ME(T, UU) hipLaunchKernelGGL((satd_search_kernel_v2<T, UU>), grid, block, lds, stream, P, cf)
+#define X266_ME(T, UU) do { if (d_costs) hipLaunchKernelGGL((satd_search_kernel_v2<T, UU, true>), grid, block, lds, stream, P, cf); \
+                            else         hipLaunchKernelGGL((satd_search_kernel_v2<T, UU, false>), grid, block, lds, stream, P, cf); } while (0)
         if (tby == 4)      { if (U == 1) X266_ME(4, 1); else if (U == 2) X266_ME(4, 2); else X266_ME(4, 3); }
         else if (tby == 1) { if (U == 1) X266_ME(1, 1); else if (U == 2) X266_ME(1, 2); else X266_ME(1, 3); }
         else               { if (U == 1) X266_ME(2, 1); else if (U == 2) X266_ME(2, 2); else X266_ME(2, 3); }

@@ -41,7 +41,7 @@ struct x266hip_ctx {
     int satd_wg_threads = 64;                       // SATD batch: one-wave workgroups (profiles/r01_satd_launch_shape.txt)
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
     int me_tile_rows = 4;                           // block rows per ME tile (1, 2 or 4)
-    int me_row_pairs = 1;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
+    int me_row_pairs = 2;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
     int me_variant = 2;                             // 1 = LDS coefficients, 2 = scalar coefficients (me_kernels.hip)
     uint32_t *d_me_coef = nullptr;                  // variant 2 scratch: 128 B per 8x8 block of the current frame
     size_t me_coef_bytes = 0;
@@ -482,8 +482,8 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
     if (cur_stride < width || ref_stride < width + 2 * range) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: stride too small");
     if (((uintptr_t)d_best & 7u) || ((uintptr_t)d_costs & 3u)) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: unaligned output");
     X_HIP(ctx, hipSetDevice(ctx->device));
-    // tile-major table: whole search tiles (8 x up to 4 blocks), partial edge tiles padded
-    const size_t need = (size_t)((width / 8 + 7) / 8) * 8 * (size_t)((height / 8 + 3) / 4) * 4 * 128;
+    // tile-major table: whole search tiles (8 x up to 4 blocks), partial edge tiles padded (tile heights 1, 2, 4, 8 all fit)
+    const size_t need = (size_t)((width / 8 + 7) / 8) * 8 * (size_t)((height / 8 + 7) / 8) * 8 * 128;
     if (ctx->me_variant == 2 && need > ctx->me_coef_bytes) {          // grow-only scratch (not stream-ordered: sync first)
         X_HIP(ctx, hipDeviceSynchronize());
         if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
