@@ -27,3 +27,10 @@ for nt in (3,):
             for bpw in (3, 4, 6, 8, 16):
                 cd.set_option("dct32_fwdinv_blocks_per_wave", bpw)
                 print("nt=%d tpb=%3d lds=%5d bpw=%d : %.4f ms %.3f TB/s" % ((nt, tpb, lds, bpw) + t()), flush=True)
+cd2 = x266_amd.Codec(0)
+cd = cd2
+print("defaults:", {k: cd.get_option(k) for k in ("nontemporal", "dct32_inv_wg_threads", "dct32_inv_lds_bytes_per_wave", "dct32_fwdinv_blocks_per_wave", "adaptive_per_wave")})
+print("fresh ctx defaults: %.4f ms %.3f TB/s" % t())
+for a in (0, 1):
+    cd.set_option("adaptive_per_wave", a)
+    print("adaptive=%d: %.4f ms %.3f TB/s" % ((a,) + t()))
