@@ -408,13 +408,14 @@ def main():
 
         # ---- BASELINE configs[4] (on request): 8K frame stream, scatter -> kernels -> gather over RCCL
         if args.stream8k > 0 and ctrl == "cuda":
-            from x266_amd.stream import FrameGeometry, ShardedFrameStream
+            from x266_amd.stream import FrameGeometry, PipelinedFrameStream
             geo = FrameGeometry(7680, 4320)
             dev = torch.device("cuda", local_rank)
-            st8 = ShardedFrameStream(
+            cur_stream = lambda: torch.cuda.current_stream().cuda_stream
+            st8 = PipelinedFrameStream(
                 geo, dev,
-                lambda tin, tout, nblk: codec.dct32_fwd_dev(tin.data_ptr(), tout.data_ptr(), nblk, stream),
-                lambda tin, tout, nblk: codec.satd8x8_dev(tin.data_ptr(), tout.data_ptr(), nblk, stream),
+                lambda tin, tout, nblk: codec.dct32_fwd_dev(tin.data_ptr(), tout.data_ptr(), nblk, cur_stream()),
+                lambda tin, tout, nblk: codec.satd8x8_dev(tin.data_ptr(), tout.data_ptr(), nblk, cur_stream()),
                 dist=dist)
             fd = fs = None
             if rank == 0:
@@ -422,22 +423,26 @@ def main():
                 fs = torch.empty(geo.satd_blocks * 64, dtype=torch.int16, device=dev)
                 codec.fill_residual_dev(fd.data_ptr(), fd.numel(), DCT_SEED, 0, stream)
                 codec.fill_residual_dev(fs.data_ptr(), fs.numel(), SATD_SEED, 0, stream)
-            for _ in range(2):
-                st8.process(fd, fs)
+            sums = []
+
+            def sink8(f, coef, cost):
+                if f == args.stream8k - 1:
+                    sums.append(int(coef.to(torch.int64).sum().item()) + int(cost.to(torch.int64).sum().item()))
+            st8.run(3, lambda f: (fd, fs), None)
             barrier()
             t0 = time.perf_counter()
-            for _ in range(args.stream8k):
-                coef8, cost8 = st8.process(fd, fs)
+            st8.run(args.stream8k, lambda f: (fd, fs), sink8)
             barrier()
             wall8 = max_over_ranks(time.perf_counter() - t0)
             also["stream8k"] = {
                 "frames_per_s": args.stream8k / wall8, "ms_per_frame": wall8 / args.stream8k * 1e3,
                 "frame": "7680x4320: %d DCT32 blocks (66.4 MB) + %d SATD blocks (66.4 MB)" % (geo.dct_blocks, geo.satd_blocks),
-                "path": "rank 0 scatters the two batches, every rank transforms its shard, rank 0 gathers coefficients and costs"
-                        if world > 1 else "single rank: device copies + kernels, no collective",
+                "path": "rank 0 sends every peer its shard of frame f+1 and receives frame f-1's coefficients and costs "
+                        "(batched isend/irecv on a side stream) while all ranks transform frame f"
+                        if world > 1 else "single rank: device copies + kernels, no transfer",
                 "link_bound": "one xGMI link ~153 GB/s => <= 7.5e7 DCT32 input blocks/s per peer (SURVEY.md 8e)"}
             if rank == 0:
-                also["stream8k"]["output_checksum"] = int(coef8.to(torch.int64).sum().item()) + int(cost8.to(torch.int64).sum().item())
+                also["stream8k"]["output_checksum"] = sums[0] if sums else None
         result["also"] = also
 
     # ---- CPU baseline for the headline leg (rank 0, N = 1 only) ------------------------------------
