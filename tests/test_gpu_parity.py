@@ -175,8 +175,8 @@ def test_argument_errors(codec):
 
 
 @pytest.mark.parametrize("variant,nt,tpb,per_wave,wgs,stage", [
-    (0, 0, 64, 1, 8, 0), (0, 4, 256, 3, 8, 0), (0, 3, 128, 16, 8, 0), (0, 0, 192, 7, 8, 0),
-    (0, 0, 64, 1, 8, 1), (0, 3, 256, 3, 8, 1), (0, 1, 128, 16, 8, 1), (0, 2, 192, 7, 8, 1),
+    (0, 0, 64, 1, 8, 0), (0, 4, 256, 3, 8, 0), (0, 3, 128, 16, 8, 0), (0, 11, 192, 7, 8, 0),
+    (0, 0, 64, 1, 8, 1), (0, 3, 256, 3, 8, 1), (0, 1, 128, 16, 8, 1), (0, 2, 192, 7, 8, 1), (0, 11, 64, 5, 8, 1), (0, 0, 256, 2, 8, 1),
     (1, 0, 256, 1, 1, 0), (1, 7, 64, 1, 3, 0), (1, 3, 256, 1, 8, 1)])
 def test_launch_geometry_options_do_not_change_results(codec, oracle, variant, nt, tpb, per_wave, wgs, stage):
     x = residual_np(3001 * 1024, 0x266).reshape(-1, 1024)

@@ -1,0 +1,89 @@
+// membench6: cache-policy bits (sc0 / sc1 / nt) on line-dense 16 B/lane loads and stores, in the
+// launch shape of the staged kernels (one-wave workgroups, 8 KiB dynamic LDS per wave, one 2 KiB
+// tile per wave).  modes: copy, read-only (sum), write-only.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+#define LD(NAME, BITS) __device__ __forceinline__ v4i NAME(const char *p) { v4i v; asm volatile("global_load_dwordx4 %0, %1, off " BITS : "=v"(v) : "v"(p) : "memory"); return v; }
+#define ST(NAME, BITS) __device__ __forceinline__ void NAME(char *p, v4i v) { asm volatile("global_store_dwordx4 %0, %1, off " BITS :: "v"(p), "v"(v) : "memory"); }
+LD(ld_0, "") LD(ld_nt, "nt") LD(ld_sc1, "sc1") LD(ld_sc0sc1, "sc0 sc1") LD(ld_sc0sc1nt, "sc0 sc1 nt") LD(ld_sc0, "sc0") LD(ld_sc1nt, "sc1 nt") LD(ld_sc0nt, "sc0 nt")
+ST(st_0, "") ST(st_nt, "nt") ST(st_sc1, "sc1") ST(st_sc0sc1, "sc0 sc1") ST(st_sc0sc1nt, "sc0 sc1 nt") ST(st_sc0, "sc0") ST(st_sc1nt, "sc1 nt") ST(st_sc0nt, "sc0 nt")
+
+template <int L, int S, int MODE>
+__global__ __launch_bounds__(64) void k(const char *in, char *out, size_t tiles)
+{
+    extern __shared__ char pad[];
+    const size_t t = blockIdx.x;
+    if (t >= tiles) return;
+    const char *src = in + t * 2048 + threadIdx.x * 16;
+    char *dst = out + t * 2048 + threadIdx.x * 16;
+    v4i a = {1, 2, 3, 4}, b = {5, 6, 7, 8};
+    if (MODE != 2) {
+        if (L == 0) { a = ld_0(src); b = ld_0(src + 1024); }
+        if (L == 1) { a = ld_nt(src); b = ld_nt(src + 1024); }
+        if (L == 2) { a = ld_sc1(src); b = ld_sc1(src + 1024); }
+        if (L == 3) { a = ld_sc0sc1(src); b = ld_sc0sc1(src + 1024); }
+        if (L == 4) { a = ld_sc0sc1nt(src); b = ld_sc0sc1nt(src + 1024); }
+        if (L == 5) { a = ld_sc0(src); b = ld_sc0(src + 1024); }
+        if (L == 6) { a = ld_sc1nt(src); b = ld_sc1nt(src + 1024); }
+        if (L == 7) { a = ld_sc0nt(src); b = ld_sc0nt(src + 1024); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (MODE == 1) {
+        const int s = a[0] + a[1] + a[2] + a[3] + b[0] + b[1] + b[2] + b[3];
+        if (s == 0x12345678) out[t] = 1;                       // never true for the fill pattern
+        return;
+    }
+    if (S == 0) { st_0(dst, a); st_0(dst + 1024, b); }
+    if (S == 1) { st_nt(dst, a); st_nt(dst + 1024, b); }
+    if (S == 2) { st_sc1(dst, a); st_sc1(dst + 1024, b); }
+    if (S == 3) { st_sc0sc1(dst, a); st_sc0sc1(dst + 1024, b); }
+    if (S == 4) { st_sc0sc1nt(dst, a); st_sc0sc1nt(dst + 1024, b); }
+    if (S == 5) { st_sc0(dst, a); st_sc0(dst + 1024, b); }
+    if (S == 6) { st_sc1nt(dst, a); st_sc1nt(dst + 1024, b); }
+    if (S == 7) { st_sc0nt(dst, a); st_sc0nt(dst + 1024, b); }
+}
+
+static const char *names[8] = {"-", "nt", "sc1", "sc0 sc1", "sc0 sc1 nt", "sc0", "sc1 nt", "sc0 nt"};
+
+template <int L, int S, int MODE>
+static void run(const char *in, char *out, size_t tiles, size_t lds)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k<L, S, MODE>), dim3((unsigned)tiles), dim3(64), lds, 0, in, out, tiles);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+        if (rep && ms < best) best = ms;
+    }
+    const double bytes = (MODE == 0 ? 4096.0 : 2048.0) * tiles;
+    printf("%-5s load[%-10s] store[%-10s] lds=%5zu : %.4f ms  %.3f TB/s\n", MODE == 0 ? "copy" : (MODE == 1 ? "read" : "write"),
+           MODE == 2 ? "" : names[L], MODE == 1 ? "" : names[S], lds, best, bytes / best / 1e9);
+    fflush(stdout);
+}
+
+int main()
+{
+    const size_t tiles = 1 << 20, bytes = tiles * 2048;
+    char *in, *out;
+    if (hipMalloc(&in, bytes) != hipSuccess || hipMalloc(&out, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipMemset(in, 1, bytes); hipMemset(out, 0, bytes); hipDeviceSynchronize();
+    for (size_t lds : {(size_t)8192}) {
+#define COPY(L, S) run<L, S, 0>(in, out, tiles, lds)
+        COPY(0, 0); COPY(1, 1); COPY(0, 1); COPY(1, 0);
+        COPY(0, 2); COPY(0, 3); COPY(0, 4); COPY(0, 5); COPY(0, 6); COPY(0, 7);
+        COPY(2, 1); COPY(3, 1); COPY(4, 1); COPY(5, 1); COPY(6, 1); COPY(7, 1);
+        COPY(1, 4); COPY(4, 4); COPY(1, 6); COPY(6, 6); COPY(1, 7);
+        COPY(0, 0); COPY(1, 1);
+#define RD(L) run<L, 0, 1>(in, out, tiles, lds)
+        RD(0); RD(1); RD(2); RD(3); RD(4); RD(5); RD(6); RD(7);
+#define WR(S) run<0, S, 2>(in, out, tiles, lds)
+        WR(0); WR(1); WR(2); WR(3); WR(4); WR(5); WR(6); WR(7);
+    }
+    return 0;
+}

@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
         __builtin_amdgcn_wave_barrier();
-        store16<(NT & 2) != 0>(dst + b * 2048, s0);
-        store16<(NT & 2) != 0>(dst + b * 2048 + 1024, s1);
+        store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst + b * 2048, s0);
+        store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst + b * 2048 + 1024, s1);
         if (nb >= end) break;
         b = nb;
     }
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
 // algorithmic bytes) instead of 4 + 4 KiB for the two kernels back to back.  After the
 // forward passes the coefficient tile sits in the wave's LDS slot for its line-dense store anyway;
 // the inverse reads its columns from there, as the staged inverse does from a loaded tile.
-template <bool NT>
+template <int NT>
 __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__restrict__ in,
                                                                int16_t *__restrict__ coef_out,
                                                                int16_t *__restrict__ recon_out, size_t n_blocks,
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__
     const char *src = reinterpret_cast<const char *>(in) + lane * 16;
     const size_t lane_off = (size_t)lane * 16;
 
-    v4i g0 = load16<NT>(src + b * 2048), g1 = load16<NT>(src + b * 2048 + 1024);
+    v4i g0 = load16<(NT & 1) != 0>(src + b * 2048), g1 = load16<(NT & 1) != 0>(src + b * 2048 + 1024);
     const LaneConsts kf = load_consts(fwd_ops, lane);
     const LaneConsts ki = load_consts(inv_ops, lane);
     v16i c2r;
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__
         *reinterpret_cast<v4i *>(slot + lin0) = g0;
         *reinterpret_cast<v4i *>(slot + lin1) = g1;
         if (nb < end) {
-            g0 = load16<NT>(src + nb * 2048);
-            g1 = load16<NT>(src + nb * 2048 + 1024);
+            g0 = load16<(NT & 1) != 0>(src + nb * 2048);
+            g1 = load16<(NT & 1) != 0>(src + nb * 2048 + 1024);
         }
         __builtin_amdgcn_wave_barrier();
         v4i o0, o1;
@@ -301,8 +301,8 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__
             const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
             const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
             char *dst = reinterpret_cast<char *>(coef_out) + b * 2048 + lane_off;
-            store16<NT>(dst, s0);
-            store16<NT>(dst + 1024, s1);
+            store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst, s0);
+            store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst + 1024, s1);
         }
         {
             uint32_t w[8];
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__
             const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
             __builtin_amdgcn_wave_barrier();
             char *dst = reinterpret_cast<char *>(recon_out) + b * 2048 + lane_off;
-            store16<NT>(dst, s0);
-            store16<NT>(dst + 1024, s1);
+            store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst, s0);
+            store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst + 1024, s1);
         }
         if (nb >= end) break;
         b = nb;
@@ -372,8 +372,8 @@ __global__ __launch_bounds__(256) void dct32_from_tiles_kernel(const x266_ref_bl
     const v4i s0 = *reinterpret_cast<const v4i *>(slot + lds_slot(lane >> 2, lane & 3));
     const v4i s1 = *reinterpret_cast<const v4i *>(slot + lds_slot(16 + (lane >> 2), lane & 3));
     char *dst = reinterpret_cast<char *>(out) + blk * 2048 + lane * 16;
-    store16<NT>(dst, s0);
-    store16<NT>(dst + 1024, s1);
+    store16m<NT ? 2 : 0>(dst, s0);
+    store16m<NT ? 2 : 0>(dst + 1024, s1);
 }
 
 }  // namespace
@@ -402,7 +402,9 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
     if (cfg.lds_stage && cfg.variant == 0) {                   // line-dense global traffic through a private LDS slot
         const size_t per_wave = cfg.lds_bytes_per_wave < 2048 ? 2048 : (size_t)cfg.lds_bytes_per_wave;
         const size_t lds = waves_per_wg * per_wave + (size_t)cfg.lds_pad_bytes;
-        if (mode == 0 && (cfg.nontemporal & 3) == 1) hipLaunchKernelGGL((dct32_lds_kernel<0, 1>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        if (mode == 0 && (cfg.nontemporal & 11) == 11) hipLaunchKernelGGL((dct32_lds_kernel<0, 11>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
+        else if (mode == 1 && (cfg.nontemporal & 11) == 11) hipLaunchKernelGGL((dct32_lds_kernel<1, 11>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops_lds_inv, bpw);
+        else if (mode == 0 && (cfg.nontemporal & 3) == 1) hipLaunchKernelGGL((dct32_lds_kernel<0, 1>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
         else if (mode == 0 && (cfg.nontemporal & 3) == 2) hipLaunchKernelGGL((dct32_lds_kernel<0, 2>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
         else if (mode == 0 && (cfg.nontemporal & 3) == 3) hipLaunchKernelGGL((dct32_lds_kernel<0, 3>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
         else if (mode == 0) hipLaunchKernelGGL((dct32_lds_kernel<0>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
@@ -427,8 +429,9 @@ hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_
     const size_t wpw = tpb / 64, waves = (n_blocks + bpw - 1) / bpw, wgs = (waves + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
-    if (cfg.nontemporal & 3) hipLaunchKernelGGL((dct32_fwdinv_lds_kernel<true>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
-    else                     hipLaunchKernelGGL((dct32_fwdinv_lds_kernel<false>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
+    if ((cfg.nontemporal & 11) == 11) hipLaunchKernelGGL((dct32_fwdinv_lds_kernel<11>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
+    else if (cfg.nontemporal & 3)     hipLaunchKernelGGL((dct32_fwdinv_lds_kernel<3>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
+    else                              hipLaunchKernelGGL((dct32_fwdinv_lds_kernel<0>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
     return hipGetLastError();
 }
 

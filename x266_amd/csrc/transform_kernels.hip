@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
         __builtin_amdgcn_wave_barrier();
-        if (live0) store16<NT>(reinterpret_cast<char *>(out) + o0, s0);
-        if (live1) store16<NT>(reinterpret_cast<char *>(out) + o1, s1);
+        if (live0) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o0, s0);   // NT: "sc1 nt" (x266_device.hpp)
+        if (live1) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o1, s1);
     }
 }
 
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
         __builtin_amdgcn_wave_barrier();
-        if (live0) store16<NT>(reinterpret_cast<char *>(out) + o0, s0);
-        if (live1) store16<NT>(reinterpret_cast<char *>(out) + o1, s1);
+        if (live0) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o0, s0);   // NT: "sc1 nt" (x266_device.hpp)
+        if (live1) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o1, s1);
     }
 }
 

@@ -30,12 +30,32 @@ __device__ __forceinline__ void store16(void *p, const v4i &v)
     else    *q = v;
 }
 
+// Streaming store with the cache-policy bits that measured best for write-once output on gfx950
+// (profiles/r01_membench_cache_policy.txt: "sc1 nt" copy 6.65 TB/s, "nt" 6.56, default 6.06).  The
+// compiler has no spelling for this combination, hence the instruction itself.  The s_nop covers
+// the gfx9 hazard "VMEM store of more than 64 bits, then a VALU write of its data VGPRs" (one wait
+// state), which the compiler's hazard recognizer cannot see through inline asm -- without it the
+// next address computation may overwrite the first 8 bytes of the data still being read.
+__device__ __forceinline__ void store16_sc1nt(void *p, const v4i &v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v));
+}
+
+// SM: 0 plain, 1 nontemporal, 2 "sc1 nt"
+template <int SM>
+__device__ __forceinline__ void store16m(void *p, const v4i &v)
+{
+    if (SM == 2) store16_sc1nt(p, v);
+    else         store16<SM == 1>(p, v);
+}
+
 struct LaunchCfg {
     int cu_count;        // compute units of the device
     int wgs_per_cu;      // persistent launch: resident workgroups per CU
     int adaptive;        // shrink units_per_wave on small batches so the grid still fills the chip
     int nontemporal;     // bit 0: nontemporal loads, bit 1: nontemporal stores in the line-dense (LDS-staged)
-                         // kernels; bit 2: the same hints in the direct fragment-pattern kernels (harmful there)
+                         // kernels; bit 2: the same hints in the direct fragment-pattern kernels (harmful there);
+                         // bit 3: line-dense stores use "sc1 nt" instead of "nt"
     int variant;         // 0 = streaming launch (grid covers the batch), 1 = persistent grid-stride
     int units_per_wave;  // streaming launch: consecutive units (DCT blocks / 32-block SATD groups) per wave
     int wg_threads;      // workgroup size, multiple of 64

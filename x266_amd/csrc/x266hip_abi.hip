@@ -31,11 +31,11 @@ struct x266hip_ctx {
     int wgs_per_cu_dct = 8;
     int wgs_per_cu_inv = 5;
     int wgs_per_cu_satd = 8;
-    int nontemporal = 3;             // see LaunchCfg: hints on for the line-dense kernels (+1.5-3.5 %), off for fragment loads
+    int nontemporal = 11;            // see LaunchCfg: nt loads + "sc1 nt" stores in the line-dense kernels (+3-5 %), none on fragment loads
     int dct_variant = 0, satd_variant = 0;          // 0 streaming launch, 1 persistent
     // streaming launch: consecutive units per wave (measured optimum on MI355X, profiles/r01_sweep.txt)
     int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 1;
-    int dct_fwdinv_blocks_per_wave = 8;
+    int dct_fwdinv_blocks_per_wave = 4;
     int adaptive_per_wave = 1;
     int wg_threads = 256;
     int satd_wg_threads = 64;                       // SATD batch: one-wave workgroups (profiles/r01_satd_launch_shape.txt)
