@@ -51,8 +51,9 @@ DCT_SEED, SATD_SEED = 0x266, 0x267
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100,
+                    help="untimed launches first; the chip needs ~50 ms of load to reach steady clocks (profiles/r01_clock_warmup.txt)")
     ap.add_argument("--dct-blocks", type=int, default=DCT_BLOCKS_PER_GPU)
     ap.add_argument("--satd-blocks", type=int, default=SATD_BLOCKS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void satd8x8_lds_kernel(const int16_t *__restr
                                                           uint32_t *__restrict__ out, size_t n_blocks,
                                                           unsigned groups_per_wave)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 4096];
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 4 KiB per wave (+ occupancy padding)
     const int lane = threadIdx.x & 63;
     unsigned char *slot = stage + (threadIdx.x >> 6) * 4096;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -313,8 +313,9 @@ hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_block
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs), block(tpb);
     if (cfg.lds_stage && cfg.variant == 0) {
-        if (cfg.nontemporal & 1) hipLaunchKernelGGL((satd8x8_lds_kernel<true>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
-        else                     hipLaunchKernelGGL((satd8x8_lds_kernel<false>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
+        const size_t lds = waves_per_wg * (size_t)(cfg.lds_bytes_per_wave < 4096 ? 4096 : cfg.lds_bytes_per_wave) + (size_t)cfg.lds_pad_bytes;
+        if (cfg.nontemporal & 1) hipLaunchKernelGGL((satd8x8_lds_kernel<true>), grid, block, lds, stream, d_diff, d_out, n_blocks, gpw);
+        else                     hipLaunchKernelGGL((satd8x8_lds_kernel<false>), grid, block, lds, stream, d_diff, d_out, n_blocks, gpw);
         return hipGetLastError();
     }
     if (cfg.nontemporal & 4) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);

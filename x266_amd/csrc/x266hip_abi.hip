@@ -34,11 +34,11 @@ struct x266hip_ctx {
     int nontemporal = 11;            // see LaunchCfg: nt loads + "sc1 nt" stores in the line-dense kernels (+3-5 %), none on fragment loads
     int dct_variant = 0, satd_variant = 0;          // 0 streaming launch, 1 persistent
     // streaming launch: consecutive units per wave (measured optimum on MI355X, profiles/r01_sweep.txt)
-    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 1;
+    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 2;
     int dct_fwdinv_blocks_per_wave = 4;
     int adaptive_per_wave = 1;
     int wg_threads = 256;
-    int satd_wg_threads = 64;                       // SATD batch: one-wave workgroups (profiles/r01_satd_launch_shape.txt)
+    int satd_wg_threads = 128;                      // SATD batch (staged): two-wave workgroups, 2 groups per wave (profiles/r01_satd_staged_nt.txt)
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
     int me_tile_rows = 4;                           // block rows per ME tile (1, 2 or 4)
     int me_row_pairs = 2;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
@@ -48,10 +48,11 @@ struct x266hip_ctx {
     int tr_lds_stage = 1;                           // transform set, contiguous batches: stage tiles through LDS
     int tr_tiles_per_wave = 1;                      // transform set: 32x32 tiles per wave
     int tr32_simple = 0;                            // diagnostic: run DCT-II 32 through the transform-set kernel
-    int satd_lds_stage = 0;                         // measured: no gain for the read-dominated SATD batch (6.2-6.3 TB/s either way)
+    int satd_lds_stage = 1;                         // line-dense nontemporal loads through a 4 KiB LDS slot: +5-10 % over fragment loads (profiles/r01_satd_staged_nt.txt)
     // staged DCT32 launch shape, measured optimum (profiles/r01_wg_occupancy.txt): forward one-wave workgroups
     // capped at 20 resident waves per CU (160 KiB / 8 KiB), 1 block per wave forward, 2 inverse
     int dct_lds_per_wave = 8192, dct_inv_lds_per_wave = 8192;
+    int satd_lds_per_wave = 6144;                   // staged SATD variant: LDS charged per wave (>= 4096)
     int dct_wg_threads = 64, dct_inv_wg_threads = 64;
     int dct_lds_stage = 1;                          // see dct32_kernels.hip: dct32_lds_kernel
     int passthrough = 0;                            // diagnostic, see x266_device.hpp
@@ -96,7 +97,7 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
     c.wg_threads = op == 2 ? ctx->satd_wg_threads : ctx->wg_threads;
     c.passthrough = ctx->passthrough;
     c.lds_stage = op == 2 ? ctx->satd_lds_stage : ctx->dct_lds_stage;
-    c.lds_bytes_per_wave = op == 1 ? ctx->dct_inv_lds_per_wave : ctx->dct_lds_per_wave;
+    c.lds_bytes_per_wave = op == 2 ? ctx->satd_lds_per_wave : (op == 1 ? ctx->dct_inv_lds_per_wave : ctx->dct_lds_per_wave);
     if (op != 2 && ctx->dct_lds_stage && ctx->dct_variant == 0) c.wg_threads = op == 1 ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
     c.lds_pad_bytes = op == 2 ? ctx->lds_pad_satd : (op == 1 ? ctx->lds_pad_inv : ctx->lds_pad_dct);
     return c;
@@ -245,6 +246,7 @@ static int *option_slot(x266hip_ctx *ctx, const char *key)
     if (!std::strcmp(key, "dct32_lds_stage")) return &ctx->dct_lds_stage;
     if (!std::strcmp(key, "dct32_lds_bytes_per_wave")) return &ctx->dct_lds_per_wave;
     if (!std::strcmp(key, "dct32_inv_lds_bytes_per_wave")) return &ctx->dct_inv_lds_per_wave;
+    if (!std::strcmp(key, "satd_lds_bytes_per_wave")) return &ctx->satd_lds_per_wave;
     if (!std::strcmp(key, "dct32_wg_threads")) return &ctx->dct_wg_threads;
     if (!std::strcmp(key, "dct32_inv_wg_threads")) return &ctx->dct_inv_wg_threads;
     if (!std::strcmp(key, "satd_lds_stage")) return &ctx->satd_lds_stage;
