@@ -357,8 +357,9 @@ __global__ __launch_bounds__(256) void dct32_from_tiles_kernel(const x266_ref_bl
     const unsigned c = lane & 31, h = lane >> 5;
     const size_t by = blk / blocks_x, bx = blk - by * blocks_x;
     const size_t tile = (by * 2 + (c >> 4)) * (size_t)tiles_x + bx * 2 + h;
-    const v4i a = *reinterpret_cast<const v4i *>(reinterpret_cast<const unsigned char *>(cur + tile) + (c & 15) * 16);
-    const v4i b = *reinterpret_cast<const v4i *>(reinterpret_cast<const unsigned char *>(pred + tile) + (c & 15) * 16);
+    // each instruction reads the whole 256-byte luma part of four tiles: line-dense, so streaming hints pay
+    const v4i a = load16<NT>(reinterpret_cast<const unsigned char *>(cur + tile) + (c & 15) * 16);
+    const v4i b = load16<NT>(reinterpret_cast<const unsigned char *>(pred + tile) + (c & 15) * 16);
     const LaneConsts k = load_consts(ops, lane);
     const v4i bias = {(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
     const v16i round1 = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};

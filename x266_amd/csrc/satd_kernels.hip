@@ -207,10 +207,12 @@ __global__ __launch_bounds__(256) void satd8x8_lds_kernel(const int16_t *__restr
 // of the signed-offset trick cancels, and negating a +-1 operand byte is an XOR with 0xFE.
 // One wave takes 8 consecutive tiles = 32 blocks (lane n: tile n/4, block n%4 of the tile), so a
 // tile's 256 luma bytes are consumed whole by one wave; costs are stored in raster order of blocks.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void satd8x8_from_tiles_kernel(const x266_ref_block_t *__restrict__ cur,
                                                                  const x266_ref_block_t *__restrict__ pred,
                                                                  uint32_t *__restrict__ out, int tiles_x, size_t n_tiles)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // STAGED: 4 KiB per wave
     const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
     const size_t group = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (group * 8 >= n_tiles) return;
@@ -218,14 +220,40 @@ __global__ __launch_bounds__(256) void satd8x8_from_tiles_kernel(const x266_ref_
     const bool live = tile < n_tiles;
     if (!live) tile = n_tiles - 1;
     const int sub_y = (n >> 1) & 1, sub_x = n & 1;                      // block inside the tile
-    const unsigned off = (unsigned)((sub_y * 8 + 4 * half) * 16 + sub_x * 8);
-    const unsigned char *pa = reinterpret_cast<const unsigned char *>(cur + tile) + off;
-    const unsigned char *pb = reinterpret_cast<const unsigned char *>(pred + tile) + off;
     uint2 a[4], b[4];
+    if (STAGED) {
+        // Line-dense loads: one instruction reads the whole 256-byte luma part of four tiles (16 lanes
+        // x 16 B each), nontemporal; a wave-private LDS slot turns that into block-per-lane order.
+        // Row r of tile t (both 0-based inside the wave's group) lives at t*256 + ((r & 8) | ((r & 7) ^ t))*16:
+        // the b128 writes and the b64 fragment reads are both bank-conflict-free.
+        unsigned char *slot = stage + (threadIdx.x >> 6) * 4096;
+        const int lt = lane >> 4, lr = lane & 15;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        a[r] = *reinterpret_cast<const uint2 *>(pa + r * 16);
-        b[r] = *reinterpret_cast<const uint2 *>(pb + r * 16);
+        for (int k = 0; k < 2; ++k) {
+            size_t t = group * 8 + 4 * k + lt;
+            if (t >= n_tiles) t = n_tiles - 1;                          // ragged tail: stay inside the frame
+            const unsigned dst = (unsigned)((4 * k + lt) * 256 + ((lr & 8) | ((lr & 7) ^ (4 * k + lt))) * 16);
+            *reinterpret_cast<v4i *>(slot + dst) = load16<true>(reinterpret_cast<const unsigned char *>(cur + t) + lr * 16);
+            *reinterpret_cast<v4i *>(slot + 2048 + dst) = load16<true>(reinterpret_cast<const unsigned char *>(pred + t) + lr * 16);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int lt8 = n >> 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = sub_y * 8 + 4 * half + r;
+            const unsigned src = (unsigned)(lt8 * 256 + ((row & 8) | ((row & 7) ^ lt8)) * 16 + sub_x * 8);
+            a[r] = *reinterpret_cast<const uint2 *>(slot + src);
+            b[r] = *reinterpret_cast<const uint2 *>(slot + 2048 + src);
+        }
+    } else {
+        const unsigned off = (unsigned)((sub_y * 8 + 4 * half) * 16 + sub_x * 8);
+        const unsigned char *pa = reinterpret_cast<const unsigned char *>(cur + tile) + off;
+        const unsigned char *pb = reinterpret_cast<const unsigned char *>(pred + tile) + off;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[r] = *reinterpret_cast<const uint2 *>(pa + r * 16);
+            b[r] = *reinterpret_cast<const uint2 *>(pb + r * 16);
+        }
     }
     const SatdOperands H = make_satd_operands(lane);
     const uint32_t S = 0x80808080u;                                     // pixels -> signed (offset cancels)
@@ -324,14 +352,15 @@ hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_block
 }
 
 hipError_t launch_satd8x8_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, uint32_t *d_out,
-                                     int width, int height, hipStream_t stream)
+                                     int width, int height, const LaunchCfg &cfg, hipStream_t stream)
 {
     const int tiles_x = width / 16;
     const size_t n_tiles = (size_t)tiles_x * (size_t)(height / 16);
     if (n_tiles == 0) return hipSuccess;
     const size_t groups = (n_tiles + 7) / 8;                            // one wave per 8 tiles, one-wave workgroups
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(satd8x8_from_tiles_kernel, dim3((unsigned)groups), dim3(64), 0, stream, d_cur, d_pred, d_out, tiles_x, n_tiles);
+    if (cfg.lds_stage) hipLaunchKernelGGL((satd8x8_from_tiles_kernel<true>), dim3((unsigned)groups), dim3(64), (size_t)(cfg.lds_bytes_per_wave < 4096 ? 4096 : cfg.lds_bytes_per_wave), stream, d_cur, d_pred, d_out, tiles_x, n_tiles);
+    else               hipLaunchKernelGGL((satd8x8_from_tiles_kernel<false>), dim3((unsigned)groups), dim3(64), 0, stream, d_cur, d_pred, d_out, tiles_x, n_tiles);
     return hipGetLastError();
 }
 
