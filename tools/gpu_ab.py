@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Developer probe: same-box, same-process A/B of two builds of libx266hip.so (GPU box).
+A = tools/_ab/libx266hip_ref.so (tools/ab_build.sh <git-ref>), B = the working tree's library.
+Alternates the two so that clock state and box are shared."""
+import ctypes, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = ctypes.c_void_p
+def load(path):
+    L = ctypes.CDLL(path)
+    ctx = P()
+    assert L.xHipCodecInit(ctypes.byref(ctx), 0) == 0
+    L.xHipMalloc.argtypes = [P, ctypes.POINTER(P), ctypes.c_size_t]
+    L.xFillResidualDev.argtypes = [P, P, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint64, P]
+    L.xHipTimeKernel.argtypes = [P, ctypes.c_int, P, P, ctypes.c_size_t, ctypes.c_int, P, ctypes.POINTER(ctypes.c_double)]
+    L.xHipStreamSync.argtypes = [P, P]
+    return L, ctx
+libs = [("ref", load(os.path.join(ROOT, "tools", "_ab", "libx266hip_ref.so"))), ("new", load(os.path.join(ROOT, "x266_amd", "libx266hip.so")))]
+N = 1 << 20
+L0, c0 = libs[0][1]
+din, dout = P(), P()
+assert L0.xHipMalloc(c0, ctypes.byref(din), N * 2048) == 0 and L0.xHipMalloc(c0, ctypes.byref(dout), N * 2048) == 0
+L0.xFillResidualDev(c0, din, N * 1024, 0x266, 0, None); L0.xHipStreamSync(c0, None)
+def t(L, ctx, op, n, reps=20):
+    ms = ctypes.c_double()
+    assert L.xHipTimeKernel(ctx, op, din, dout, n, reps, None, ctypes.byref(ms)) == 0
+    return ms.value
+t(L0, c0, 0, N, 150)                                      # warm the clocks
+for op, name, n, unit in ((0, "fwd", N, 4096), (1, "inv", N, 4096), (2, "satd", 1 << 24, 132)):
+    best = {"ref": 1e9, "new": 1e9}
+    for rnd in range(6):
+        for tag, (L, ctx) in libs:
+            best[tag] = min(best[tag], t(L, ctx, op, n))
+    print("%-4s ref %.4f ms %.3f TB/s | new %.4f ms %.3f TB/s | new/ref time %.4f" % (
+        name, best["ref"], n * unit / best["ref"] / 1e9, best["new"], n * unit / best["new"] / 1e9, best["new"] / best["ref"]), flush=True)
