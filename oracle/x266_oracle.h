@@ -75,6 +75,15 @@ void orc_conv_output_420(const uint8_t *tiles, uint8_t *y, ptrdiff_t strd_y, uin
 void orc_residual_luma(const uint8_t *cur_tiles, const uint8_t *pred_tiles, int width, int height, int edge,
                        int16_t *res);
 
+/* ---- 32x32 intra prediction (src/mkIntra32-wip.bsv is a WIP sketch) ---- UNPINNED */
+/* HEVC 35-mode scheme, nTbS = 32 (H.265 8.4.4.2.4-6): mode 0 planar, 1 DC, 2..34 angular, references
+ * used as given.  left[y] = p[-1][y]; top[0] = corner, top[1+x] = p[x][-1] (IntraRef_t, :36-39). */
+int orc_intra_angle(int mode);
+int orc_intra_inv_angle(int mode);
+int orc_intra32_predict(const uint8_t left[64], const uint8_t top[65], int mode, uint8_t pred[1024]);
+int orc_intra32_predict_batch(const uint8_t *refs /* n_refs x 129 */, const uint8_t *modes, const uint32_t *ref_index /* or NULL */,
+                              uint8_t *pred /* n x 1024 */, size_t n);
+
 /* ---- BDPI word packing (src_tb/dct32.c:205-246, satd.c:143-147) ---- PINNED */
 void     orc_pack_diff_rows(const int16_t *mat, int first_row, uint32_t res[32]);
 uint64_t orc_pack_dct_word(const int16_t *dct, int idx);

@@ -110,6 +110,17 @@ class Oracle:
         assert self.lib.orc_transform_inv(ttype, n, _P(x.ctypes.data), _P(out.ctypes.data), _SZ(x.shape[0])) == 0
         return out
 
+    def intra32_predict(self, refs, modes, ref_index=None):
+        """refs [n_refs,129] uint8 (left[64] | top[65]); modes [n]; ref_index [n] or None -> [n,1024] uint8."""
+        refs = np.ascontiguousarray(refs, np.uint8).reshape(-1, 129)
+        modes = np.ascontiguousarray(modes, np.uint8)
+        ri = None if ref_index is None else np.ascontiguousarray(ref_index, np.uint32)
+        out = np.empty((modes.shape[0], 1024), np.uint8)
+        rc = self.lib.orc_intra32_predict_batch(_P(refs.ctypes.data), _P(modes.ctypes.data), _P(ri.ctypes.data if ri is not None else None),
+                                                _P(out.ctypes.data), _SZ(modes.shape[0]))
+        assert rc == 0
+        return out
+
     def satd_search(self, cur, ref_padded, pad, rng, threads=1, want_costs=False):
         """cur [H,W] uint8; ref_padded [H+2*pad, W+2*pad] uint8 with pad >= rng."""
         cur = np.ascontiguousarray(cur, np.uint8)
@@ -289,3 +300,24 @@ def satd_edge_blocks():
         add("impulse_%d" % pos, imp)
     add("asymmetric", (np.arange(64) % 8) * 5 - (np.arange(64) // 8) * 11)
     return np.stack(blocks), names
+
+
+def intra_refs_np(n, seed):
+    """n reference sets (left[64] | top[65]): smooth ramps + noise, plus the WIP testbench's stimulus
+    (src/mkIntra32-wip.bsv:539-543: left[i] = -(i+1), top[i] = i) as set 0 and flat / extreme sets."""
+    r = splitmix64(seed, 0, n * 129)
+    base = ((r >> np.uint64(17)) & np.uint64(0xFF)).astype(np.int64).reshape(n, 129)
+    ramp = np.linspace(0, 255, 129)[None, :] * (((r.reshape(n, 129)[:, :1] >> np.uint64(40)) & np.uint64(3)).astype(np.int64) / 3.0)
+    refs = np.clip(0.35 * base + 0.65 * ramp, 0, 255).astype(np.uint8)
+    if n > 0:
+        refs[0, :64] = (256 - (np.arange(64) + 1)) & 0xFF
+        refs[0, 64:] = np.arange(65)
+    if n > 1:
+        refs[1] = 255
+    if n > 2:
+        refs[2] = 0
+    if n > 3:
+        refs[3] = np.where(np.arange(129) % 2 == 0, 255, 0)
+    if n > 4:
+        refs[4] = base[4].astype(np.uint8)                 # pure noise
+    return refs
