@@ -174,6 +174,19 @@ int xSatd8x8FromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const 
  * riscv/programs/benchmarks/sad/sad.c:28-39 (whose 64 x 64 known answer 344807 the tests replay). */
 int xSadBatchDev(x266hip_ctx *ctx, int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out,
                  size_t n_blocks, void *stream);
+/* 32x32 intra prediction.  Upstream has only a work-in-progress RTL sketch of this
+ * stage (src/mkIntra32-wip.bsv; no C model, so parity is UNPINNED): the HEVC 35-mode predictor
+ * (H.265 8.4.4.2.4-6, nTbS = 32) -- mode 0 planar, 1 DC, 2..34 angular -- on references used as
+ * given.  x266_intra_ref_t mirrors IntraRef_t (:36-39): left[y] = p[-1][y], top[0] = the corner
+ * sample, top[1+x] = p[x][-1]; padded to 144 bytes so that sets are 16-byte aligned.
+ * Output block i (1024 bytes, row-major) = mode d_modes[i] on set d_ref_index[i] (NULL: set i). */
+typedef struct x266_intra_ref_t {
+    uint8_t left[64];
+    uint8_t top[65];
+    uint8_t reserved[15];
+} x266_intra_ref_t;
+int xIntra32PredictDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const uint8_t *d_modes,
+                       const uint32_t *d_ref_index, uint8_t *d_pred, size_t n, void *stream);
 /* Synthetic residual stream with the reference's stimulus distribution
  * ((rand()&0xFF)-(rand()&0xFF), src_tb/dct32.c:191-193) from a counter-based
  * SplitMix64: sample i = lo8(r) - lo8(r>>8), r = mix(seed+(first_index+i+1)*phi). */

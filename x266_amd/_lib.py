@@ -57,6 +57,7 @@ def load_library():
         getattr(L, name).argtypes = [_P, _P, _P, _SZ, _P]
     L.xDct32FwdInvBatchDev.argtypes = [_P, _P, _P, _P, _SZ, _P]
     L.xFillResidualDev.argtypes = [_P, _P, _SZ, _U64, _U64, _P]
+    L.xIntra32PredictDev.argtypes = [_P, _P, _P, _P, _P, _SZ, _P]
     L.xTransformFwdBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
     L.xConvInputFmtDev.argtypes = [_P, _P, _P, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
     L.xConvOutput420Dev.argtypes = [_P, _P, _P, ctypes.c_ssize_t, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
@@ -206,6 +207,27 @@ class Codec:
 
     def dct32_fwd_inv_dev(self, d_in, d_coef, d_recon, n_blocks, stream=0):
         self._check(self.L.xDct32FwdInvBatchDev(self.ctx, d_in, d_coef or None, d_recon, n_blocks, stream), "xDct32FwdInvBatchDev")
+
+    def intra32_predict_dev(self, d_refs, d_modes, d_ref_index, d_pred, n, stream=0):
+        self._check(self.L.xIntra32PredictDev(self.ctx, d_refs, d_modes, d_ref_index or None, d_pred, n, stream), "xIntra32PredictDev")
+
+    def intra32_predict(self, refs, modes, ref_index=None):
+        """Host convenience: refs [n_refs,129] uint8 (left | top) -> predictions [n,1024] uint8."""
+        refs = np.ascontiguousarray(refs, np.uint8).reshape(-1, 129)
+        modes = np.ascontiguousarray(modes, np.uint8)
+        n = modes.shape[0]
+        padded = np.zeros((refs.shape[0], 144), np.uint8)
+        padded[:, :129] = refs
+        d_r, d_m, d_p = self.alloc(max(padded.nbytes, 16)), self.alloc(max(n, 16)), self.alloc(max(n * 1024, 16))
+        d_r.upload(padded)
+        d_m.upload(modes)
+        d_i = None
+        if ref_index is not None:
+            d_i = self.alloc(max(4 * n, 16))
+            d_i.upload(np.ascontiguousarray(ref_index, np.uint32))
+        self.intra32_predict_dev(d_r.ptr, d_m.ptr, d_i.ptr if d_i else 0, d_p.ptr, n)
+        self.stream_sync()
+        return d_p.download(np.uint8, n * 1024).reshape(n, 1024)
 
     def satd8x8_dev(self, d_in, d_out, n_blocks, stream=0):
         self._check(self.L.xSatd8x8BatchDev(self.ctx, d_in, d_out, n_blocks, stream), "xSatd8x8BatchDev")

@@ -1,0 +1,207 @@
+// intra_kernels.hip -- 32x32 intra prediction, gfx950.
+//
+// The HEVC 35-mode predictor the reference's WIP RTL sketch tabulates (src/mkIntra32-wip.bsv:
+// IntraRef_t :36-39, iIdx / iFact tables :75-112, projected side references :150-316, two-tap
+// interpolation :358-361, DC :380-384) -- H.265 8.4.4.2.4-6 at nTbS = 32: mode 0 planar, 1 DC,
+// 2..34 angular, references used as given.  PARITY UNPINNED upstream (no C model); bit-exact with
+// this repository's oracle.
+//
+// One wave per predicted block (reference set r, mode m): 144 bytes in, 1 KiB out -- a write-bound
+// byte kernel.  The wave builds the extended reference array ref[-32 .. 65] in a private LDS slot
+// (main side as it lies, negative positions projected from the other side with invAngle); lane
+// (k = l >> 1, h = l & 1) then interpolates 16 consecutive samples of line k: its two taps are
+// adjacent bytes of ref[], so one v_dot4_u32_u8 per sample against the weights (32 - f, f) with
+// the rounding term as the accumulator.  The vertical family (modes 18..34) produces rows and is
+// stored directly; the horizontal family (2..17) produces columns and is turned through a 1 KiB
+// LDS tile.  Stores are 1 KiB-linear, "sc1 nt" (x266_device.hpp).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "x266_device.hpp"
+
+namespace x266 {
+namespace {
+
+// intraPredAngle (H.265 Table 8-4) and |invAngle| (Table 8-5) from the mode, in scalar code: the
+// mode is wave-uniform, so these are a handful of SALU selects instead of dependent memory reads.
+__device__ __forceinline__ int angle_magnitude(int j)      // j = distance from the pure horizontal / vertical mode, 0..8
+{
+    const uint32_t lo = 0x09050200u, hi = 0x1A15110Du;      // 0,2,5,9 | 13,17,21,26
+    return j >= 8 ? 32 : (int)(((j & 4) ? hi : lo) >> (8 * (j & 3))) & 0xFF;
+}
+__device__ __forceinline__ int intra_angle(int mode)
+{
+    const int pure = mode < 18 ? 10 : 26;
+    const int j = mode - pure, m = angle_magnitude(j < 0 ? -j : j);
+    return (mode < 18) == (j < 0) ? m : -m;                 // horizontal family: positive below 10; vertical: positive above 26
+}
+__device__ __forceinline__ int intra_inv_angle_magnitude(int j)   // j = 1..8
+{
+    const int t[8] = {4096, 1638, 910, 630, 482, 390, 315, 256};
+    int v = t[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) v = (j == i + 1) ? t[i] : v;
+    return v;
+}
+
+constexpr int kUnits = 4;           // predictions per wave: one round trip fetches all four reference sets
+constexpr int kRawBytes = 144;      // x266_intra_ref_t
+constexpr int kExtBytes = 128;      // ref[-32 .. 95]: negative-angle modes only
+constexpr int kSlotBytes = 16 + kUnits * kRawBytes + kExtBytes + 1024;
+
+// 16 samples of one line: taps are the 17 bytes from `p` on (any alignment), weights (32 - f, f).
+// Packed 16-bit arithmetic, two samples per instruction: even samples (32-f)*B[2i] + f*B[2i+1],
+// odd samples (32-f)*B[2i+1] + f*B[2i+2].
+__device__ __forceinline__ void interpolate16(const unsigned char *p, uint32_t f, uint32_t (&px)[4])
+{
+    typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+    const int o = (int)((uintptr_t)p & 3);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p - o);
+    uint32_t d[6], a[5];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = q[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) a[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], (uint32_t)(8 * o));   // bytes p[4i .. 4i+3]
+    const uint32_t w0 = (32u - f) * 0x00010001u, w1 = f * 0x00010001u;
+    const v2u W0 = __builtin_bit_cast(v2u, w0), W1 = __builtin_bit_cast(v2u, w1), R = {16, 16}, S = {5, 5};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const v2u t0 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a[g], 0x0c020c00u));            // B0, B2
+        const v2u t1 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a[g], 0x0c030c01u));            // B1, B3
+        const v2u t2 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(a[g + 1], a[g], 0x0c040c02u));      // B2, B4
+        const v2u e = (t0 * W0 + R + t1 * W1) >> S;          // samples 0, 2
+        const v2u od = (t1 * W0 + R + t2 * W1) >> S;         // samples 1, 3
+        px[g] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, od), __builtin_bit_cast(uint32_t, e), 0x06020400u);   // e0 o0 e1 o1
+    }
+}
+
+__global__ __launch_bounds__(256) void intra32_predict_kernel(const x266_intra_ref_t *__restrict__ refs,
+                                                              const uint8_t *__restrict__ modes,
+                                                              const uint32_t *__restrict__ ref_index,
+                                                              uint8_t *__restrict__ pred, size_t n)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kSlotBytes];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t unit0 = ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_wg) * kUnits;
+    if (unit0 >= n) return;
+    unsigned char *slot = lds + wave_in_wg * kSlotBytes;
+    unsigned char *raw_all = slot + 16;                     // set j at raw_all + 144 j: left[64] | top[65]; byte raw-1 = corner copy
+    unsigned char *ext = raw_all + kUnits * kRawBytes;      // ext[e] = ref[e - 32]
+    unsigned char *tile = ext + kExtBytes;
+
+    // one round trip: modes and set indices of the wave's units, then all reference sets at once
+    const int ju = lane < kUnits ? lane : kUnits - 1;
+    size_t u = unit0 + ju;
+    if (u >= n) u = n - 1;
+    const int my_mode = modes[u];
+    const uint32_t my_ref = ref_index ? ref_index[u] : (uint32_t)u;
+    {
+        const int set = lane / 9, piece = lane - 9 * set;   // lanes 0..35 fetch 4 x 9 pieces of 16 bytes
+        const uint32_t r = (uint32_t)__shfl((int)my_ref, set < kUnits ? set : 0);
+        if (lane < 9 * kUnits)
+            *reinterpret_cast<v4i *>(raw_all + lane * 16) = load16<true>(reinterpret_cast<const unsigned char *>(refs + r) + piece * 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int k = lane >> 1, h = lane & 1;                  // line k, samples 16h .. 16h+15 of it
+#pragma unroll 1
+    for (int j = 0; j < kUnits; ++j) {
+        const size_t unit = unit0 + j;
+        if (unit >= n) break;
+        const int mode = __builtin_amdgcn_readlane(my_mode, j);
+        const unsigned char *left = raw_all + j * kRawBytes, *top = left + 64;   // top[0] = corner
+        uint32_t px[4];
+        if (mode >= 2) {
+            const int angle = intra_angle(mode);
+            const bool vertical = mode >= 18;
+            const int t = (k + 1) * angle;
+            const int idx = t >> 5;
+            const uint32_t f = (uint32_t)(t & 31);
+            const unsigned char *line;                      // line[x] = ref[x]
+            if (angle >= 0) {
+                // ref[x] = p[-1+x][-1] is the top array as it lies; ref[1+i] = p[-1][i] is the left array
+                // (ref[0] is never a tap when the angle is not negative)
+                line = vertical ? top : left - 1;
+            } else {
+                // negative angles: the other side's samples, projected with invAngle, sit in front of
+                // ref[0].  Build ref[-32 .. 64] in ext (two positions per lane).
+                const int inv = intra_inv_angle_magnitude(vertical ? 26 - mode : mode - 10);
+                const int last = angle;                     // (32 * angle) >> 5
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int e = lane + 64 * rep, x = e - 32;
+                    unsigned v = 0;
+                    if (x >= 0) {
+                        if (x <= 64) v = vertical ? top[x] : (x == 0 ? top[0] : left[x - 1]);
+                    } else if (last < -1 && x >= last) {
+                        const int s = -1 + ((-x * inv + 128) >> 8);          // x * invAngle, invAngle = -inv
+                        v = vertical ? left[s] : top[1 + s];
+                    }
+                    ext[e] = (unsigned char)v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                line = ext + 32;
+            }
+            interpolate16(line + 16 * h + idx + 1, f, px);
+            if (!vertical) {                                // lane holds column k, rows 16h..: turn through the tile
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) tile[(16 * h + 4 * g + jj) * 32 + k] = (unsigned char)(px[g] >> (8 * jj));
+                __builtin_amdgcn_wave_barrier();
+                const v4i row = *reinterpret_cast<const v4i *>(tile + lane * 16);
+                px[0] = (uint32_t)row[0]; px[1] = (uint32_t)row[1]; px[2] = (uint32_t)row[2]; px[3] = (uint32_t)row[3];
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (mode == 1) {                             // DC: 32 top + 32 left samples
+            uint32_t s = lane < 32 ? (uint32_t)top[1 + lane] + (uint32_t)left[lane] : 0u;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) s += (uint32_t)__shfl_xor((int)s, m);
+            const uint32_t dc = (s + 32u) >> 6;
+            px[0] = px[1] = px[2] = px[3] = dc * 0x01010101u;
+        } else {
+            // planar, row y = k, columns 16h..: ((31-x) L + (x+1) TR + (31-y) T[x] + (y+1) BL + 32) >> 6
+            //   = (C + x (TR - L) + (31-y) T[x]) >> 6,  C = 31 L + TR + (y+1) BL + 32: a per-lane ramp plus one
+            // multiply per sample, in packed 16-bit lanes (all partial sums stay below 2^16 modulo wraparound).
+            typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+            const int tr = top[33], bl = left[32], y = k, lv = left[y];
+            const int D = tr - lv, x0 = 16 * h;
+            const int c0 = 31 * lv + tr + (y + 1) * bl + 32 + x0 * D;
+            v2u re = {(unsigned short)c0, (unsigned short)(c0 + 2 * D)}, ro = {(unsigned short)(c0 + D), (unsigned short)(c0 + 3 * D)};
+            const v2u inc = {(unsigned short)(4 * D), (unsigned short)(4 * D)}, S = {6, 6};
+            const unsigned short wy = (unsigned short)(31 - y);
+            const v2u W = {wy, wy};
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(top + x0);       // top[1 + x0 ..]: one byte past a dword boundary
+            uint32_t d[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) d[i] = q[i];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t a = __builtin_amdgcn_alignbit(d[g + 1], d[g], 8u);
+                const v2u t0 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a, 0x0c020c00u));
+                const v2u t1 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a, 0x0c030c01u));
+                const v2u e = (t0 * W + re) >> S, od = (t1 * W + ro) >> S;
+                px[g] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, od), __builtin_bit_cast(uint32_t, e), 0x06020400u);
+                re += inc;
+                ro += inc;
+            }
+        }
+        store16_sc1nt(pred + unit * 1024 + lane * 16, v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]});
+    }
+}
+
+}  // namespace
+
+hipError_t launch_intra32_predict(const x266_intra_ref_t *d_refs, const uint8_t *d_modes, const uint32_t *d_ref_index,
+                                  uint8_t *d_pred, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const size_t waves = (n + kUnits - 1) / kUnits, wgs = (waves + 3) / 4;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(intra32_predict_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, d_refs, d_modes, d_ref_index, d_pred, n);
+    return hipGetLastError();
+}
+
+}  // namespace x266

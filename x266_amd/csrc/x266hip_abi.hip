@@ -323,6 +323,18 @@ int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out, s
     return launch_op(ctx, 2, d_diff, d_out, n, (hipStream_t)stream);
 }
 
+int xIntra32PredictDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const uint8_t *d_modes,
+                       const uint32_t *d_ref_index, uint8_t *d_pred, size_t n, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (n && (!d_refs || !d_modes || !d_pred || (((uintptr_t)d_refs | (uintptr_t)d_pred) & 15u) || ((uintptr_t)d_ref_index & 3u)))
+        return fail(ctx, X266HIP_EINVAL, "xIntra32PredictDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_intra32_predict(d_refs, d_modes, d_ref_index, d_pred, n, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "intra launch", e);
+    return X266HIP_OK;
+}
+
 int xFillResidualDev(x266hip_ctx *ctx, int16_t *d_dst, size_t n_samples, uint64_t seed, uint64_t first_index,
                      void *stream)
 {
