@@ -187,6 +187,13 @@ typedef struct x266_intra_ref_t {
 } x266_intra_ref_t;
 int xIntra32PredictDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const uint8_t *d_modes,
                        const uint32_t *d_ref_index, uint8_t *d_pred, size_t n, void *stream);
+/* Intra mode decision (the sketch's "Decide" channel, IntraChannel_t :41-44): for block b with reference
+ * set d_refs[b] and source samples d_src[b*1024 ..] (row-major 32x32, 16-byte aligned),
+ * d_costs[b*35 + m] = sum over the sixteen 8x8 sub-blocks of satd8x8(src - prediction m)
+ * (satd8x8 = src_tb/satd.c:31-118), m = 0..34; d_best_mode[b] (may be NULL) = the cheapest mode,
+ * lowest index on ties.  The predictions are never written to memory. */
+int xIntra32CostsDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const uint8_t *d_src,
+                     uint32_t *d_costs, uint8_t *d_best_mode, size_t n_blocks, void *stream);
 /* Synthetic residual stream with the reference's stimulus distribution
  * ((rand()&0xFF)-(rand()&0xFF), src_tb/dct32.c:191-193) from a counter-based
  * SplitMix64: sample i = lo8(r) - lo8(r>>8), r = mix(seed+(first_index+i+1)*phi). */

@@ -93,3 +93,36 @@ int orc_intra32_predict_batch(const uint8_t *refs, const uint8_t *modes, const u
     }
     return 0;
 }
+
+/* Mode decision (the RTL sketch's "Decide" channel, IntraChannel_t :41-44): for every block the
+ * SATD cost of each of the 35 predictions against the source block, cost = sum over the sixteen
+ * 8x8 sub-blocks of satd8x8(src - pred) (src_tb/satd.c:31-118 per sub-block).  costs[b*35 + mode];
+ * best_mode[b] = the cheapest mode, lowest index on ties (may be NULL). */
+int orc_intra32_costs(const uint8_t *refs /* n x 129 */, const uint8_t *src /* n x 1024 */, size_t n,
+                      uint32_t *costs, uint8_t *best_mode)
+{
+    uint8_t pred[1024];
+    int16_t diff[64];
+    for (size_t b = 0; b < n; ++b) {
+        const uint8_t *r = refs + b * 129, *s = src + b * 1024;
+        uint32_t best = 0xFFFFFFFFu;
+        int best_m = 0;
+        for (int m = 0; m < 35; ++m) {
+            if (orc_intra32_predict(r, r + 64, m, pred)) return -1;
+            uint32_t c = 0;
+            for (int sy = 0; sy < 4; ++sy)
+                for (int sx = 0; sx < 4; ++sx) {
+                    for (int y = 0; y < 8; ++y)
+                        for (int x = 0; x < 8; ++x) {
+                            const int o = (8 * sy + y) * 32 + 8 * sx + x;
+                            diff[y * 8 + x] = (int16_t)((int)s[o] - (int)pred[o]);
+                        }
+                    c += orc_satd8x8(diff);
+                }
+            costs[b * 35 + m] = c;
+            if (c < best) { best = c; best_m = m; }
+        }
+        if (best_mode) best_mode[b] = (uint8_t)best_m;
+    }
+    return 0;
+}

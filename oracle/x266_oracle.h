@@ -84,6 +84,10 @@ int orc_intra32_predict(const uint8_t left[64], const uint8_t top[65], int mode,
 int orc_intra32_predict_batch(const uint8_t *refs /* n_refs x 129 */, const uint8_t *modes, const uint32_t *ref_index /* or NULL */,
                               uint8_t *pred /* n x 1024 */, size_t n);
 
+/* mode decision: costs[b*35 + m] = sum of satd8x8 over the 16 sub-blocks of (src - prediction m) */
+int orc_intra32_costs(const uint8_t *refs /* n x 129 */, const uint8_t *src /* n x 1024 */, size_t n,
+                      uint32_t *costs /* n x 35 */, uint8_t *best_mode /* n or NULL */);
+
 /* ---- BDPI word packing (src_tb/dct32.c:205-246, satd.c:143-147) ---- PINNED */
 void     orc_pack_diff_rows(const int16_t *mat, int first_row, uint32_t res[32]);
 uint64_t orc_pack_dct_word(const int16_t *dct, int idx);

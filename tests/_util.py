@@ -121,6 +121,16 @@ class Oracle:
         assert rc == 0
         return out
 
+    def intra32_costs(self, refs, src):
+        """refs [n,129], src [n,1024] uint8 -> (costs [n,35] uint32, best_mode [n] uint8)."""
+        refs = np.ascontiguousarray(refs, np.uint8).reshape(-1, 129)
+        src = np.ascontiguousarray(src, np.uint8).reshape(-1, 1024)
+        n = refs.shape[0]
+        costs = np.empty((n, 35), np.uint32)
+        best = np.empty(n, np.uint8)
+        assert self.lib.orc_intra32_costs(_P(refs.ctypes.data), _P(src.ctypes.data), _SZ(n), _P(costs.ctypes.data), _P(best.ctypes.data)) == 0
+        return costs, best
+
     def satd_search(self, cur, ref_padded, pad, rng, threads=1, want_costs=False):
         """cur [H,W] uint8; ref_padded [H+2*pad, W+2*pad] uint8 with pad >= rng."""
         cur = np.ascontiguousarray(cur, np.uint8)

@@ -54,3 +54,53 @@ def test_large_batch_all_modes(codec, oracle):
     want = oracle.intra32_predict(refs, modes, idx)
     assert int(got.astype(np.uint64).sum()) == int(want.astype(np.uint64).sum())
     assert np.array_equal(got, want)
+
+
+def _sources(oracle, refs, seed):
+    """Source blocks that make the decision non-trivial: each is one mode's prediction plus noise."""
+    n = refs.shape[0]
+    modes = ((np.arange(n) * 11 + seed) % 35).astype(np.uint8)
+    clean = oracle.intra32_predict(refs, modes).astype(np.int64)
+    from _util import splitmix64
+    noise = ((splitmix64(seed, 0, n * 1024) >> np.uint64(21)) & np.uint64(15)).astype(np.int64).reshape(n, 1024) - 7
+    return np.clip(clean + noise, 0, 255).astype(np.uint8), modes
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 37, 300])
+def test_mode_decision_costs_and_winner(codec, oracle, n):
+    refs = intra_refs_np(max(n, 5), 1000 + n)[:n]
+    src, planted = _sources(oracle, refs, 3 + n)
+    costs, best = codec.intra32_costs(refs, src)
+    ocosts, obest = oracle.intra32_costs(refs, src)
+    assert np.array_equal(costs, ocosts)                     # every mode of every block
+    assert np.array_equal(best, obest)                       # same winner, same tie-break
+    smooth = np.arange(n) >= 5                                # sets 0..4 are the flat / extreme / noise borders
+    if smooth.any():
+        assert np.mean(best[smooth] == planted[smooth]) > 0.5
+
+
+def test_mode_decision_extremes_and_ties(codec, oracle):
+    refs = intra_refs_np(5, 31)
+    src = np.zeros((5, 1024), np.uint8)
+    src[1] = 255                                              # flat border 255 + flat source 255: all costs 0, mode 0 wins
+    src[3] = np.where((np.arange(1024) // 32 + np.arange(1024) % 32) % 2 == 0, 255, 0)
+    src[4] = np.arange(1024) % 251
+    costs, best = codec.intra32_costs(refs, src)
+    ocosts, obest = oracle.intra32_costs(refs, src)
+    assert np.array_equal(costs, ocosts) and np.array_equal(best, obest)
+    assert np.all(costs[1] == 0) and best[1] == 0
+    assert costs.max() < (1 << 26)                            # the (cost << 6 | mode) key cannot overflow
+
+
+def test_mode_decision_is_prediction_plus_satd(codec, oracle):
+    """Composition check against the two GPU kernels it fuses: predictions, residual sub-blocks, xSatd8x8BatchDev."""
+    refs = intra_refs_np(9, 77)
+    src, _ = _sources(oracle, refs, 5)
+    costs, _ = codec.intra32_costs(refs, src)
+    modes = np.tile(np.arange(35, dtype=np.uint8), 9)
+    idx = np.repeat(np.arange(9, dtype=np.uint32), 35)
+    pred = codec.intra32_predict(refs, modes, idx).reshape(9, 35, 32, 32).astype(np.int16)
+    diff = src.reshape(9, 1, 32, 32).astype(np.int16) - pred
+    sub = diff.reshape(9, 35, 4, 8, 4, 8).transpose(0, 1, 2, 4, 3, 5).reshape(-1, 64)
+    sat = codec.satd8x8(sub).reshape(9, 35, 16).sum(axis=2)
+    assert np.array_equal(costs, sat.astype(np.uint32))

@@ -26,3 +26,19 @@ allm = np.tile(np.arange(35), nref); idx = np.repeat(np.arange(nref), 35)
 run(allm, idx, "all 35 modes per border")
 for m, name in ((0, "planar"), (1, "DC"), (26, "vertical 26"), (10, "horizontal 10"), (34, "angular 34"), (2, "angular 2"), (21, "angular 21 (neg, vert)"), (15, "angular 15 (neg, horiz)")):
     run(np.full(n, m), idx, name)
+
+# ---- mode decision: all 35 modes of every block, costs only
+nb = 1 << 17
+refs2 = np.zeros((nb, 144), np.uint8); refs2[:, :129] = intra_refs_np(nb, 2)
+src = (np.arange(nb * 1024, dtype=np.uint32) * 2654435761 >> 24).astype(np.uint8)
+d_r2 = cd.alloc(refs2.nbytes); d_r2.upload(refs2)
+d_s = cd.alloc(nb * 1024); d_s.upload(src)
+d_c = cd.alloc(nb * 35 * 4); d_b = cd.alloc(nb)
+for _ in range(10): cd.intra32_costs_dev(d_r2.ptr, d_s.ptr, d_c.ptr, d_b.ptr, nb)
+cd.stream_sync(); best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter()
+    for _ in range(10): cd.intra32_costs_dev(d_r2.ptr, d_s.ptr, d_c.ptr, d_b.ptr, nb)
+    cd.stream_sync(); best = min(best, (time.perf_counter() - t0) / 10)
+print("mode decision (35 modes x 16 SATD): %.3f ms per %d blocks  %.3e blocks/s  %.3e mode evaluations/s  %.3e 8x8 SATD/s" % (
+    best * 1e3, nb, nb / best, nb * 35 / best, nb * 35 * 16 / best), flush=True)

@@ -58,6 +58,7 @@ def load_library():
     L.xDct32FwdInvBatchDev.argtypes = [_P, _P, _P, _P, _SZ, _P]
     L.xFillResidualDev.argtypes = [_P, _P, _SZ, _U64, _U64, _P]
     L.xIntra32PredictDev.argtypes = [_P, _P, _P, _P, _P, _SZ, _P]
+    L.xIntra32CostsDev.argtypes = [_P, _P, _P, _P, _P, _SZ, _P]
     L.xTransformFwdBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
     L.xConvInputFmtDev.argtypes = [_P, _P, _P, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
     L.xConvOutput420Dev.argtypes = [_P, _P, _P, ctypes.c_ssize_t, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
@@ -228,6 +229,24 @@ class Codec:
         self.intra32_predict_dev(d_r.ptr, d_m.ptr, d_i.ptr if d_i else 0, d_p.ptr, n)
         self.stream_sync()
         return d_p.download(np.uint8, n * 1024).reshape(n, 1024)
+
+    def intra32_costs_dev(self, d_refs, d_src, d_costs, d_best_mode, n, stream=0):
+        self._check(self.L.xIntra32CostsDev(self.ctx, d_refs, d_src, d_costs, d_best_mode or None, n, stream), "xIntra32CostsDev")
+
+    def intra32_costs(self, refs, src):
+        """Host convenience: refs [n,129], src [n,1024] uint8 -> (costs [n,35] uint32, best_mode [n] uint8)."""
+        refs = np.ascontiguousarray(refs, np.uint8).reshape(-1, 129)
+        src = np.ascontiguousarray(src, np.uint8).reshape(-1, 1024)
+        n = refs.shape[0]
+        padded = np.zeros((n, 144), np.uint8)
+        padded[:, :129] = refs
+        d_r, d_s = self.alloc(max(padded.nbytes, 16)), self.alloc(max(src.nbytes, 16))
+        d_c, d_b = self.alloc(max(n * 35 * 4, 16)), self.alloc(max(n, 16))
+        d_r.upload(padded)
+        d_s.upload(src)
+        self.intra32_costs_dev(d_r.ptr, d_s.ptr, d_c.ptr, d_b.ptr, n)
+        self.stream_sync()
+        return d_c.download(np.uint32, n * 35).reshape(n, 35), d_b.download(np.uint8, n)
 
     def satd8x8_dev(self, d_in, d_out, n_blocks, stream=0):
         self._check(self.L.xSatd8x8BatchDev(self.ctx, d_in, d_out, n_blocks, stream), "xSatd8x8BatchDev")

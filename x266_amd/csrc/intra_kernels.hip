@@ -19,6 +19,7 @@
 #include <cstdint>
 
 #include "x266_device.hpp"
+#include "x266_hadamard.hpp"
 
 namespace x266 {
 namespace {
@@ -76,6 +77,93 @@ __device__ __forceinline__ void interpolate16(const unsigned char *p, uint32_t f
     }
 }
 
+// This lane's 16 samples (16h .. 16h+15) of line k = lane >> 1 of the prediction.  Lines are ROWS for
+// planar, DC and the vertical family, COLUMNS for the horizontal family (return value true).
+// left / top: the reference set in LDS (top[0] = corner); ext: 128 bytes of wave-private LDS scratch.
+__device__ __forceinline__ bool predict_line16(int mode, const unsigned char *left, const unsigned char *top,
+                                               unsigned char *ext, int lane, uint32_t (&px)[4])
+{
+    const int k = lane >> 1, h = lane & 1;
+    if (mode >= 2) {
+        const int angle = intra_angle(mode);
+        const bool vertical = mode >= 18;
+        const int t = (k + 1) * angle;
+        const int idx = t >> 5;
+        const uint32_t f = (uint32_t)(t & 31);
+        const unsigned char *line;                          // line[x] = ref[x]
+        if (angle >= 0) {
+            // ref[x] = p[-1+x][-1] is the top array as it lies; ref[1+i] = p[-1][i] is the left array
+            // (ref[0] is never a tap when the angle is not negative)
+            line = vertical ? top : left - 1;
+        } else {
+            // negative angles: the other side's samples, projected with invAngle, sit in front of
+            // ref[0].  Build ref[-32 .. 64] in ext (two positions per lane).
+            const int inv = intra_inv_angle_magnitude(vertical ? 26 - mode : mode - 10);
+            const int last = angle;                         // (32 * angle) >> 5
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                const int e = lane + 64 * rep, x = e - 32;
+                unsigned v = 0;
+                if (x >= 0) {
+                    if (x <= 64) v = vertical ? top[x] : (x == 0 ? top[0] : left[x - 1]);
+                } else if (last < -1 && x >= last) {
+                    const int s = -1 + ((-x * inv + 128) >> 8);              // x * invAngle, invAngle = -inv
+                    v = vertical ? left[s] : top[1 + s];
+                }
+                ext[e] = (unsigned char)v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            line = ext + 32;
+        }
+        interpolate16(line + 16 * h + idx + 1, f, px);
+        return !vertical;
+    }
+    if (mode == 1) {                                        // DC: 32 top + 32 left samples
+        uint32_t s = lane < 32 ? (uint32_t)top[1 + lane] + (uint32_t)left[lane] : 0u;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += (uint32_t)__shfl_xor((int)s, m);
+        const uint32_t dc = (s + 32u) >> 6;
+        px[0] = px[1] = px[2] = px[3] = dc * 0x01010101u;
+        return false;
+    }
+    // planar, row y = k, columns 16h..: ((31-x) L + (x+1) TR + (31-y) T[x] + (y+1) BL + 32) >> 6
+    //   = (C + x (TR - L) + (31-y) T[x]) >> 6,  C = 31 L + TR + (y+1) BL + 32: a per-lane ramp plus one
+    // multiply per sample, in packed 16-bit lanes (all partial sums stay below 2^16 modulo wraparound).
+    typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+    const int tr = top[33], bl = left[32], y = k, lv = left[y];
+    const int D = tr - lv, x0 = 16 * h;
+    const int c0 = 31 * lv + tr + (y + 1) * bl + 32 + x0 * D;
+    v2u re = {(unsigned short)c0, (unsigned short)(c0 + 2 * D)}, ro = {(unsigned short)(c0 + D), (unsigned short)(c0 + 3 * D)};
+    const v2u inc = {(unsigned short)(4 * D), (unsigned short)(4 * D)}, S = {6, 6};
+    const unsigned short wy = (unsigned short)(31 - y);
+    const v2u W = {wy, wy};
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(top + x0);               // top[1 + x0 ..]: one byte past a dword boundary
+    uint32_t d[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) d[i] = q[i];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t a = __builtin_amdgcn_alignbit(d[g + 1], d[g], 8u);
+        const v2u t0 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a, 0x0c020c00u));
+        const v2u t1 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a, 0x0c030c01u));
+        const v2u e = (t0 * W + re) >> S, od = (t1 * W + ro) >> S;
+        px[g] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, od), __builtin_bit_cast(uint32_t, e), 0x06020400u);
+        re += inc;
+        ro += inc;
+    }
+    return false;
+}
+
+// lane (k, h) holds samples 16h..16h+15 of COLUMN k: scatter them into a row-major 32x32 byte tile
+__device__ __forceinline__ void scatter_column(unsigned char *tile, int lane, const uint32_t (&px)[4])
+{
+    const int k = lane >> 1, h = lane & 1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) tile[(16 * h + 4 * g + jj) * 32 + k] = (unsigned char)(px[g] >> (8 * jj));
+}
+
 __global__ __launch_bounds__(256) void intra32_predict_kernel(const x266_intra_ref_t *__restrict__ refs,
                                                               const uint8_t *__restrict__ modes,
                                                               const uint32_t *__restrict__ ref_index,
@@ -105,7 +193,6 @@ __global__ __launch_bounds__(256) void intra32_predict_kernel(const x266_intra_r
     }
     __builtin_amdgcn_wave_barrier();
 
-    const int k = lane >> 1, h = lane & 1;                  // line k, samples 16h .. 16h+15 of it
 #pragma unroll 1
     for (int j = 0; j < kUnits; ++j) {
         const size_t unit = unit0 + j;
@@ -113,83 +200,99 @@ __global__ __launch_bounds__(256) void intra32_predict_kernel(const x266_intra_r
         const int mode = __builtin_amdgcn_readlane(my_mode, j);
         const unsigned char *left = raw_all + j * kRawBytes, *top = left + 64;   // top[0] = corner
         uint32_t px[4];
-        if (mode >= 2) {
-            const int angle = intra_angle(mode);
-            const bool vertical = mode >= 18;
-            const int t = (k + 1) * angle;
-            const int idx = t >> 5;
-            const uint32_t f = (uint32_t)(t & 31);
-            const unsigned char *line;                      // line[x] = ref[x]
-            if (angle >= 0) {
-                // ref[x] = p[-1+x][-1] is the top array as it lies; ref[1+i] = p[-1][i] is the left array
-                // (ref[0] is never a tap when the angle is not negative)
-                line = vertical ? top : left - 1;
-            } else {
-                // negative angles: the other side's samples, projected with invAngle, sit in front of
-                // ref[0].  Build ref[-32 .. 64] in ext (two positions per lane).
-                const int inv = intra_inv_angle_magnitude(vertical ? 26 - mode : mode - 10);
-                const int last = angle;                     // (32 * angle) >> 5
-#pragma unroll
-                for (int rep = 0; rep < 2; ++rep) {
-                    const int e = lane + 64 * rep, x = e - 32;
-                    unsigned v = 0;
-                    if (x >= 0) {
-                        if (x <= 64) v = vertical ? top[x] : (x == 0 ? top[0] : left[x - 1]);
-                    } else if (last < -1 && x >= last) {
-                        const int s = -1 + ((-x * inv + 128) >> 8);          // x * invAngle, invAngle = -inv
-                        v = vertical ? left[s] : top[1 + s];
-                    }
-                    ext[e] = (unsigned char)v;
-                }
-                __builtin_amdgcn_wave_barrier();
-                line = ext + 32;
-            }
-            interpolate16(line + 16 * h + idx + 1, f, px);
-            if (!vertical) {                                // lane holds column k, rows 16h..: turn through the tile
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) tile[(16 * h + 4 * g + jj) * 32 + k] = (unsigned char)(px[g] >> (8 * jj));
-                __builtin_amdgcn_wave_barrier();
-                const v4i row = *reinterpret_cast<const v4i *>(tile + lane * 16);
-                px[0] = (uint32_t)row[0]; px[1] = (uint32_t)row[1]; px[2] = (uint32_t)row[2]; px[3] = (uint32_t)row[3];
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else if (mode == 1) {                             // DC: 32 top + 32 left samples
-            uint32_t s = lane < 32 ? (uint32_t)top[1 + lane] + (uint32_t)left[lane] : 0u;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) s += (uint32_t)__shfl_xor((int)s, m);
-            const uint32_t dc = (s + 32u) >> 6;
-            px[0] = px[1] = px[2] = px[3] = dc * 0x01010101u;
-        } else {
-            // planar, row y = k, columns 16h..: ((31-x) L + (x+1) TR + (31-y) T[x] + (y+1) BL + 32) >> 6
-            //   = (C + x (TR - L) + (31-y) T[x]) >> 6,  C = 31 L + TR + (y+1) BL + 32: a per-lane ramp plus one
-            // multiply per sample, in packed 16-bit lanes (all partial sums stay below 2^16 modulo wraparound).
-            typedef unsigned short v2u __attribute__((ext_vector_type(2)));
-            const int tr = top[33], bl = left[32], y = k, lv = left[y];
-            const int D = tr - lv, x0 = 16 * h;
-            const int c0 = 31 * lv + tr + (y + 1) * bl + 32 + x0 * D;
-            v2u re = {(unsigned short)c0, (unsigned short)(c0 + 2 * D)}, ro = {(unsigned short)(c0 + D), (unsigned short)(c0 + 3 * D)};
-            const v2u inc = {(unsigned short)(4 * D), (unsigned short)(4 * D)}, S = {6, 6};
-            const unsigned short wy = (unsigned short)(31 - y);
-            const v2u W = {wy, wy};
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(top + x0);       // top[1 + x0 ..]: one byte past a dword boundary
-            uint32_t d[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) d[i] = q[i];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint32_t a = __builtin_amdgcn_alignbit(d[g + 1], d[g], 8u);
-                const v2u t0 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a, 0x0c020c00u));
-                const v2u t1 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a, 0x0c030c01u));
-                const v2u e = (t0 * W + re) >> S, od = (t1 * W + ro) >> S;
-                px[g] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, od), __builtin_bit_cast(uint32_t, e), 0x06020400u);
-                re += inc;
-                ro += inc;
-            }
+        if (predict_line16(mode, left, top, ext, lane, px)) {    // columns: turn through the tile
+            scatter_column(tile, lane, px);
+            __builtin_amdgcn_wave_barrier();
+            const v4i row = *reinterpret_cast<const v4i *>(tile + lane * 16);
+            px[0] = (uint32_t)row[0]; px[1] = (uint32_t)row[1]; px[2] = (uint32_t)row[2]; px[3] = (uint32_t)row[3];
+            __builtin_amdgcn_wave_barrier();
         }
         store16_sc1nt(pred + unit * 1024 + lane * 16, v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]});
     }
+}
+
+// ---- mode decision ("Decide" channel of the RTL sketch, IntraChannel_t :41-44) ------------------
+// costs[b][m] = sum over the sixteen 8x8 sub-blocks of satd8x8(src - prediction m), m = 0..34, without
+// the predictions ever leaving the CU.  The Hadamard transform is linear and a 9-bit difference cannot
+// wrap int16, so satd(src - pred) = (sum |H src - H pred| + 2) >> 2 per sub-block (as in me_kernels.hip):
+// H src is formed once per block, H pred once per mode -- two modes per matrix-core pass, their
+// 16 + 16 sub-blocks being the 32 columns of the 64x64x32 Hadamard GEMM -- and scored with v_sad_u16.
+constexpr int kCostSlot = 16 + kRawBytes + kExtBytes + 1024 + 2048;   // raw | ext | src tile | two prediction tiles
+
+__global__ __launch_bounds__(256) void intra32_costs_kernel(const x266_intra_ref_t *__restrict__ refs,
+                                                            const uint8_t *__restrict__ src,
+                                                            uint32_t *__restrict__ costs, uint8_t *__restrict__ best_mode,
+                                                            size_t n)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kCostSlot];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t b = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+    if (b >= n) return;
+    unsigned char *raw = lds + wave_in_wg * kCostSlot + 16;
+    unsigned char *ext = raw + kRawBytes, *stile = ext + kExtBytes, *ptile = stile + 1024;
+    const v4i S = {(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};   // pixels -> signed; the offset cancels
+
+    if (lane < 9) *reinterpret_cast<v4i *>(raw + lane * 16) = load16<true>(reinterpret_cast<const unsigned char *>(refs + b) + lane * 16);
+    *reinterpret_cast<v4i *>(stile + lane * 16) = load16<true>(src + b * 1024 + lane * 16) ^ S;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned char *left = raw, *top = raw + 64;
+
+    // lane (n, half): rows 4*half .. +3 of sub-block n & 15 (sy = bits 3:2, sx = bits 1:0); columns 16..31 repeat 0..15
+    const int nn = lane & 31, half = lane >> 5, sb = nn & 15;
+    const unsigned frag = (unsigned)((8 * (sb >> 2) + 4 * half) * 32 + 8 * (sb & 3));
+    const HadamardOps H = make_hadamard_ops(lane);
+    auto window = [&](const unsigned char *tile, v4i &w0, v4i &w1) {
+        const uint2 r0 = *reinterpret_cast<const uint2 *>(tile + frag), r1 = *reinterpret_cast<const uint2 *>(tile + frag + 32);
+        const uint2 r2 = *reinterpret_cast<const uint2 *>(tile + frag + 64), r3 = *reinterpret_cast<const uint2 *>(tile + frag + 96);
+        w0 = v4i{(int)r0.x, (int)r0.y, (int)r1.x, (int)r1.y};
+        w1 = v4i{(int)r2.x, (int)r2.y, (int)r3.x, (int)r3.y};
+    };
+    uint32_t cs[16];
+    {
+        v4i w0, w1;
+        window(stile, w0, w1);
+        hadamard_pack(H, w0, w1, cs);
+    }
+    uint32_t best_key = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (int pair = 0; pair < 18; ++pair) {
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            const int mode = 2 * pair + t;
+            if (mode > 34) break;
+            uint32_t px[4];
+            const bool columns = predict_line16(mode, left, top, ext, lane, px);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) px[g] ^= 0x80808080u;
+            unsigned char *tile = ptile + t * 1024;
+            if (columns) scatter_column(tile, lane, px);
+            else         *reinterpret_cast<v4i *>(tile + lane * 16) = v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]};
+        }
+        __builtin_amdgcn_wave_barrier();
+        v4i w0, w1;
+        window(ptile + (nn >> 4) * 1024, w0, w1);
+        uint32_t p[16];
+        hadamard_pack(H, w0, w1, p);
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = __builtin_amdgcn_sad_u16(p[k], cs[k], s);
+        s += (uint32_t)__shfl_xor((int)s, 32);               // the other half of the coefficient rows
+        uint32_t c = (s + 2u) >> 2;                          // satd8x8 of this sub-block
+#pragma unroll
+        for (int m = 1; m <= 8; m <<= 1) c += (uint32_t)__shfl_xor((int)c, m);   // sixteen sub-blocks
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t c_a = (uint32_t)__builtin_amdgcn_readlane((int)c, 0), c_b = (uint32_t)__builtin_amdgcn_readlane((int)c, 16);
+        const int m_a = 2 * pair, m_b = 2 * pair + 1;
+        if (lane == 0) {
+            costs[b * 35 + m_a] = c_a;
+            if (m_b < 35) costs[b * 35 + m_b] = c_b;
+        }
+        const uint32_t k_a = (c_a << 6) | (uint32_t)m_a, k_b = m_b < 35 ? ((c_b << 6) | (uint32_t)m_b) : 0xFFFFFFFFu;
+        best_key = k_a < best_key ? k_a : best_key;
+        best_key = k_b < best_key ? k_b : best_key;
+    }
+    if (best_mode && lane == 0) best_mode[b] = (uint8_t)(best_key & 63u);
 }
 
 }  // namespace
@@ -201,6 +304,20 @@ hipError_t launch_intra32_predict(const x266_intra_ref_t *d_refs, const uint8_t 
     const size_t waves = (n + kUnits - 1) / kUnits, wgs = (waves + 3) / 4;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(intra32_predict_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, d_refs, d_modes, d_ref_index, d_pred, n);
+    return hipGetLastError();
+}
+
+}  // namespace x266
+
+namespace x266 {
+
+hipError_t launch_intra32_costs(const x266_intra_ref_t *d_refs, const uint8_t *d_src, uint32_t *d_costs, uint8_t *d_best_mode,
+                                size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const size_t wgs = (n + 3) / 4;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(intra32_costs_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, d_refs, d_src, d_costs, d_best_mode, n);
     return hipGetLastError();
 }
 

@@ -335,6 +335,18 @@ int xIntra32PredictDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const u
     return X266HIP_OK;
 }
 
+int xIntra32CostsDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const uint8_t *d_src,
+                     uint32_t *d_costs, uint8_t *d_best_mode, size_t n, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (n && (!d_refs || !d_src || !d_costs || (((uintptr_t)d_refs | (uintptr_t)d_src) & 15u) || ((uintptr_t)d_costs & 3u)))
+        return fail(ctx, X266HIP_EINVAL, "xIntra32CostsDev: NULL or unaligned buffer");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_intra32_costs(d_refs, d_src, d_costs, d_best_mode, n, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "intra decision launch", e);
+    return X266HIP_OK;
+}
+
 int xFillResidualDev(x266hip_ctx *ctx, int16_t *d_dst, size_t n_samples, uint64_t seed, uint64_t first_index,
                      void *stream)
 {
