@@ -407,6 +407,42 @@ def main():
             also["fused_from_tiles"] = fused
             del tcur, tpred, fcoef, fcost, fres
 
+        # ---- 32x32 intra prediction and mode decision (HEVC 35 modes; parity unpinned upstream)
+        if not args.no_transform_set:
+            g = torch.Generator(device="cuda")
+            g.manual_seed(0x32 + rank)
+            n_sets = 59918                                              # x 35 modes = 2 GiB of predictions
+            refs_t = torch.randint(0, 256, (n_sets, 144), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
+            modes_t = torch.arange(35, device="cuda", dtype=torch.uint8).repeat(n_sets)
+            index_t = torch.arange(n_sets, device="cuda", dtype=torch.int32).repeat_interleave(35)
+            pred_t = torch.empty(n_sets * 35 * 1024, dtype=torch.uint8, device="cuda")
+            n_dec = 1 << 17
+            src_t = torch.randint(0, 256, (n_dec * 1024,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
+            cost_t = torch.empty(n_dec * 35, dtype=torch.int32, device="cuda")
+            bestm_t = torch.empty(n_dec, dtype=torch.uint8, device="cuda")
+            intra = {}
+            for name, units, fn in (
+                    ("predict", n_sets * 35, lambda: codec.intra32_predict_dev(refs_t.data_ptr(), modes_t.data_ptr(), index_t.data_ptr(),
+                                                                             pred_t.data_ptr(), n_sets * 35, stream)),
+                    ("decide_35_modes", n_dec, lambda: codec.intra32_costs_dev(refs_t.data_ptr(), src_t.data_ptr(), cost_t.data_ptr(),
+                                                                             bestm_t.data_ptr(), min(n_dec, n_sets), stream))):
+                steps_i = max(2, args.steps // 4)
+                for _ in range(5):
+                    fn()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(steps_i):
+                    fn()
+                barrier()
+                wall_i2 = max_over_ranks(time.perf_counter() - t0)
+                units = units if name == "predict" else min(n_dec, n_sets)
+                intra[name] = {"value": world * units * steps_i / wall_i2, "unit": "predictions/s" if name == "predict" else "blocks/s"}
+            intra["predict"]["written_hbm_frac"] = 1024.0 * intra["predict"]["value"] / world / HBM_PEAK_BYTES_PER_S
+            intra["decide_35_modes"]["satd8x8_per_s"] = intra["decide_35_modes"]["value"] * 35 * 16
+            intra["parity"] = "unpinned upstream (src/mkIntra32-wip.bsv is a sketch without a model); bit-exact vs this repo's oracle"
+            also["intra32"] = intra
+            del refs_t, modes_t, index_t, pred_t, src_t, cost_t, bestm_t
+
         # ---- BASELINE configs[4] (on request): 8K frame stream, scatter -> kernels -> gather over RCCL
         if args.stream8k > 0 and ctrl == "cuda":
             from x266_amd.stream import FrameGeometry, PipelinedFrameStream
