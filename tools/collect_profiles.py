@@ -18,7 +18,7 @@ def short(n):
     if "dct32_lds_kernel<1" in n or "dct32_kernel<1" in n or "dct32_kernel<true" in n: return "dct32_kernel<inverse>"
     if "dct32_lds_kernel<0" in n or "dct32_kernel<0" in n or "dct32_kernel<false" in n: return "dct32_kernel<forward>"
     if "dct32_kernel<2" in n: return "dct32_kernel<passthrough>"
-    if "satd8x8_kernel" in n: return "satd8x8_kernel"
+    if "satd8x8_kernel" in n or "satd8x8_lds_kernel" in n: return "satd8x8_kernel"
     if "fill_residual" in n: return "fill_residual_kernel"
     return None
 
