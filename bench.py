@@ -362,8 +362,34 @@ def main():
                     ts["%s_%dx%d" % (tname, n, n)] = {
                         "value": world * nblk * args.steps / wall_t, "unit": "blocks/s",
                         "hbm_frac": 4.0 * n * n * nblk / (wall_t / args.steps) / HBM_PEAK_BYTES_PER_S}
-            del zt
-            also["transform_set"] = {"classes": ts, "parity": "unpinned upstream except DCT-II 32; bit-exact vs this repo's oracle",
+            # per-CTU mixed batches: every 64x64 CTU's quadrants cycle through the four TU sizes; one call per
+            # (type, size) class over an offset table into the shared residual / coefficient buffers
+            n_ctu = (n_dct * 1024) // 4096
+            q = torch.arange(n_ctu * 4, device="cuda", dtype=torch.int64)
+            qbase, qkind = q * 1024, (q + q // 4) % 7          # quadrant -> one of the seven (type, size) classes
+            mixed = []
+            for kind, (tt, n) in enumerate(((0, 32), (0, 16), (1, 16), (0, 8), (1, 8), (0, 4), (1, 4))):
+                base = qbase[qkind == kind]
+                sub = torch.arange(1024 // (n * n), device="cuda", dtype=torch.int64) * (n * n)
+                mixed.append((tt, n, (base[:, None] + sub[None, :]).reshape(-1).to(torch.int32).contiguous()))
+            assert sum(o.numel() * nn * nn for _, nn, o in mixed) == n_ctu * 4096
+
+            def ctu_pass():
+                for tt, nn, o in mixed:
+                    codec.transform_fwd_dev(tt, nn, x.data_ptr(), zt.data_ptr(), o.numel(), o.data_ptr(), stream)
+            for _ in range(3):
+                ctu_pass()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(max(2, args.steps // 4)):
+                ctu_pass()
+            barrier()
+            wall_c = max_over_ranks(time.perf_counter() - t0) / max(2, args.steps // 4)
+            per_ctu = {"value": world * n_ctu / wall_c, "unit": "CTUs/s", "hbm_frac": 4.0 * n_ctu * 4096 / wall_c / HBM_PEAK_BYTES_PER_S,
+                       "layout": "64x64 CTUs whose 32x32 quadrants cycle through the seven classes (DCT-II 32/16/8/4, DST-VII 16/8/4), "
+                                 "TUs of a quadrant contiguous; 7 calls per pass over offset tables", "ctus": n_ctu}
+            del zt, mixed, q, qbase, qkind
+            also["transform_set"] = {"classes": ts, "per_ctu_mixed": per_ctu, "parity": "unpinned upstream except DCT-II 32; bit-exact vs this repo's oracle",
                                      "note": "wall-clock rates (launch gaps included); 4*N*N algorithmic bytes per block"}
         # ---- fused front end: tiled cur/pred frames -> coefficients / costs, residual never in HBM
         if not args.no_transform_set:

@@ -94,10 +94,10 @@ __global__ __launch_bounds__(256) void tr_fwd_small_kernel(const int16_t *__rest
 // memory, moved with linear 1 KiB instructions (whole 128-byte lines per instruction, see
 // dct32_kernels.hip section "LDS-staged variant") and re-read from a wave-private LDS slot in
 // fragment order.  N = 8 does not need it: its fragment loads are line-dense already.
-template <int LOGN, bool NT>
+template <int LOGN, bool NT, bool INDEXED>
 __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
                                                                size_t n_blocks, const DctOps *__restrict__ ops,
-                                                               unsigned tiles_per_wave)
+                                                               const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
 {
     constexpr int N = 1 << LOGN;
     constexpr int PER = 32 / N, PIECES = N >= 16 ? 1 : 16 / N, NSB = PER * PER;
@@ -123,11 +123,28 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
         frag[q] = (sb * (unsigned)(N * N) + (unsigned)row * N + (N == 32 ? 16u * h : 0u)) * 2u;
     }
     for (; t < t_end; ++t) {
-        const size_t base = t * 2048;
-        size_t o0 = base + (size_t)lane * 16, o1 = o0 + 1024;
-        const bool live0 = o0 + 16 <= total_bytes, live1 = o1 + 16 <= total_bytes;
-        if (!live0) o0 = total_bytes - 16;                               // ragged tail: stay inside the buffer
-        if (!live1) o1 = total_bytes - 16;
+        size_t o0, o1;
+        bool live0, live1;
+        if (INDEXED) {
+            // chunk c (16 bytes) of the tile belongs to block c / CPB of the tile, placed by the offset table:
+            // blocks that sit next to each other in memory still make line-dense instructions
+            constexpr int CPB = N * N / 8;                               // 16-byte chunks per block
+            size_t b0 = t * NSB + (size_t)(lane / CPB), b1 = t * NSB + (size_t)((lane + 64) / CPB);
+            live0 = b0 < n_blocks;
+            live1 = b1 < n_blocks;
+            if (!live0) b0 = n_blocks - 1;                               // ragged tail: re-read the last block
+            if (!live1) b1 = n_blocks - 1;
+            o0 = ((size_t)offsets[b0] * 2) + (size_t)(lane % CPB) * 16;
+            o1 = ((size_t)offsets[b1] * 2) + (size_t)((lane + 64) % CPB) * 16;
+        } else {
+            const size_t base = t * 2048;
+            o0 = base + (size_t)lane * 16;
+            o1 = o0 + 1024;
+            live0 = o0 + 16 <= total_bytes;
+            live1 = o1 + 16 <= total_bytes;
+            if (!live0) o0 = total_bytes - 16;                           // ragged tail: stay inside the buffer
+            if (!live1) o1 = total_bytes - 16;
+        }
         const v4i g0 = load16<NT>(reinterpret_cast<const char *>(in) + o0);
         const v4i g1 = load16<NT>(reinterpret_cast<const char *>(in) + o1);
         *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
@@ -268,14 +285,16 @@ hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out
     const size_t tiles = (n_blocks + per_tile - 1) / per_tile;
     const unsigned tpw = units_per_wave_for(cfg, tiles);
     const size_t waves = (tiles + tpw - 1) / tpw;
-    if (!d_offsets && cfg.lds_stage) {                           // contiguous batch: line-dense traffic through LDS
+    if (cfg.lds_stage) {                                         // line-dense traffic through LDS (contiguous or placed by the offset table)
         const unsigned tpb = (unsigned)cfg.wg_threads;            // same launch shape as the staged DCT32 kernel
         const size_t wpw = tpb / 64, swgs = (waves + wpw - 1) / wpw;
         if (swgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
         const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
         dim3 sgrid((unsigned)swgs), sblock(tpb);
-#define X266_TRL(L) do { if (cfg.nontemporal & 3) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, true>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw); \
-                         else                     hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, false>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, tpw); } while (0)
+        // streaming cache hints only for contiguous batches: scattered blocks may share lines across instructions
+#define X266_TRL(L) do { if (d_offsets)                hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, false, true>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
+                         else if (cfg.nontemporal & 3) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, true, false>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
+                         else                          hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, false, false>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
         if (log2n == 2) X266_TRL(2); else if (log2n == 3) X266_TRL(3); else if (log2n == 4) X266_TRL(4); else if (log2n == 5) X266_TRL(5);
         else return hipErrorInvalidValue;
 #undef X266_TRL
