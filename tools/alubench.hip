@@ -20,6 +20,11 @@ template <int OP> __global__ __launch_bounds__(256) void k(unsigned* out, unsign
                 if (OP == 7) a[i] = __builtin_amdgcn_sad_u8(a[i], b, c);
                 if (OP == 8) a[i] = (int)a[i] >> 4;
                 if (OP == 9) a[i] = a[i] < b ? a[i] : b;
+                if (OP == 10) { typedef short v2s __attribute__((ext_vector_type(2))); v2s r = __builtin_amdgcn_cvt_pk_i16((int)a[i], (int)b); a[i] = __builtin_bit_cast(unsigned, r) + c; }
+                if (OP == 11) { int v = (int)a[i]; a[i] = (unsigned)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)) + c; }
+                if (OP == 12) { typedef unsigned short v2u __attribute__((ext_vector_type(2))); v2u x = __builtin_bit_cast(v2u, a[i]), y = __builtin_bit_cast(v2u, b), z = __builtin_bit_cast(v2u, c); a[i] = __builtin_bit_cast(unsigned, (v2u)(x * y + z)); }
+                if (OP == 13) a[i] = __builtin_amdgcn_udot4(a[i], b, c, false);
+                if (OP == 14) a[i] = __builtin_amdgcn_ubfe(a[i], 5u, 8u) + b;
             }
         }
     }
@@ -28,10 +33,10 @@ template <int OP> __global__ __launch_bounds__(256) void k(unsigned* out, unsign
 typedef void (*kt)(unsigned*, unsigned, int);
 int main() {
     unsigned* out; CK(hipMalloc(&out, 256 * 2048 * 4 * 4)); hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const char* names[] = {"v_add_u32", "v_sad_u16", "v_perm_b32", "v_lshl_add_u32", "v_mul_lo_u32", "v_alignbit_b32", "v_permlane32_swap", "v_sad_u8", "v_ashrrev_i32", "v_min_u32"};
-    kt ks[] = {k<0>, k<1>, k<2>, k<3>, k<4>, k<5>, k<6>, k<7>, k<8>, k<9>};
+    const char* names[] = {"v_add_u32", "v_sad_u16", "v_perm_b32", "v_lshl_add_u32", "v_mul_lo_u32", "v_alignbit_b32", "v_permlane32_swap", "v_sad_u8", "v_ashrrev_i32", "v_min_u32", "v_cvt_pk_i16_i32 (+add)", "v_med3_i32 (+add)", "v_pk_mad_u16", "v_dot4_u32_u8", "v_bfe_u32 (+add)"};
+    kt ks[] = {k<0>, k<1>, k<2>, k<3>, k<4>, k<5>, k<6>, k<7>, k<8>, k<9>, k<10>, k<11>, k<12>, k<13>, k<14>};
     const int iters = 2000, wgs = 256 * 8;       // 8 WGs of 256 per CU = 8 waves per SIMD
-    for (int o = 0; o < 10; ++o) {
+    for (int o = 0; o < 15; ++o) {
         hipLaunchKernelGGL(ks[o], dim3(wgs), dim3(256), 0, 0, out, 1u, 10);
         CK(hipEventRecord(e0, 0)); hipLaunchKernelGGL(ks[o], dim3(wgs), dim3(256), 0, 0, out, 1u, iters); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
