@@ -217,6 +217,20 @@ int xHipFree(x266hip_ctx *ctx, void *d_ptr);
 int xHipMemcpyH2D(x266hip_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 int xHipMemcpyD2H(x266hip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 int xHipStreamSync(x266hip_ctx *ctx, void *stream);
+int xHipStreamCreate(x266hip_ctx *ctx, void **stream);     /* a non-blocking hipStream_t */
+int xHipStreamDestroy(x266hip_ctx *ctx, void *stream);
+/* HIP graphs for launch-bound sequences (a frame's handful of small kernels costs more in launch
+ * overhead than in execution): everything enqueued on `stream` (not the NULL stream) between
+ * xHipGraphBegin and xHipGraphEnd -- any of the ...Dev calls above, in any number -- is recorded
+ * instead of run, and xHipGraphLaunch replays the whole sequence with one submission.  The recorded
+ * calls keep their pointer and size arguments, so a graph is replayed over the same buffers with new
+ * contents.  Run the sequence once before capturing it: calls that size internal scratch on first use
+ * (xSatd8x8SearchDev) must not do so inside a capture. */
+typedef struct x266hip_graph x266hip_graph;
+int xHipGraphBegin(x266hip_ctx *ctx, void *stream);
+int xHipGraphEnd(x266hip_ctx *ctx, void *stream, x266hip_graph **graph);
+int xHipGraphLaunch(x266hip_ctx *ctx, x266hip_graph *graph, void *stream);
+void xHipGraphFree(x266hip_ctx *ctx, x266hip_graph *graph);
 /* Times `reps` back-to-back launches of one kernel with HIP events recorded on
  * `stream` itself; returns the mean milliseconds per launch in *ms_per_launch.
  * op: 0 = dct32 fwd, 1 = dct32 inv, 2 = satd8x8 (buffers as in the Dev calls). */

@@ -58,6 +58,13 @@ def load_library():
     L.xDct32FwdInvBatchDev.argtypes = [_P, _P, _P, _P, _SZ, _P]
     L.xFillResidualDev.argtypes = [_P, _P, _SZ, _U64, _U64, _P]
     L.xIntra32PredictDev.argtypes = [_P, _P, _P, _P, _P, _SZ, _P]
+    L.xHipStreamCreate.argtypes = [_P, ctypes.POINTER(_P)]
+    L.xHipStreamDestroy.argtypes = [_P, _P]
+    L.xHipGraphBegin.argtypes = [_P, _P]
+    L.xHipGraphEnd.argtypes = [_P, _P, ctypes.POINTER(_P)]
+    L.xHipGraphLaunch.argtypes = [_P, _P, _P]
+    L.xHipGraphFree.argtypes = [_P, _P]
+    L.xHipGraphFree.restype = None
     L.xIntra32CostsDev.argtypes = [_P, _P, _P, _P, _P, _SZ, _P]
     L.xTransformFwdBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
     L.xConvInputFmtDev.argtypes = [_P, _P, _P, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
@@ -344,6 +351,29 @@ class Codec:
     def fill_residual_dev(self, d_dst, n_samples, seed, first_index=0, stream=0):
         self._check(self.L.xFillResidualDev(self.ctx, d_dst, n_samples, seed, first_index, stream),
                     "xFillResidualDev")
+
+    # -- streams and graphs (for launch-bound sequences) ---------------------------------------
+    def stream_create(self):
+        s = _P()
+        self._check(self.L.xHipStreamCreate(self.ctx, ctypes.byref(s)), "xHipStreamCreate")
+        return s.value
+
+    def stream_destroy(self, stream):
+        self._check(self.L.xHipStreamDestroy(self.ctx, stream), "xHipStreamDestroy")
+
+    def graph_begin(self, stream):
+        self._check(self.L.xHipGraphBegin(self.ctx, stream), "xHipGraphBegin")
+
+    def graph_end(self, stream):
+        g = _P()
+        self._check(self.L.xHipGraphEnd(self.ctx, stream, ctypes.byref(g)), "xHipGraphEnd")
+        return g.value
+
+    def graph_launch(self, graph, stream):
+        self._check(self.L.xHipGraphLaunch(self.ctx, graph, stream), "xHipGraphLaunch")
+
+    def graph_free(self, graph):
+        self.L.xHipGraphFree(self.ctx, graph)
 
     def stream_sync(self, stream=0):
         self._check(self.L.xHipStreamSync(self.ctx, stream), "xHipStreamSync")

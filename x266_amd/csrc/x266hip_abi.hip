@@ -628,6 +628,80 @@ int xHipStreamSync(x266hip_ctx *ctx, void *stream)
     return X266HIP_OK;
 }
 
+int xHipStreamCreate(x266hip_ctx *ctx, void **stream)
+{
+    if (!ctx || !stream) return X266HIP_EINVAL;
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = nullptr;
+    X_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return X266HIP_OK;
+}
+
+int xHipStreamDestroy(x266hip_ctx *ctx, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (!stream) return X266HIP_OK;
+    X_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+    return X266HIP_OK;
+}
+
+struct x266hip_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+int xHipGraphBegin(x266hip_ctx *ctx, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (!stream) return fail(ctx, X266HIP_EINVAL, "xHipGraphBegin: capture needs a stream of its own, not the NULL stream");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_HIP(ctx, hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return X266HIP_OK;
+}
+
+int xHipGraphEnd(x266hip_ctx *ctx, void *stream, x266hip_graph **graph)
+{
+    if (!ctx || !graph || !stream) return X266HIP_EINVAL;
+    *graph = nullptr;
+    hipGraph_t g = nullptr;
+    X_HIP(ctx, hipStreamEndCapture((hipStream_t)stream, &g));
+    if (!g) return fail(ctx, X266HIP_EDEVICE, "xHipGraphEnd: the capture was invalidated");
+    hipGraphExec_t e = nullptr;
+    const hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    if (rc != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return fail(ctx, X266HIP_EDEVICE, "hipGraphInstantiate", rc);
+    }
+    x266hip_graph *out = new (std::nothrow) x266hip_graph;
+    if (!out) {
+        (void)hipGraphExecDestroy(e);
+        (void)hipGraphDestroy(g);
+        return X266HIP_ENOMEM;
+    }
+    out->graph = g;
+    out->exec = e;
+    *graph = out;
+    return X266HIP_OK;
+}
+
+int xHipGraphLaunch(x266hip_ctx *ctx, x266hip_graph *graph, void *stream)
+{
+    if (!ctx || !graph || !graph->exec) return X266HIP_EINVAL;
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_HIP(ctx, hipGraphLaunch(graph->exec, (hipStream_t)stream));
+    return X266HIP_OK;
+}
+
+void xHipGraphFree(x266hip_ctx *ctx, x266hip_graph *graph)
+{
+    (void)ctx;
+    if (!graph) return;
+    if (graph->exec) (void)hipGraphExecDestroy(graph->exec);
+    if (graph->graph) (void)hipGraphDestroy(graph->graph);
+    delete graph;
+}
+
 int xHipTimeKernel(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n, int reps, void *stream,
                    double *ms_per_launch)
 {
