@@ -358,3 +358,41 @@ def test_plain_c_host_example():
     out = subprocess.run([exe, "5000"], timeout=300, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "agree on the rand() block" in out.stdout
+
+
+# ---------------------------------------------------------------- batches beyond 4 GiB
+def test_batches_larger_than_4_gib(codec, oracle):
+    """Byte offsets beyond 2^32 (8 GiB of DCT32 blocks, 4 GiB of SATD blocks, ragged counts): samples at
+    the start, across the 4 GiB boundary and at the ragged end are bit-exact with the oracle."""
+    n = (1 << 22) + 3
+    din, dout, drec = codec.alloc(n * 2048), codec.alloc(n * 2048), codec.alloc(n * 2048)
+    codec.fill_residual_dev(din.ptr, n * 1024, 0x4A11)
+    codec.dct32_fwd_dev(din.ptr, dout.ptr, n)
+    codec.stream_sync()
+
+    def sample(buf, first, count, dtype=np.int16, unit=1024):
+        out = np.empty(count * unit, dtype)
+        codec._check(codec.L.xHipMemcpyD2H(codec.ctx, out.ctypes.data, buf.ptr + first * unit * out.itemsize, out.nbytes), "D2H")
+        return out.reshape(count, unit)
+
+    spots = [(0, 64), ((1 << 21) - 32, 64), (n - 67, 67)]          # block 2^21 starts at byte 2^32
+    for first, count in spots:
+        x = sample(din, first, count)
+        assert np.array_equal(sample(dout, first, count), oracle.dct32_fwd(x)), first
+    codec.dct32_inv_dev(dout.ptr, drec.ptr, n)
+    codec.stream_sync()
+    for first, count in spots:
+        assert np.array_equal(sample(drec, first, count), oracle.dct32_inv(sample(dout, first, count))), first
+    codec.dct32_fwd_inv_dev(din.ptr, dout.ptr, drec.ptr, n)        # fused: same coefficients, same reconstruction
+    codec.stream_sync()
+    for first, count in spots:
+        z = oracle.dct32_fwd(sample(din, first, count))
+        assert np.array_equal(sample(dout, first, count), z) and np.array_equal(sample(drec, first, count), oracle.dct32_inv(z)), first
+    ns = (1 << 25) + 70                                             # 4 GiB + a ragged group of SATD blocks, reusing din
+    cost = codec.alloc(ns * 4)
+    codec.satd8x8_dev(din.ptr, cost.ptr, ns)
+    codec.stream_sync()
+    for first, count in [(0, 96), ((1 << 25) - 48, 118), (ns - 70, 70)]:
+        d = sample(din, first, count, np.int16, 64)
+        got = sample(cost, first, count, np.uint32, 1).ravel()
+        assert np.array_equal(got, oracle.satd8x8(d)), first
