@@ -62,16 +62,21 @@ const char *xHipLastError(const x266hip_ctx *ctx);
 /* Device facts for reports: name, CU count, max engine clock (MHz), HBM bytes. */
 int  xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap,
                     int *cu_count, int *clock_mhz, size_t *hbm_bytes);
-/* Launch-geometry options, for A/B measurement (defaults are the measured optimum):
- *   "dct32_variant" / "satd_variant"   0 = streaming launch (grid covers the batch; each wave
- *                                          transforms a short run of consecutive blocks),
- *                                      1 = persistent grid-stride launch
- *   "dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "satd_groups_per_wave"
- *                                      run length per wave of the streaming launch
- *   "dct32_wgs_per_cu", "dct32_inv_wgs_per_cu", "satd_wgs_per_cu"
- *                                      resident workgroups per CU of the persistent launch
- *   "wg_threads" (64..256), "nontemporal" (0/1)
- * Results never depend on them.  Unknown keys return X266HIP_EINVAL. */
+/* Launch options, for A/B measurement (defaults are the measured optimum; results never depend on
+ * them; unknown keys and out-of-range values return X266HIP_EINVAL).  The full list with ranges is
+ * the kOptions table in x266_amd/csrc/x266hip_abi.hip; the ones that matter:
+ *   "nontemporal"            cache-policy bits for line-dense accesses: 1 nt loads, 2 nt stores,
+ *                            8 "sc1 nt" stores (default 11); 4 = hints on fragment loads too
+ *   "dct32_lds_stage", "satd_lds_stage", "tr_lds_stage"
+ *                            1 = move tiles with 1 KiB-linear instructions through LDS (default)
+ *   "dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "dct32_fwdinv_blocks_per_wave",
+ *   "satd_groups_per_wave", "tr_tiles_per_wave"
+ *                            consecutive units one wave loops over
+ *   "dct32_wg_threads", "dct32_inv_wg_threads", "satd_wg_threads" (64..256)
+ *   "dct32_lds_bytes_per_wave", ... LDS charged per wave = cap on resident waves per CU
+ *   "adaptive_per_wave"      shrink the per-wave run on small batches (default 1)
+ *   "dct32_variant" / "satd_variant" 1 = persistent grid-stride launch of the direct kernels
+ *   "me_variant", "me_tile_rows", "me_row_pairs"   motion-search kernel shape */
 int  xHipSetOption(x266hip_ctx *ctx, const char *key, int value);
 int  xHipGetOption(const x266hip_ctx *ctx, const char *key, int *value);
 

@@ -171,6 +171,10 @@ def test_argument_errors(codec):
     assert L.xDct32FwdBatchDev(codec.ctx, buf.ptr + 2, buf.ptr, 1, None) < 0        # misaligned
     assert L.xSatd8x8Batch(codec.ctx, None, None, 3) < 0
     assert L.xHipSetOption(codec.ctx, b"no_such_option", 1) < 0
+    for key, bad in ((b"dct32_wg_threads", 96), (b"dct32_wg_threads", 512), (b"dct32_blocks_per_wave", 0), (b"nontemporal", 16),
+                     (b"dct32_lds_bytes_per_wave", 1024), (b"me_variant", 0)):
+        assert L.xHipSetOption(codec.ctx, key, bad) < 0, key                     # out of range: rejected, value unchanged
+    assert codec.get_option("dct32_wg_threads") == 64
     assert b"" != L.xHipLastError(codec.ctx)
 
 

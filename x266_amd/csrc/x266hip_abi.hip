@@ -225,62 +225,70 @@ int xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap, int *cu_
     return X266HIP_OK;
 }
 
-static int *option_slot(x266hip_ctx *ctx, const char *key)
+// One table for every launch option: key, the context member it sets, accepted range, and a
+// required divisor (workgroup sizes are whole waves).
+struct OptionDesc {
+    const char *key;
+    int x266hip_ctx::*member;
+    int lo, hi, multiple_of;
+};
+
+static const OptionDesc kOptions[] = {
+    {"dct32_wgs_per_cu", &x266hip_ctx::wgs_per_cu_dct, 1, 64, 1},
+    {"dct32_inv_wgs_per_cu", &x266hip_ctx::wgs_per_cu_inv, 1, 64, 1},
+    {"satd_wgs_per_cu", &x266hip_ctx::wgs_per_cu_satd, 1, 64, 1},
+    {"nontemporal", &x266hip_ctx::nontemporal, 0, 15, 1},
+    {"adaptive_per_wave", &x266hip_ctx::adaptive_per_wave, 0, 1, 1},
+    {"dct32_variant", &x266hip_ctx::dct_variant, 0, 1, 1},
+    {"satd_variant", &x266hip_ctx::satd_variant, 0, 1, 1},
+    {"dct32_blocks_per_wave", &x266hip_ctx::dct_blocks_per_wave, 1, 4096, 1},
+    {"dct32_inv_blocks_per_wave", &x266hip_ctx::dct_inv_blocks_per_wave, 1, 4096, 1},
+    {"dct32_fwdinv_blocks_per_wave", &x266hip_ctx::dct_fwdinv_blocks_per_wave, 1, 4096, 1},
+    {"satd_groups_per_wave", &x266hip_ctx::satd_groups_per_wave, 1, 4096, 1},
+    {"tr_tiles_per_wave", &x266hip_ctx::tr_tiles_per_wave, 1, 64, 1},
+    {"wg_threads", &x266hip_ctx::wg_threads, 64, 256, 64},
+    {"satd_wg_threads", &x266hip_ctx::satd_wg_threads, 64, 256, 64},
+    {"dct32_wg_threads", &x266hip_ctx::dct_wg_threads, 64, 256, 64},
+    {"dct32_inv_wg_threads", &x266hip_ctx::dct_inv_wg_threads, 64, 256, 64},
+    {"dct32_lds_stage", &x266hip_ctx::dct_lds_stage, 0, 1, 1},
+    {"satd_lds_stage", &x266hip_ctx::satd_lds_stage, 0, 1, 1},
+    {"tr_lds_stage", &x266hip_ctx::tr_lds_stage, 0, 1, 1},
+    {"dct32_lds_bytes_per_wave", &x266hip_ctx::dct_lds_per_wave, 2048, 40960, 1},
+    {"dct32_inv_lds_bytes_per_wave", &x266hip_ctx::dct_inv_lds_per_wave, 2048, 40960, 1},
+    {"satd_lds_bytes_per_wave", &x266hip_ctx::satd_lds_per_wave, 2048, 40960, 1},
+    {"dct32_lds_pad_bytes", &x266hip_ctx::lds_pad_dct, 0, 160 * 1024, 1},
+    {"dct32_inv_lds_pad_bytes", &x266hip_ctx::lds_pad_inv, 0, 160 * 1024, 1},
+    {"satd_lds_pad_bytes", &x266hip_ctx::lds_pad_satd, 0, 160 * 1024, 1},
+    {"me_tile_rows", &x266hip_ctx::me_tile_rows, 1, 4, 1},
+    {"me_variant", &x266hip_ctx::me_variant, 1, 2, 1},
+    {"me_row_pairs", &x266hip_ctx::me_row_pairs, 1, 3, 1},
+    {"diag_passthrough", &x266hip_ctx::passthrough, 0, 1, 1},
+    {"diag_tr32_simple", &x266hip_ctx::tr32_simple, 0, 1, 1},
+};
+
+static const OptionDesc *find_option(const char *key)
 {
-    if (!ctx || !key) return nullptr;
-    if (!std::strcmp(key, "dct32_wgs_per_cu")) return &ctx->wgs_per_cu_dct;
-    if (!std::strcmp(key, "dct32_inv_wgs_per_cu")) return &ctx->wgs_per_cu_inv;
-    if (!std::strcmp(key, "satd_wgs_per_cu")) return &ctx->wgs_per_cu_satd;
-    if (!std::strcmp(key, "nontemporal")) return &ctx->nontemporal;
-    if (!std::strcmp(key, "adaptive_per_wave")) return &ctx->adaptive_per_wave;
-    if (!std::strcmp(key, "dct32_variant")) return &ctx->dct_variant;
-    if (!std::strcmp(key, "satd_variant")) return &ctx->satd_variant;
-    if (!std::strcmp(key, "dct32_blocks_per_wave")) return &ctx->dct_blocks_per_wave;
-    if (!std::strcmp(key, "dct32_inv_blocks_per_wave")) return &ctx->dct_inv_blocks_per_wave;
-    if (!std::strcmp(key, "dct32_fwdinv_blocks_per_wave")) return &ctx->dct_fwdinv_blocks_per_wave;
-    if (!std::strcmp(key, "satd_groups_per_wave")) return &ctx->satd_groups_per_wave;
-    if (!std::strcmp(key, "wg_threads")) return &ctx->wg_threads;
-    if (!std::strcmp(key, "satd_wg_threads")) return &ctx->satd_wg_threads;
-    if (!std::strcmp(key, "diag_passthrough")) return &ctx->passthrough;
-    if (!std::strcmp(key, "me_tile_rows")) return &ctx->me_tile_rows;
-    if (!std::strcmp(key, "dct32_lds_stage")) return &ctx->dct_lds_stage;
-    if (!std::strcmp(key, "dct32_lds_bytes_per_wave")) return &ctx->dct_lds_per_wave;
-    if (!std::strcmp(key, "dct32_inv_lds_bytes_per_wave")) return &ctx->dct_inv_lds_per_wave;
-    if (!std::strcmp(key, "satd_lds_bytes_per_wave")) return &ctx->satd_lds_per_wave;
-    if (!std::strcmp(key, "dct32_wg_threads")) return &ctx->dct_wg_threads;
-    if (!std::strcmp(key, "dct32_inv_wg_threads")) return &ctx->dct_inv_wg_threads;
-    if (!std::strcmp(key, "satd_lds_stage")) return &ctx->satd_lds_stage;
-    if (!std::strcmp(key, "tr_tiles_per_wave")) return &ctx->tr_tiles_per_wave;
-    if (!std::strcmp(key, "tr_lds_stage")) return &ctx->tr_lds_stage;
-    if (!std::strcmp(key, "diag_tr32_simple")) return &ctx->tr32_simple;
-    if (!std::strcmp(key, "me_variant")) return &ctx->me_variant;
-    if (!std::strcmp(key, "me_row_pairs")) return &ctx->me_row_pairs;
-    if (!std::strcmp(key, "dct32_lds_pad_bytes")) return &ctx->lds_pad_dct;
-    if (!std::strcmp(key, "dct32_inv_lds_pad_bytes")) return &ctx->lds_pad_inv;
-    if (!std::strcmp(key, "satd_lds_pad_bytes")) return &ctx->lds_pad_satd;
+    if (!key) return nullptr;
+    for (const OptionDesc &o : kOptions)
+        if (!std::strcmp(key, o.key)) return &o;
     return nullptr;
 }
 
 int xHipSetOption(x266hip_ctx *ctx, const char *key, int value)
 {
-    int *slot = option_slot(ctx, key);
-    if (!slot) return X266HIP_EINVAL;
-    if (std::strstr(key, "wgs_per_cu") && (value < 1 || value > 64)) return fail(ctx, X266HIP_EINVAL, "wgs_per_cu out of range");
-    if (!std::strcmp(key, "tr_tiles_per_wave") && (value < 1 || value > 64)) return fail(ctx, X266HIP_EINVAL, "tiles per wave out of range");
-    if (std::strstr(key, "_per_wave") && !std::strstr(key, "lds_bytes") && std::strcmp(key, "tr_tiles_per_wave") && std::strcmp(key, "adaptive_per_wave") && (value < 1 || value > 4096)) return fail(ctx, X266HIP_EINVAL, "units per wave out of range");
-    if (std::strstr(key, "lds_pad_bytes") && (value < 0 || value > 160 * 1024)) return fail(ctx, X266HIP_EINVAL, "lds pad out of range");
-    if (std::strstr(key, "lds_bytes_per_wave") && (value < 2048 || value > 40960)) return fail(ctx, X266HIP_EINVAL, "lds bytes per wave out of range");
-    if (std::strstr(key, "_wg_threads") && (value < 64 || value > 256 || value % 64)) return fail(ctx, X266HIP_EINVAL, "wg_threads must be 64, 128, 192 or 256");
-    if (!std::strcmp(key, "wg_threads") && (value < 64 || value > 256 || value % 64)) return fail(ctx, X266HIP_EINVAL, "wg_threads must be 64, 128, 192 or 256");
-    *slot = value;
+    if (!ctx) return X266HIP_EINVAL;
+    const OptionDesc *o = find_option(key);
+    if (!o) return fail(ctx, X266HIP_EINVAL, "unknown option");
+    if (value < o->lo || value > o->hi || value % o->multiple_of) return fail(ctx, X266HIP_EINVAL, "option value out of range");
+    ctx->*(o->member) = value;
     return X266HIP_OK;
 }
 
 int xHipGetOption(const x266hip_ctx *ctx, const char *key, int *value)
 {
-    int *slot = option_slot(const_cast<x266hip_ctx *>(ctx), key);
-    if (!slot || !value) return X266HIP_EINVAL;
-    *value = *slot;
+    const OptionDesc *o = find_option(key);
+    if (!ctx || !o || !value) return X266HIP_EINVAL;
+    *value = ctx->*(o->member);
     return X266HIP_OK;
 }
 
