@@ -73,6 +73,19 @@ def test_dct32_fwd_ragged_counts(codec, oracle, n):
         assert np.array_equal(got, oracle.dct32_fwd(x))
 
 
+def test_valu_butterfly_variant_is_bit_identical(codec, oracle):
+    """dct32_variant = 2: the reference's even/odd decomposition on the vector ALU (comparison variant)."""
+    x = np.concatenate([_mixed(777, 1024, 55), dct_edge_blocks()[0]])
+    want = oracle.dct32_fwd(x, threads=8)
+    codec.set_option("dct32_variant", 2)
+    try:
+        assert np.array_equal(codec.dct32_fwd(x), want)
+        assert np.array_equal(codec.dct32_fwd(x[:1]), want[:1])
+        assert np.array_equal(codec.dct32_inv(want), oracle.dct32_inv(want, threads=8))      # inverse unaffected
+    finally:
+        codec.set_option("dct32_variant", 0)
+
+
 # ---------------------------------------------------------------- DCT32 inverse
 def test_dct32_inv_vs_oracle(codec, oracle):
     x = _mixed(1500, 1024, 301)

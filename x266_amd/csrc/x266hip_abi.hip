@@ -32,7 +32,7 @@ struct x266hip_ctx {
     int wgs_per_cu_inv = 5;
     int wgs_per_cu_satd = 8;
     int nontemporal = 11;            // see LaunchCfg: nt loads + "sc1 nt" stores in the line-dense kernels (+3-5 %), none on fragment loads
-    int dct_variant = 0, satd_variant = 0;          // 0 streaming launch, 1 persistent
+    int dct_variant = 0, satd_variant = 0;          // 0 streaming launch, 1 persistent; dct 2 = VALU butterfly (comparison only)
     // streaming launch: consecutive units per wave (measured optimum on MI355X, profiles/r01_sweep.txt)
     int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 2;
     int dct_fwdinv_blocks_per_wave = 4;
@@ -92,13 +92,13 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
     c.wgs_per_cu = op == 0 ? ctx->wgs_per_cu_dct : (op == 1 ? ctx->wgs_per_cu_inv : ctx->wgs_per_cu_satd);
     c.nontemporal = ctx->nontemporal;
     c.adaptive = ctx->adaptive_per_wave;
-    c.variant = op == 2 ? ctx->satd_variant : ctx->dct_variant;
+    c.variant = op == 2 ? ctx->satd_variant : (ctx->dct_variant == 2 ? 0 : ctx->dct_variant);   // 2 = butterfly, forward only
     c.units_per_wave = op == 2 ? ctx->satd_groups_per_wave : (op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave);
     c.wg_threads = op == 2 ? ctx->satd_wg_threads : ctx->wg_threads;
     c.passthrough = ctx->passthrough;
     c.lds_stage = op == 2 ? ctx->satd_lds_stage : ctx->dct_lds_stage;
     c.lds_bytes_per_wave = op == 2 ? ctx->satd_lds_per_wave : (op == 1 ? ctx->dct_inv_lds_per_wave : ctx->dct_lds_per_wave);
-    if (op != 2 && ctx->dct_lds_stage && ctx->dct_variant == 0) c.wg_threads = op == 1 ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
+    if (op != 2 && ctx->dct_lds_stage && c.variant == 0) c.wg_threads = op == 1 ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
     c.lds_pad_bytes = op == 2 ? ctx->lds_pad_satd : (op == 1 ? ctx->lds_pad_inv : ctx->lds_pad_dct);
     return c;
 }
@@ -107,7 +107,10 @@ int launch_op(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n,
 {
     hipError_t e;
     switch (op) {
-    case 0: e = launch_dct32(false, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_fwd, nullptr, cfg_for(ctx, 0), s); break;
+    case 0:
+        if (ctx->dct_variant == 2) e = launch_dct32_butterfly((const int16_t *)d_in, (int16_t *)d_out, n, s);   // VALU comparison variant
+        else e = launch_dct32(false, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_fwd, nullptr, cfg_for(ctx, 0), s);
+        break;
     case 1: e = launch_dct32(true, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_inv, ctx->d_inv_lds, cfg_for(ctx, 1), s); break;
     case 2: e = launch_satd8x8((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s); break;
     default: return fail(ctx, X266HIP_EINVAL, "unknown op");
@@ -239,7 +242,7 @@ static const OptionDesc kOptions[] = {
     {"satd_wgs_per_cu", &x266hip_ctx::wgs_per_cu_satd, 1, 64, 1},
     {"nontemporal", &x266hip_ctx::nontemporal, 0, 15, 1},
     {"adaptive_per_wave", &x266hip_ctx::adaptive_per_wave, 0, 1, 1},
-    {"dct32_variant", &x266hip_ctx::dct_variant, 0, 1, 1},
+    {"dct32_variant", &x266hip_ctx::dct_variant, 0, 2, 1},
     {"satd_variant", &x266hip_ctx::satd_variant, 0, 1, 1},
     {"dct32_blocks_per_wave", &x266hip_ctx::dct_blocks_per_wave, 1, 4096, 1},
     {"dct32_inv_blocks_per_wave", &x266hip_ctx::dct_inv_blocks_per_wave, 1, 4096, 1},
