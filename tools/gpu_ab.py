@@ -48,3 +48,32 @@ for rnd in range(6):
         best[tag] = min(best[tag], t_fused(L, ctx))
 print("fused ref %.4f ms %.3f TB/s | new %.4f ms %.3f TB/s | new/ref time %.4f" % (
     best["ref"], N * 6144 / best["ref"] / 1e9, best["new"], N * 6144 / best["new"] / 1e9, best["new"] / best["ref"]), flush=True)
+
+# ---- motion search (one 4K frame, +-64) and intra mode decision (2^17 blocks), wall-clock
+w, h, rng = 3840, 2160, 64
+stride = w + 2 * rng + 16
+cur, refp, bestb = P(), P(), P()
+L0.xHipMalloc(c0, ctypes.byref(cur), w * h); L0.xHipMalloc(c0, ctypes.byref(refp), stride * (h + 2 * rng + 16)); L0.xHipMalloc(c0, ctypes.byref(bestb), (w // 8) * (h // 8) * 8)
+L0.xFillResidualDev(c0, cur, w * h // 2, 1, 0, None); L0.xFillResidualDev(c0, refp, stride * (h + 2 * rng + 16) // 2, 2, 0, None)
+nb = 1 << 17
+irefs, isrc, icost, ibest = P(), P(), P(), P()
+L0.xHipMalloc(c0, ctypes.byref(irefs), nb * 144); L0.xHipMalloc(c0, ctypes.byref(isrc), nb * 1024); L0.xHipMalloc(c0, ctypes.byref(icost), nb * 35 * 4); L0.xHipMalloc(c0, ctypes.byref(ibest), nb)
+L0.xFillResidualDev(c0, irefs, nb * 72, 3, 0, None); L0.xFillResidualDev(c0, isrc, nb * 512, 4, 0, None); L0.xHipStreamSync(c0, None)
+def wall(fn, L, ctx, reps):
+    for _ in range(2): fn(L, ctx)
+    L.xHipStreamSync(ctx, None); t0 = time.perf_counter()
+    for _ in range(reps): fn(L, ctx)
+    L.xHipStreamSync(ctx, None); return (time.perf_counter() - t0) / reps * 1e3
+def me(L, ctx):
+    L.xSatd8x8SearchDev.argtypes = [P, P, ctypes.c_ssize_t, P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, P, P]
+    assert L.xSatd8x8SearchDev(ctx, cur, w, P(refp.value + rng * stride + rng), stride, w, h, rng, bestb, None, None) == 0
+def intra(L, ctx):
+    L.xIntra32CostsDev.argtypes = [P, P, P, P, P, ctypes.c_size_t, P]
+    assert L.xIntra32CostsDev(ctx, irefs, isrc, icost, ibest, nb, None) == 0
+for name, fn, reps in (("me 4K", me, 5), ("intra decide", intra, 10)):
+    best = {"ref": 1e9, "new": 1e9}
+    for rnd in range(4):
+        for tag, (L, ctx) in libs:
+            if hasattr(L, "xIntra32CostsDev") or name != "intra decide":
+                best[tag] = min(best[tag], wall(fn, L, ctx, reps))
+    print("%-12s ref %.4f ms | new %.4f ms | new/ref time %.4f" % (name, best["ref"], best["new"], best["new"] / best["ref"]), flush=True)

@@ -155,13 +155,14 @@ __device__ __forceinline__ bool predict_line16(int mode, const unsigned char *le
 }
 
 // lane (k, h) holds samples 16h..16h+15 of COLUMN k: scatter them into a row-major 32x32 byte tile
+template <int PITCH>
 __device__ __forceinline__ void scatter_column(unsigned char *tile, int lane, const uint32_t (&px)[4])
 {
     const int k = lane >> 1, h = lane & 1;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) tile[(16 * h + 4 * g + jj) * 32 + k] = (unsigned char)(px[g] >> (8 * jj));
+        for (int jj = 0; jj < 4; ++jj) tile[(16 * h + 4 * g + jj) * PITCH + k] = (unsigned char)(px[g] >> (8 * jj));
 }
 
 __global__ __launch_bounds__(256) void intra32_predict_kernel(const x266_intra_ref_t *__restrict__ refs,
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void intra32_predict_kernel(const x266_intra_r
         const unsigned char *left = raw_all + j * kRawBytes, *top = left + 64;   // top[0] = corner
         uint32_t px[4];
         if (predict_line16(mode, left, top, ext, lane, px)) {    // columns: turn through the tile
-            scatter_column(tile, lane, px);
+            scatter_column<32>(tile, lane, px);
             __builtin_amdgcn_wave_barrier();
             const v4i row = *reinterpret_cast<const v4i *>(tile + lane * 16);
             px[0] = (uint32_t)row[0]; px[1] = (uint32_t)row[1]; px[2] = (uint32_t)row[2]; px[3] = (uint32_t)row[3];
@@ -217,7 +218,11 @@ __global__ __launch_bounds__(256) void intra32_predict_kernel(const x266_intra_r
 // wrap int16, so satd(src - pred) = (sum |H src - H pred| + 2) >> 2 per sub-block (as in me_kernels.hip):
 // H src is formed once per block, H pred once per mode -- two modes per matrix-core pass, their
 // 16 + 16 sub-blocks being the 32 columns of the 64x64x32 Hadamard GEMM -- and scored with v_sad_u16.
-constexpr int kCostSlot = 16 + kRawBytes + kExtBytes + 1024 + 2048;   // raw | ext | src tile | two prediction tiles
+// Tiles of the decision kernel have a 40-byte row pitch and the second prediction tile starts 32 bytes past a
+// 256-byte boundary: the 8-byte window reads of the 16 + 16 sub-blocks then fall into 32 distinct bank pairs
+// (with a 32-byte pitch all four sub-block rows and both tiles share banks: 8-way conflicts).
+constexpr int kPitch = 40, kTile = 32 * kPitch, kTileB = kTile + 32;
+constexpr int kCostSlot = 16 + kRawBytes + kExtBytes + kTile + kTileB + kTile;   // raw | ext | src tile | two prediction tiles
 
 __global__ __launch_bounds__(256) void intra32_costs_kernel(const x266_intra_ref_t *__restrict__ refs,
                                                             const uint8_t *__restrict__ src,
@@ -230,21 +235,26 @@ __global__ __launch_bounds__(256) void intra32_costs_kernel(const x266_intra_ref
     const size_t b = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
     if (b >= n) return;
     unsigned char *raw = lds + wave_in_wg * kCostSlot + 16;
-    unsigned char *ext = raw + kRawBytes, *stile = ext + kExtBytes, *ptile = stile + 1024;
+    unsigned char *ext = raw + kRawBytes, *stile = ext + kExtBytes, *ptile = stile + kTile;
     const v4i S = {(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};   // pixels -> signed; the offset cancels
 
     if (lane < 9) *reinterpret_cast<v4i *>(raw + lane * 16) = load16<true>(reinterpret_cast<const unsigned char *>(refs + b) + lane * 16);
-    *reinterpret_cast<v4i *>(stile + lane * 16) = load16<true>(src + b * 1024 + lane * 16) ^ S;
+    {
+        const v4i sv = load16<true>(src + b * 1024 + lane * 16) ^ S;
+        unsigned char *d = stile + (lane >> 1) * kPitch + (lane & 1) * 16;                      // 8-byte aligned rows
+        *reinterpret_cast<uint2 *>(d) = make_uint2((uint32_t)sv[0], (uint32_t)sv[1]);
+        *reinterpret_cast<uint2 *>(d + 8) = make_uint2((uint32_t)sv[2], (uint32_t)sv[3]);
+    }
     __builtin_amdgcn_wave_barrier();
     const unsigned char *left = raw, *top = raw + 64;
 
     // lane (n, half): rows 4*half .. +3 of sub-block n & 15 (sy = bits 3:2, sx = bits 1:0); columns 16..31 repeat 0..15
     const int nn = lane & 31, half = lane >> 5, sb = nn & 15;
-    const unsigned frag = (unsigned)((8 * (sb >> 2) + 4 * half) * 32 + 8 * (sb & 3));
+    const unsigned frag = (unsigned)((8 * (sb >> 2) + 4 * half) * kPitch + 8 * (sb & 3));
     const HadamardOps H = make_hadamard_ops(lane);
     auto window = [&](const unsigned char *tile, v4i &w0, v4i &w1) {
-        const uint2 r0 = *reinterpret_cast<const uint2 *>(tile + frag), r1 = *reinterpret_cast<const uint2 *>(tile + frag + 32);
-        const uint2 r2 = *reinterpret_cast<const uint2 *>(tile + frag + 64), r3 = *reinterpret_cast<const uint2 *>(tile + frag + 96);
+        const uint2 r0 = *reinterpret_cast<const uint2 *>(tile + frag), r1 = *reinterpret_cast<const uint2 *>(tile + frag + kPitch);
+        const uint2 r2 = *reinterpret_cast<const uint2 *>(tile + frag + 2 * kPitch), r3 = *reinterpret_cast<const uint2 *>(tile + frag + 3 * kPitch);
         w0 = v4i{(int)r0.x, (int)r0.y, (int)r1.x, (int)r1.y};
         w1 = v4i{(int)r2.x, (int)r2.y, (int)r3.x, (int)r3.y};
     };
@@ -265,13 +275,18 @@ __global__ __launch_bounds__(256) void intra32_costs_kernel(const x266_intra_ref
             const bool columns = predict_line16(mode, left, top, ext, lane, px);
 #pragma unroll
             for (int g = 0; g < 4; ++g) px[g] ^= 0x80808080u;
-            unsigned char *tile = ptile + t * 1024;
-            if (columns) scatter_column(tile, lane, px);
-            else         *reinterpret_cast<v4i *>(tile + lane * 16) = v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]};
+            unsigned char *tile = ptile + t * kTileB;
+            if (columns) {
+                scatter_column<kPitch>(tile, lane, px);
+            } else {
+                unsigned char *d = tile + (lane >> 1) * kPitch + (lane & 1) * 16;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(px[0], px[1]);
+                *reinterpret_cast<uint2 *>(d + 8) = make_uint2(px[2], px[3]);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         v4i w0, w1;
-        window(ptile + (nn >> 4) * 1024, w0, w1);
+        window(ptile + (nn >> 4) * kTileB, w0, w1);
         uint32_t p[16];
         hadamard_pack(H, w0, w1, p);
         uint32_t s = 0;
