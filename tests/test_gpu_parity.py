@@ -145,6 +145,20 @@ def test_satd_random_vs_oracle(codec, oracle):
     assert np.array_equal(codec.satd8x8(d), oracle.satd8x8(d, threads=8))
 
 
+def test_satd_valu_butterfly_variant_is_bit_identical(codec, oracle):
+    """satd_variant = 2: radix-2 butterflies in packed int16 on the vector ALU (comparison variant)."""
+    edge, _ = satd_edge_blocks()
+    codec.set_option("satd_variant", 2)
+    try:
+        for n in (1, 63, 64, 65, 4097):
+            d = fullrange_np(n * 64, 900 + n).reshape(-1, 64)
+            assert np.array_equal(codec.satd8x8(d), oracle.satd8x8(d)), n
+        d = np.concatenate([_mixed(20000, 64, 41), edge])
+        assert np.array_equal(codec.satd8x8(d), oracle.satd8x8(d, threads=8))
+    finally:
+        codec.set_option("satd_variant", 0)
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 31, 32, 33, 63, 64, 65, 127, 1000, 4097])
 def test_satd_ragged_counts(codec, oracle, n):
     d = fullrange_np(max(n, 1) * 64, 500 + n)[: n * 64].reshape(-1, 64)

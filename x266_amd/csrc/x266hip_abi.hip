@@ -112,7 +112,10 @@ int launch_op(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n,
         else e = launch_dct32(false, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_fwd, nullptr, cfg_for(ctx, 0), s);
         break;
     case 1: e = launch_dct32(true, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_inv, ctx->d_inv_lds, cfg_for(ctx, 1), s); break;
-    case 2: e = launch_satd8x8((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s); break;
+    case 2:
+        if (ctx->satd_variant == 2) e = launch_satd8x8_butterfly((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s);   // VALU comparison variant
+        else e = launch_satd8x8((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s);
+        break;
     default: return fail(ctx, X266HIP_EINVAL, "unknown op");
     }
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "kernel launch", e);
@@ -243,7 +246,7 @@ static const OptionDesc kOptions[] = {
     {"nontemporal", &x266hip_ctx::nontemporal, 0, 15, 1},
     {"adaptive_per_wave", &x266hip_ctx::adaptive_per_wave, 0, 1, 1},
     {"dct32_variant", &x266hip_ctx::dct_variant, 0, 2, 1},
-    {"satd_variant", &x266hip_ctx::satd_variant, 0, 1, 1},
+    {"satd_variant", &x266hip_ctx::satd_variant, 0, 2, 1},
     {"dct32_blocks_per_wave", &x266hip_ctx::dct_blocks_per_wave, 1, 4096, 1},
     {"dct32_inv_blocks_per_wave", &x266hip_ctx::dct_inv_blocks_per_wave, 1, 4096, 1},
     {"dct32_fwdinv_blocks_per_wave", &x266hip_ctx::dct_fwdinv_blocks_per_wave, 1, 4096, 1},
