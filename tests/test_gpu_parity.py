@@ -427,3 +427,36 @@ def test_batches_larger_than_4_gib(codec, oracle):
         d = sample(din, first, count, np.int16, 64)
         got = sample(cost, first, count, np.uint32, 1).ravel()
         assert np.array_equal(got, oracle.satd8x8(d)), first
+
+
+# ---------------------------------------------------------------- threads
+def test_two_host_threads_two_contexts(oracle):
+    """The batch API is thread-safe per context (include/x266hip.h): two host threads, each with its own
+    context on the same device, run forward / inverse / SATD batches concurrently through the host-pointer
+    and device-pointer entry points (ctypes releases the GIL during the calls)."""
+    import threading
+    import x266_amd
+    x = residual_np(3000 * 1024, 0xABC).reshape(-1, 1024)
+    want = oracle.dct32_fwd(x, threads=8)
+    want_inv = oracle.dct32_inv(want, threads=8)
+    d = x.reshape(-1, 64)[:70000]
+    want_s = oracle.satd8x8(d, threads=8)
+    errors = []
+
+    def worker(tid):
+        try:
+            cd = x266_amd.Codec(0)
+            for rep in range(6):
+                lo = (tid * 7 + rep * 13) % 500
+                assert np.array_equal(cd.dct32_fwd(x[lo:]), want[lo:])
+                assert np.array_equal(cd.dct32_inv(want[lo:]), want_inv[lo:])
+                assert np.array_equal(cd.satd8x8(d[lo:]), want_s[lo:])
+        except Exception as e:                               # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
