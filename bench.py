@@ -433,6 +433,43 @@ def main():
             also["fused_from_tiles"] = fused
             del tcur, tpred, fcoef, fcost, fres
 
+        # ---- frame container conversion, residual formation, SAD -- pure data movement, HBM-bound
+        if not args.no_transform_set:
+            fw2, fh2 = 16384, 16384                                      # 256 Mi luma samples
+            npx = fw2 * fh2
+            g = torch.Generator(device="cuda")
+            g.manual_seed(0x77 + rank)
+            ypl = torch.randint(0, 256, (npx,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
+            upl = ypl[: npx // 4].clone()
+            vpl = ypl[npx // 4: npx // 2].clone()
+            t_a = torch.zeros(npx * 2, dtype=torch.uint8, device="cuda")  # 512-byte tiles: 2 bytes per luma sample
+            t_b = torch.zeros(npx * 2, dtype=torch.uint8, device="cuda")
+            res2 = torch.empty(npx, dtype=torch.int16, device="cuda")
+            sad_o = torch.empty(npx // 64, dtype=torch.int32, device="cuda")
+            front = {}
+            for name, nbytes, fn in (
+                    ("conv_input_fmt", 3.0 * npx, lambda: codec.conv_input_fmt_dev(t_a.data_ptr(), ypl.data_ptr(), upl.data_ptr(), vpl.data_ptr(), fw2, fw2, fh2, stream)),
+                    ("conv_output_420", 3.0 * npx, lambda: codec.conv_output_420_dev(t_a.data_ptr(), ypl.data_ptr(), fw2, upl.data_ptr(), vpl.data_ptr(), fw2 // 2, fw2, fh2, stream)),
+                    ("residual_luma_32", 4.0 * npx, lambda: codec.residual_luma_dev(t_a.data_ptr(), t_b.data_ptr(), fw2, fh2, 32, res2.data_ptr(), stream)),
+                    ("sad_8x8", 2.0 * npx + 4.0 * (npx // 64), lambda: codec.sad_dev(8, ypl.data_ptr(), t_b.data_ptr(), sad_o.data_ptr(), npx // 64, stream)),
+                    ("sad_16x16", 2.0 * npx + 4.0 * (npx // 256), lambda: codec.sad_dev(16, ypl.data_ptr(), t_b.data_ptr(), sad_o.data_ptr(), npx // 256, stream)),
+                    ("sad_64x64", 2.0 * npx + 4.0 * (npx // 4096), lambda: codec.sad_dev(64, ypl.data_ptr(), t_b.data_ptr(), sad_o.data_ptr(), npx // 4096, stream))):
+                steps_f = max(2, args.steps // 4)
+                for _ in range(5):
+                    fn()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(steps_f):
+                    fn()
+                barrier()
+                wall_ff = max_over_ranks(time.perf_counter() - t0) / steps_f
+                front[name] = {"GBps": world * nbytes / wall_ff / 1e9, "hbm_frac": nbytes / wall_ff / HBM_PEAK_BYTES_PER_S,
+                               "samples_per_s": world * npx / wall_ff}
+            front["note"] = ("%dx%d frame; bytes = planes read + tile bytes written (conv), luma of both tile frames + int16 residual "
+                             "(residual), both blocks + 4-byte result (sad)" % (fw2, fh2))
+            also["front_end_and_sad"] = front
+            del ypl, upl, vpl, t_a, t_b, res2, sad_o
+
         # ---- 32x32 intra prediction and mode decision (HEVC 35 modes; parity unpinned upstream)
         if not args.no_transform_set:
             g = torch.Generator(device="cuda")

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void sad_kernel(const uint8_t *__restrict__ a,
         size_t off = (first * CPB + (size_t)it * 64 + lane) * 16;
         const bool live = off + 16 <= total;
         if (!live) off = total - 16;                        // ragged tail
-        const v4i va = *reinterpret_cast<const v4i *>(a + off), vb = *reinterpret_cast<const v4i *>(b + off);
+        const v4i va = load16<true>(a + off), vb = load16<true>(b + off);      // line-dense, read once: streaming hint
         const uint32_t part = sad_chunk(va, vb, 0);
         s += live ? part : 0u;
     }

@@ -11,7 +11,11 @@
 // src/x266.cpp:526-555) -- and is defined in include/x266hip.h.
 //
 // Pure data movement, HBM-bound.  One thread per 16-byte luma row of a tile; the first 8 rows of
-// a tile also carry its chroma row (8 U + 8 V bytes <-> 16 interleaved bytes).
+// a tile also carry its chroma row (8 U + 8 V bytes <-> 16 interleaved bytes).  A wave takes eight
+// horizontally adjacent tiles x eight rows (lane = 8 * row + tile): on the planar side eight lanes
+// then cover one whole 128-byte line of a picture row, on the tile side the eight rows of a tile are
+// one whole line, and the residual rows of a block pair are contiguous -- every load and store
+// instruction consumes whole lines, which is what lets the streaming cache hints pay.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -26,32 +30,60 @@ __device__ __forceinline__ uint32_t bperm(uint32_t hi_src, uint32_t lo_src, uint
     return __builtin_amdgcn_perm(hi_src, lo_src, sel);
 }
 
+// wave -> (tile row ty, group of 8 tiles, upper / lower half of the tiles); lane -> (row, tile)
+struct TileRow {
+    size_t tile;      // tile index in the frame raster
+    size_t ty, tx;
+    int i;            // luma row inside the tile, 0..15
+    bool live;        // this lane's tile exists
+    bool unit_live;   // the wave's (tile row, group, half) exists: false for the whole wave at once
+};
+
+__device__ __forceinline__ TileRow tile_row_of_thread(int tiles_x, int groups_x, size_t n_units)
+{
+    const size_t unit = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // (ty, group, half)
+    const int lane = threadIdx.x & 63;
+    TileRow r;
+    r.unit_live = unit < n_units;
+    r.live = r.unit_live;
+    const size_t u = r.live ? unit : 0;
+    const int half = (int)(u & 1);
+    const size_t gq = u >> 1;
+    r.ty = gq / groups_x;
+    r.tx = (gq - r.ty * groups_x) * 8 + (lane & 7);
+    r.i = 8 * half + (lane >> 3);
+    r.live = r.live && r.tx < (size_t)tiles_x;
+    if (r.tx >= (size_t)tiles_x) r.tx = tiles_x - 1;
+    r.tile = r.ty * tiles_x + r.tx;
+    return r;
+}
+
 // PACK: planar -> tiles, else tiles -> planar
 template <bool PACK>
 __global__ __launch_bounds__(256) void tile_convert_kernel(x266_ref_block_t *tiles, uint8_t *y, uint8_t *u, uint8_t *v,
-                                                           long long strd_y, long long strd_c, int tiles_x, size_t n_rows)
+                                                           long long strd_y, long long strd_c, int tiles_x, int groups_x,
+                                                           size_t n_units)
 {
-    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, luma row)
-    if (id >= n_rows) return;
-    const size_t tile = id >> 4;
-    const int i = (int)(id & 15);
-    const size_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    uint8_t *t = reinterpret_cast<uint8_t *>(tiles + tile);
-    uint8_t *py = y + (long long)(ty * 16 + i) * strd_y + tx * 16;
-    if (PACK) *reinterpret_cast<v4i *>(t + i * 16) = *reinterpret_cast<const v4i *>(py);
-    else      *reinterpret_cast<v4i *>(py) = *reinterpret_cast<const v4i *>(t + i * 16);
+    const TileRow r = tile_row_of_thread(tiles_x, groups_x, n_units);
+    if (!r.live) return;
+    const int i = r.i;
+    uint8_t *t = reinterpret_cast<uint8_t *>(tiles + r.tile);
+    uint8_t *py = y + (long long)(r.ty * 16 + i) * strd_y + r.tx * 16;
+    if (PACK) store16_sc1nt(t + i * 16, load16<true>(py));
+    else      store16_sc1nt(py, load16<true>(t + i * 16));
     if (i < 8) {
-        uint8_t *pu = u + (long long)(ty * 8 + i) * strd_c + tx * 8;
-        uint8_t *pv = v + (long long)(ty * 8 + i) * strd_c + tx * 8;
+        uint8_t *pu = u + (long long)(r.ty * 8 + i) * strd_c + r.tx * 8;
+        uint8_t *pv = v + (long long)(r.ty * 8 + i) * strd_c + r.tx * 8;
         uint32_t *c = reinterpret_cast<uint32_t *>(t + 256 + i * 16);
         if (PACK) {
             const uint2 a = *reinterpret_cast<const uint2 *>(pu), b = *reinterpret_cast<const uint2 *>(pv);
-            c[0] = bperm(b.x, a.x, 0x05010400u);      // u0 v0 u1 v1
-            c[1] = bperm(b.x, a.x, 0x07030602u);      // u2 v2 u3 v3
-            c[2] = bperm(b.y, a.y, 0x05010400u);
-            c[3] = bperm(b.y, a.y, 0x07030602u);
+            const v4i o = {(int)bperm(b.x, a.x, 0x05010400u),      // u0 v0 u1 v1
+                           (int)bperm(b.x, a.x, 0x07030602u),      // u2 v2 u3 v3
+                           (int)bperm(b.y, a.y, 0x05010400u), (int)bperm(b.y, a.y, 0x07030602u)};
+            store16_sc1nt(c, o);
         } else {
-            const uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+            const v4i cc = load16<true>(c);
+            const uint32_t c0 = (uint32_t)cc[0], c1 = (uint32_t)cc[1], c2 = (uint32_t)cc[2], c3 = (uint32_t)cc[3];
             *reinterpret_cast<uint2 *>(pu) = make_uint2(bperm(c1, c0, 0x06040200u), bperm(c3, c2, 0x06040200u));
             *reinterpret_cast<uint2 *>(pv) = make_uint2(bperm(c1, c0, 0x07050301u), bperm(c3, c2, 0x07050301u));
         }
@@ -63,16 +95,17 @@ __global__ __launch_bounds__(256) void tile_convert_kernel(x266_ref_block_t *til
 template <int LOGB>
 __global__ __launch_bounds__(256) void residual_luma_kernel(const x266_ref_block_t *__restrict__ cur,
                                                             const x266_ref_block_t *__restrict__ pred,
-                                                            int16_t *__restrict__ res, int tiles_x, size_t n_rows)
+                                                            int16_t *__restrict__ res, int tiles_x, int groups_x, size_t n_units)
 {
     constexpr int B = 1 << LOGB;
-    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, luma row)
-    if (id >= n_rows) return;
-    const size_t tile = id >> 4;
-    const int i = (int)(id & 15);
-    const size_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const v4i a = *reinterpret_cast<const v4i *>(reinterpret_cast<const uint8_t *>(cur + tile) + i * 16);
-    const v4i b = *reinterpret_cast<const v4i *>(reinterpret_cast<const uint8_t *>(pred + tile) + i * 16);
+    const TileRow r = tile_row_of_thread(tiles_x, groups_x, n_units);
+    // B = 32 stores cooperatively: lanes whose tile lies beyond the frame edge (clamped to the last tile, so
+    // their loads are valid) stay in the wave; their runs are skipped at the store
+    if (B == 32 ? !r.unit_live : !r.live) return;
+    const int i = r.i;
+    const size_t ty = r.ty, tx = r.tx;
+    const v4i a = load16<true>(reinterpret_cast<const uint8_t *>(cur + r.tile) + i * 16);
+    const v4i b = load16<true>(reinterpret_cast<const uint8_t *>(pred + r.tile) + i * 16);
     uint32_t d[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -85,15 +118,33 @@ __global__ __launch_bounds__(256) void residual_luma_kernel(const x266_ref_block
     const size_t py = ty * 16 + i, px = tx * 16;                           // pixel coordinates of this segment
     const size_t width = (size_t)tiles_x * 16;
     if (B == 32) {
-        const size_t blk = (py >> 5) * (width >> 5) + (px >> 5);
-        int16_t *dst = res + blk * 1024 + (py & 31) * 32 + (px & 31);
-        *reinterpret_cast<v4i *>(dst) = v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
-        *reinterpret_cast<v4i *>(dst + 8) = v4i{(int)d[4], (int)d[5], (int)d[6], (int)d[7]};
+        // A wave's 2 KiB of residual are four 512-byte runs (8 rows x 64 bytes of four 32x32 blocks), but a
+        // lane's 32 bytes are only a quarter line: written straight, every store instruction would touch half
+        // of each line.  Through a wave-private 2 KiB LDS slot the wave stores its runs with two 1 KiB-linear
+        // instructions instead.
+        __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 2048];
+        unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+        const int lane = threadIdx.x & 63, t = lane & 7, rr = lane >> 3;
+        unsigned char *mine = slot + (t >> 1) * 512 + rr * 64 + (t & 1) * 32;
+        *reinterpret_cast<v4i *>(mine) = v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
+        *reinterpret_cast<v4i *>(mine + 16) = v4i{(int)d[4], (int)d[5], (int)d[6], (int)d[7]};
+        __builtin_amdgcn_wave_barrier();
+        const size_t tx0 = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 7) % (size_t)groups_x * 8;   // first tile of the wave's group
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = lane + 64 * j, run = c >> 5;                      // 16-byte chunk of the 2 KiB, its 512-byte run
+            const size_t bx = (tx0 >> 1) + run;                             // block column of that run
+            if (bx * 2 < (size_t)tiles_x) {
+                const size_t blk = (py >> 5) * (width >> 5) + bx;
+                char *dst = reinterpret_cast<char *>(res + blk * 1024 + ((py & 31) & ~7) * 32) + (c & 31) * 16;
+                store16_sc1nt(dst, *reinterpret_cast<const v4i *>(slot + c * 16));
+            }
+        }
     } else {                                                               // two 8x8 blocks side by side
         const size_t blk = (py >> 3) * (width >> 3) + (px >> 3);
         int16_t *dst = res + blk * 64 + (py & 7) * 8;
-        *reinterpret_cast<v4i *>(dst) = v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
-        *reinterpret_cast<v4i *>(dst + 64) = v4i{(int)d[4], (int)d[5], (int)d[6], (int)d[7]};
+        store16_sc1nt(dst, v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]});
+        store16_sc1nt(dst + 64, v4i{(int)d[4], (int)d[5], (int)d[6], (int)d[7]});
     }
 }
 
@@ -102,24 +153,26 @@ __global__ __launch_bounds__(256) void residual_luma_kernel(const x266_ref_block
 hipError_t launch_tile_convert(bool pack, x266_ref_block_t *d_tiles, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
                                long long strd_y, long long strd_c, int width, int height, hipStream_t stream)
 {
-    const int tiles_x = width / 16;
-    const size_t n_rows = (size_t)tiles_x * (height / 16) * 16;
-    if (n_rows == 0) return hipSuccess;
-    dim3 grid((unsigned)((n_rows + 255) / 256)), block(256);
-    if (pack) hipLaunchKernelGGL((tile_convert_kernel<true>), grid, block, 0, stream, d_tiles, d_y, d_u, d_v, strd_y, strd_c, tiles_x, n_rows);
-    else      hipLaunchKernelGGL((tile_convert_kernel<false>), grid, block, 0, stream, d_tiles, d_y, d_u, d_v, strd_y, strd_c, tiles_x, n_rows);
+    const int tiles_x = width / 16, groups_x = (tiles_x + 7) / 8;
+    const size_t n_units = (size_t)groups_x * (height / 16) * 2;           // one wave per (tile row, 8 tiles, half)
+    if (n_units == 0) return hipSuccess;
+    if ((n_units + 3) / 4 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((n_units + 3) / 4)), block(256);
+    if (pack) hipLaunchKernelGGL((tile_convert_kernel<true>), grid, block, 0, stream, d_tiles, d_y, d_u, d_v, strd_y, strd_c, tiles_x, groups_x, n_units);
+    else      hipLaunchKernelGGL((tile_convert_kernel<false>), grid, block, 0, stream, d_tiles, d_y, d_u, d_v, strd_y, strd_c, tiles_x, groups_x, n_units);
     return hipGetLastError();
 }
 
 hipError_t launch_residual_luma(int block_edge, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_res,
                                 int width, int height, hipStream_t stream)
 {
-    const int tiles_x = width / 16;
-    const size_t n_rows = (size_t)tiles_x * (height / 16) * 16;
-    if (n_rows == 0) return hipSuccess;
-    dim3 grid((unsigned)((n_rows + 255) / 256)), block(256);
-    if (block_edge == 32) hipLaunchKernelGGL((residual_luma_kernel<5>), grid, block, 0, stream, d_cur, d_pred, d_res, tiles_x, n_rows);
-    else                  hipLaunchKernelGGL((residual_luma_kernel<3>), grid, block, 0, stream, d_cur, d_pred, d_res, tiles_x, n_rows);
+    const int tiles_x = width / 16, groups_x = (tiles_x + 7) / 8;
+    const size_t n_units = (size_t)groups_x * (height / 16) * 2;
+    if (n_units == 0) return hipSuccess;
+    if ((n_units + 3) / 4 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((n_units + 3) / 4)), block(256);
+    if (block_edge == 32) hipLaunchKernelGGL((residual_luma_kernel<5>), grid, block, 0, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
+    else                  hipLaunchKernelGGL((residual_luma_kernel<3>), grid, block, 0, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
     return hipGetLastError();
 }
 
