@@ -13,10 +13,10 @@ LD(ld_0, "") LD(ld_nt, "nt") LD(ld_sc1, "sc1") LD(ld_sc0sc1, "sc0 sc1") LD(ld_sc
 ST(st_0, "") ST(st_nt, "nt") ST(st_sc1, "sc1") ST(st_sc0sc1, "sc0 sc1") ST(st_sc0sc1nt, "sc0 sc1 nt") ST(st_sc0, "sc0") ST(st_sc1nt, "sc1 nt") ST(st_sc0nt, "sc0 nt")
 
 template <int L, int S, int MODE>
-__global__ __launch_bounds__(64) void k(const char *in, char *out, size_t tiles)
+__global__ __launch_bounds__(64) void k(const char *in, char *out, size_t tiles, unsigned spread = 1)
 {
     extern __shared__ char pad[];
-    const size_t t = blockIdx.x;
+    const size_t t = spread > 1 ? (size_t)(blockIdx.x % spread) * (tiles / spread) + blockIdx.x / spread : (size_t)blockIdx.x;
     if (t >= tiles) return;
     const char *src = in + t * 2048 + threadIdx.x * 16;
     char *dst = out + t * 2048 + threadIdx.x * 16;
@@ -50,19 +50,19 @@ __global__ __launch_bounds__(64) void k(const char *in, char *out, size_t tiles)
 static const char *names[8] = {"-", "nt", "sc1", "sc0 sc1", "sc0 sc1 nt", "sc0", "sc1 nt", "sc0 nt"};
 
 template <int L, int S, int MODE>
-static void run(const char *in, char *out, size_t tiles, size_t lds)
+static void run(const char *in, char *out, size_t tiles, size_t lds, unsigned spread = 1)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
-        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k<L, S, MODE>), dim3((unsigned)tiles), dim3(64), lds, 0, in, out, tiles);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k<L, S, MODE>), dim3((unsigned)tiles), dim3(64), lds, 0, in, out, tiles, spread);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
         if (rep && ms < best) best = ms;
     }
     const double bytes = (MODE == 0 ? 4096.0 : 2048.0) * tiles;
-    printf("%-5s load[%-10s] store[%-10s] lds=%5zu : %.4f ms  %.3f TB/s\n", MODE == 0 ? "copy" : (MODE == 1 ? "read" : "write"),
+    printf("%-5s spread=%5u load[%-10s] store[%-10s] lds=%5zu : %.4f ms  %.3f TB/s\n", MODE == 0 ? "copy" : (MODE == 1 ? "read" : "write"), spread,
            MODE == 2 ? "" : names[L], MODE == 1 ? "" : names[S], lds, best, bytes / best / 1e9);
     fflush(stdout);
 }
@@ -73,6 +73,12 @@ int main()
     char *in, *out;
     if (hipMalloc(&in, bytes) != hipSuccess || hipMalloc(&out, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(in, 1, bytes); hipMemset(out, 0, bytes); hipDeviceSynchronize();
+    if (getenv("SPREAD_ONLY")) {
+        for (int rep = 0; rep < 2; ++rep)
+            for (unsigned sp : {1u, 2u, 8u, 64u, 256u, 1024u, 4096u, 16384u, 65536u}) { run<1, 6, 0>(in, out, tiles, 8192, sp); }
+        for (unsigned sp : {1u, 64u, 4096u}) { run<1, 0, 1>(in, out, tiles, 8192, sp); run<0, 6, 2>(in, out, tiles, 8192, sp); }
+        return 0;
+    }
     for (size_t lds : {(size_t)8192}) {
 #define COPY(L, S) run<L, S, 0>(in, out, tiles, lds)
         COPY(0, 0); COPY(1, 1); COPY(0, 1); COPY(1, 0);
