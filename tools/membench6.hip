@@ -47,6 +47,69 @@ __global__ __launch_bounds__(64) void k(const char *in, char *out, size_t tiles,
     if (S == 7) { st_sc0nt(dst, a); st_sc0nt(dst + 1024, b); }
 }
 
+// plain copy, 16 bytes per lane per instruction, ITER instructions per lane, TPB threads per workgroup, no LDS
+template <int TPB, int ITER>
+__global__ __launch_bounds__(TPB) void kc(const char *in, char *out, size_t bytes)
+{
+    const size_t wave = ((size_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    const size_t base = wave * (size_t)(ITER * 1024) + (threadIdx.x & 63) * 16;
+    if (base + (ITER - 1) * 1024 + 16 > bytes) return;
+    v4i v[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) v[i] = ld_nt(in + base + i * 1024);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) st_sc1nt(out + base + i * 1024, v[i]);
+}
+template <int TPB, int ITER>
+static void runc(const char *in, char *out, size_t bytes)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const size_t waves = bytes / (ITER * 1024), wgs = (waves + TPB / 64 - 1) / (TPB / 64);
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((kc<TPB, ITER>), dim3((unsigned)wgs), dim3(TPB), 0, 0, in, out, bytes);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+        if (rep && ms < best) best = ms;
+    }
+    printf("plain copy tpb=%3d, %d KiB per wave, no LDS : %.4f ms  %.3f TB/s\n", TPB, ITER, best, 2.0 * bytes / best / 1e9);
+    fflush(stdout);
+}
+
+// conv-like pattern: a workgroup of 8 waves owns 8 tiles (2 KiB each) that lie PITCH bytes apart; every wave
+// instruction takes one 128-byte line of each of the 8 tiles (lane = 8 * tile + chunk)
+template <int PITCH_KB>
+__global__ __launch_bounds__(512) void kc2(const char *in, char *out, size_t bytes)
+{
+    const size_t pitch = (size_t)PITCH_KB * 1024, tiles_per_row = pitch / 2048;
+    const size_t g = blockIdx.x, band = g / tiles_per_row, col = g % tiles_per_row;      // band = 8 rows of `pitch` bytes
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, q = lane & 7;
+    const size_t base = (band * 8 + r) * pitch + col * 2048 + q * 16;
+    if ((band * 8 + 8) * pitch > bytes) return;
+    const v4i a = ld_nt(in + base + (2 * w) * 128), b = ld_nt(in + base + (2 * w + 1) * 128);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_sc1nt(out + base + (2 * w) * 128, a);
+    st_sc1nt(out + base + (2 * w + 1) * 128, b);
+}
+template <int PITCH_KB>
+static void runc2(const char *in, char *out, size_t bytes)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const size_t wgs = bytes / (8 * 2048);
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((kc2<PITCH_KB>), dim3((unsigned)wgs), dim3(512), 0, 0, in, out, bytes);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+        if (rep && ms < best) best = ms;
+    }
+    printf("8-tile workgroups, tiles %4d KiB apart, line per tile per instruction : %.4f ms  %.3f TB/s\n", PITCH_KB, best, 2.0 * bytes / best / 1e9);
+    fflush(stdout);
+}
+
 static const char *names[8] = {"-", "nt", "sc1", "sc0 sc1", "sc0 sc1 nt", "sc0", "sc1 nt", "sc0 nt"};
 
 template <int L, int S, int MODE>
@@ -73,6 +136,16 @@ int main()
     char *in, *out;
     if (hipMalloc(&in, bytes) != hipSuccess || hipMalloc(&out, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(in, 1, bytes); hipMemset(out, 0, bytes); hipDeviceSynchronize();
+    if (getenv("PLAIN_ONLY")) {
+        for (int rep = 0; rep < 2; ++rep) {
+            runc<64, 1>(in, out, bytes); runc<64, 2>(in, out, bytes); runc<64, 4>(in, out, bytes);
+            runc<256, 1>(in, out, bytes); runc<256, 2>(in, out, bytes); runc<256, 4>(in, out, bytes);
+            runc<512, 1>(in, out, bytes); runc<1024, 1>(in, out, bytes);
+            run<1, 6, 0>(in, out, tiles, 8192, 1);
+            runc2<2>(in, out, bytes); runc2<16>(in, out, bytes); runc2<64>(in, out, bytes); runc2<1024>(in, out, bytes);
+        }
+        return 0;
+    }
     if (getenv("SPREAD_ONLY")) {
         for (int rep = 0; rep < 2; ++rep)
             for (unsigned sp : {1u, 2u, 8u, 64u, 256u, 1024u, 4096u, 16384u, 65536u}) { run<1, 6, 0>(in, out, tiles, 8192, sp); }
