@@ -142,6 +142,12 @@ typedef struct x266_me_result_t {
 int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride,
                       const uint8_t *d_ref, intptr_t ref_stride, int width, int height,
                       int range, x266_me_result_t *d_best, uint32_t *d_costs, void *stream);
+/* The same search with the cheaper metric: cost = sum |cur - ref| over the 8x8 block,
+ * i.e. sad() of riscv/programs/benchmarks/sad/sad.c:28-39 at n = 8; same candidate order and
+ * tie-break.  d_cur must be 4-byte aligned with cur_stride a multiple of 4. */
+int xSad8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride, const uint8_t *d_ref,
+                     intptr_t ref_stride, int width, int height, int range, x266_me_result_t *d_best,
+                     uint32_t *d_costs, void *stream);
 /* Frame container of the codec skeleton: ref_block_t, src/x266.cpp:56-63 -- a frame is a
  * raster of 512-byte tiles (16x16 luma, 8 rows of interleaved U,V pairs, 128 info bytes). */
 typedef struct x266_ref_block_t {

@@ -86,6 +86,7 @@ typedef struct {
     int w, h, range, by0, by1;
     int16_t *mv;
     uint32_t *cost, *costs;
+    int metric;                       /* 0 = satd8x8, 1 = sum of absolute differences (sad.c:28-39 on the 8x8 block) */
 } me_job_t;
 
 static void *me_worker(void *p)
@@ -103,7 +104,13 @@ static void *me_worker(void *p)
                         for (int x = 0; x < 8; x++)
                             d[8 * y + x] = (int16_t)((int)j->cur[(by * 8 + y) * j->cs + bx * 8 + x] -
                                                      (int)j->ref[(by * 8 + y + dy) * j->rs + bx * 8 + x + dx]);
-                    const uint32_t c = orc_satd8x8(d);
+                    uint32_t c;
+                    if (j->metric == 0) {
+                        c = orc_satd8x8(d);
+                    } else {
+                        c = 0;
+                        for (int k = 0; k < 64; k++) c += (uint32_t)(d[k] < 0 ? -d[k] : d[k]);
+                    }
                     if (j->costs)
                         j->costs[((size_t)by * bxn + bx) * (size_t)(span * span) + (size_t)(dy + j->range) * span + (dx + j->range)] = c;
                     if (c < best) { best = c; bdx = dx; bdy = dy; }
@@ -115,9 +122,9 @@ static void *me_worker(void *p)
     return NULL;
 }
 
-void orc_satd8x8_search(const uint8_t *cur, ptrdiff_t cur_stride, const uint8_t *ref, ptrdiff_t ref_stride,
-                        int width, int height, int range, int16_t *best_mv, uint32_t *best_cost,
-                        uint32_t *costs, int threads)
+static void me_search(int metric, const uint8_t *cur, ptrdiff_t cur_stride, const uint8_t *ref, ptrdiff_t ref_stride,
+                      int width, int height, int range, int16_t *best_mv, uint32_t *best_cost,
+                      uint32_t *costs, int threads)
 {
     const int byn = height / 8;
     if (threads < 1) threads = 1;
@@ -127,10 +134,26 @@ void orc_satd8x8_search(const uint8_t *cur, ptrdiff_t cur_stride, const uint8_t 
     int done = 0;
     for (int t = 0; t < threads; t++) {
         const int cnt = byn / threads + (t < byn % threads ? 1 : 0);
-        job[t] = (me_job_t){cur, ref, cur_stride, ref_stride, width, height, range, done, done + cnt, best_mv, best_cost, costs};
+        job[t] = (me_job_t){cur, ref, cur_stride, ref_stride, width, height, range, done, done + cnt, best_mv, best_cost, costs, metric};
         done += cnt;
         pthread_create(&tid[t], NULL, me_worker, &job[t]);
     }
     for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
     free(tid); free(job);
+}
+
+void orc_satd8x8_search(const uint8_t *cur, ptrdiff_t cur_stride, const uint8_t *ref, ptrdiff_t ref_stride,
+                        int width, int height, int range, int16_t *best_mv, uint32_t *best_cost,
+                        uint32_t *costs, int threads)
+{
+    me_search(0, cur, cur_stride, ref, ref_stride, width, height, range, best_mv, best_cost, costs, threads);
+}
+
+/* Same harness, cheaper metric: cost = sum |cur - ref| over the 8x8 block, i.e. sad() of
+ * riscv/programs/benchmarks/sad/sad.c:28-39 at n = 8. */
+void orc_sad8x8_search(const uint8_t *cur, ptrdiff_t cur_stride, const uint8_t *ref, ptrdiff_t ref_stride,
+                       int width, int height, int range, int16_t *best_mv, uint32_t *best_cost,
+                       uint32_t *costs, int threads)
+{
+    me_search(1, cur, cur_stride, ref, ref_stride, width, height, range, best_mv, best_cost, costs, threads);
 }

@@ -67,6 +67,11 @@ void orc_satd8x8_search(const uint8_t *cur, ptrdiff_t cur_stride, const uint8_t 
                         int width, int height, int range, int16_t *best_mv, uint32_t *best_cost,
                         uint32_t *costs /* NULL or [blocks][(2R+1)^2] */, int threads);
 
+/* same harness with the cheaper metric of SURVEY 8 f3: cost = sum |cur - ref| (sad.c:28-39 at n = 8) */
+void orc_sad8x8_search(const uint8_t *cur, ptrdiff_t cur_stride, const uint8_t *ref, ptrdiff_t ref_stride,
+                       int width, int height, int range, int16_t *best_mv, uint32_t *best_cost,
+                       uint32_t *costs, int threads);
+
 /* ---- frame container (src/x266.cpp:56-63, 415-492) -------- restated, not executed; residual UNPINNED */
 void orc_conv_input_fmt(uint8_t *tiles, const uint8_t *y, const uint8_t *u, const uint8_t *v,
                         ptrdiff_t strd_y, int width, int height);

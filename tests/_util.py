@@ -131,8 +131,8 @@ class Oracle:
         assert self.lib.orc_intra32_costs(_P(refs.ctypes.data), _P(src.ctypes.data), _SZ(n), _P(costs.ctypes.data), _P(best.ctypes.data)) == 0
         return costs, best
 
-    def satd_search(self, cur, ref_padded, pad, rng, threads=1, want_costs=False):
-        """cur [H,W] uint8; ref_padded [H+2*pad, W+2*pad] uint8 with pad >= rng."""
+    def satd_search(self, cur, ref_padded, pad, rng, threads=1, want_costs=False, metric="satd"):
+        """cur [H,W] uint8; ref_padded [H+2*pad, W+2*pad] uint8 with pad >= rng.  metric: "satd" or "sad"."""
         cur = np.ascontiguousarray(cur, np.uint8)
         refp = np.ascontiguousarray(ref_padded, np.uint8)
         h, w = cur.shape
@@ -141,7 +141,8 @@ class Oracle:
         cost = np.empty(nb, np.uint32)
         costs = np.empty((nb, (2 * rng + 1) ** 2), np.uint32) if want_costs else None
         origin = refp.ctypes.data + pad * refp.strides[0] + pad
-        self.lib.orc_satd8x8_search(_P(cur.ctypes.data), ctypes.c_ssize_t(cur.strides[0]), _P(origin),
+        fn = self.lib.orc_satd8x8_search if metric == "satd" else self.lib.orc_sad8x8_search
+        fn(_P(cur.ctypes.data), ctypes.c_ssize_t(cur.strides[0]), _P(origin),
                                     ctypes.c_ssize_t(refp.strides[0]), w, h, rng, _P(mv.ctypes.data),
                                     _P(cost.ctypes.data), _P(costs.ctypes.data if want_costs else None), threads)
         return mv, cost, costs

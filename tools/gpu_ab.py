@@ -70,10 +70,13 @@ def me(L, ctx):
 def intra(L, ctx):
     L.xIntra32CostsDev.argtypes = [P, P, P, P, P, ctypes.c_size_t, P]
     assert L.xIntra32CostsDev(ctx, irefs, isrc, icost, ibest, nb, None) == 0
-for name, fn, reps in (("me 4K", me, 5), ("intra decide", intra, 10)):
+def sadme(L, ctx):
+    L.xSad8x8SearchDev.argtypes = [P, P, ctypes.c_ssize_t, P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, P, P]
+    assert L.xSad8x8SearchDev(ctx, cur, w, P(refp.value + rng * stride + rng), stride, w, h, rng, bestb, None, None) == 0
+for name, fn, reps in (("me 4K", me, 5), ("intra decide", intra, 10), ("sad me 4K", sadme, 5)):
     best = {"ref": 1e9, "new": 1e9}
     for rnd in range(4):
         for tag, (L, ctx) in libs:
-            if hasattr(L, "xIntra32CostsDev") or name != "intra decide":
+            if (hasattr(L, "xIntra32CostsDev") or name != "intra decide") and (hasattr(L, "xSad8x8SearchDev") or name != "sad me 4K"):
                 best[tag] = min(best[tag], wall(fn, L, ctx, reps))
     print("%-12s ref %.4f ms | new %.4f ms | new/ref time %.4f" % (name, best["ref"], best["new"], best["new"] / best["ref"]), flush=True)

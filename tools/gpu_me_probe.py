@@ -22,3 +22,12 @@ for var, tr, rp in ((1, 2, 1), (2, 2, 2), (2, 4, 1), (2, 4, 2), (2, 4, 3), (2, 4
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
     ncand = nb * (2 * rng + 1) ** 2
     print("variant=%d tile_rows=%d row_pairs=%d: %.3f ms/frame  %.3e SATD/s" % (var, tr, rp, dt * 1e3, ncand / dt), flush=True)
+
+for tr in (2, 4):
+    cd.set_option("me_tile_rows", tr)
+    cd.sad_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr()); torch.cuda.synchronize()
+    t = time.perf_counter(); reps = 5
+    for _ in range(reps): cd.sad_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr())
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
+    print("SAD search tile_rows=%d: %.3f ms/frame  %.3e SAD/s" % (tr, dt * 1e3, ncand / dt), flush=True)
+cd.set_option("me_tile_rows", 4)

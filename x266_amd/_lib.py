@@ -76,6 +76,8 @@ def load_library():
     L.xTransformInvBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P]
     L.xSatd8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, _P, _P, _P]
+    L.xSad8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, _P, _P, _P]
     for name in ("xDct32FwdBatch", "xDct32InvBatch", "xSatd8x8Batch"):
         getattr(L, name).argtypes = [_P, _P, _P, _SZ]
     L.xHipMalloc.argtypes = [_P, ctypes.POINTER(_P), _SZ]
@@ -328,8 +330,13 @@ class Codec:
         self._check(self.L.xSatd8x8SearchDev(self.ctx, d_cur, cur_stride, d_ref_origin, ref_stride, width, height,
                                              rng, d_best, d_costs or None, stream), "xSatd8x8SearchDev")
 
-    def satd_search(self, cur, ref_padded, pad, rng, want_costs=False):
-        """numpy convenience around xSatd8x8SearchDev: cur [H,W] uint8, ref_padded [H+2*pad, W+2*pad]."""
+    def sad_search_dev(self, d_cur, cur_stride, d_ref_origin, ref_stride, width, height, rng, d_best, d_costs=0,
+                       stream=0):
+        self._check(self.L.xSad8x8SearchDev(self.ctx, d_cur, cur_stride, d_ref_origin, ref_stride, width, height,
+                                            rng, d_best, d_costs or None, stream), "xSad8x8SearchDev")
+
+    def satd_search(self, cur, ref_padded, pad, rng, want_costs=False, metric="satd"):
+        """numpy convenience around xSatd8x8SearchDev / xSad8x8SearchDev: cur [H,W] uint8, ref_padded [H+2*pad, W+2*pad]."""
         cur = np.ascontiguousarray(cur, np.uint8)
         refp = np.ascontiguousarray(ref_padded, np.uint8)
         h, w = cur.shape
@@ -339,8 +346,9 @@ class Codec:
         dcost = self.alloc(nb * ncand * 4) if want_costs else None
         dc.upload(cur)
         dr.upload(refp)
-        self.satd_search_dev(dc.ptr, cur.strides[0], dr.ptr + pad * refp.strides[0] + pad, refp.strides[0], w, h, rng,
-                             db.ptr, dcost.ptr if want_costs else 0)
+        fn = self.satd_search_dev if metric == "satd" else self.sad_search_dev
+        fn(dc.ptr, cur.strides[0], dr.ptr + pad * refp.strides[0] + pad, refp.strides[0], w, h, rng,
+           db.ptr, dcost.ptr if want_costs else 0)
         self.stream_sync()
         raw = db.download(np.uint8, nb * 8)
         mv = raw.view(np.int16).reshape(nb, 4)[:, :2].copy()

@@ -429,6 +429,151 @@ __global__ __launch_bounds__(256) void satd_search_kernel_v2(const MeParams P, c
     }
 }
 
+// ============================================================================
+// Full search with the cheaper metric: cost = sum |cur - ref| over the 8x8 block, i.e.
+// sad() of riscv/programs/benchmarks/sad/sad.c:28-39 at n = 8, same harness (raster order, first
+// minimum wins) as the SATD search above.
+//
+// Lane = candidate column.  A reference row's 8 pixels at that column (two dwords, aligned once with
+// v_alignbit) are shared by the eight candidates (dy) whose blocks contain the row, one per block row
+// p = 0..7: eight rotating accumulators per block, the slot that has just received p = 7 is a finished
+// candidate.  Four horizontally adjacent blocks per pass share the row too; their 4 x 8 current rows
+// sit in 64 SGPRs (scalar loads), so the inner loop is v_sad_u8 against scalar operands: 64 per
+// reference row and lane, plus 5 instructions to fetch the row and 4 x 4 to score the finished
+// candidates.  Work item = (block row of the tile, left / right half of its blocks, 64 columns).
+// ============================================================================
+template <int TBY, bool COSTS>
+__global__ __launch_bounds__(256) void sad_search_kernel(const MeParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NBLK = kTileBlocksX * TBY;
+    const int R = P.range, span = 2 * R + 1;
+    const int win_rows = P.n_rows + 7;
+    uint32_t *best_lds = reinterpret_cast<uint32_t *>(smem);
+    unsigned char *win = smem + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, n_waves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
+    const int x0 = tx * (8 * kTileBlocksX), y0 = ty * (8 * TBY);
+
+    {   // reference window, raw pixels (edge-clamped like the SATD search)
+        const int dwords_per_row = P.pitch >> 2;
+        const int total = win_rows * dwords_per_row;
+        for (int i = tid; i < total; i += blockDim.x) {
+            const int ry = i / dwords_per_row, cx = (i - ry * dwords_per_row) * 4;
+            int gy = y0 - R + ry;
+            gy = gy < -R ? -R : (gy > P.height + R - 1 ? P.height + R - 1 : gy);
+            const uint8_t *row = P.ref + (long long)gy * P.ref_stride;
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int gx = x0 - R + cx + b;
+                gx = gx < -R ? -R : (gx > P.width + R - 1 ? P.width + R - 1 : gx);
+                v |= (uint32_t)row[gx] << (8 * b);
+            }
+            reinterpret_cast<uint32_t *>(win)[i] = v;
+        }
+    }
+    if (tid < NBLK) best_lds[tid] = 0xFFFFFFFFu;
+    __syncthreads();
+
+    const int n_items = TBY * 2 * P.n_groups;                        // here n_groups counts 64-column groups
+    const int sh = (lane & 3) * 8;
+    for (int item = wave; item < n_items; item += n_waves) {
+        const int g = item % P.n_groups, jh = item / P.n_groups, ih = jh & 1, j = jh >> 1;   // wave-uniform
+        const int by = ty * TBY + j;
+        if (by >= P.blocks_y) continue;
+        // current rows of the four blocks: scalar loads (addresses are wave-uniform)
+        uint32_t c[4][8][2];
+        bool have[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bx = tx * kTileBlocksX + 4 * ih + i;
+            have[i] = bx < P.blocks_x;
+            const int bxc = have[i] ? bx : P.blocks_x - 1;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(P.cur + (long long)(by * 8 + p) * P.cur_stride + bxc * 8);
+                c[i][p][0] = q[0];
+                c[i][p][1] = q[1];
+            }
+        }
+        // per-lane candidate column of each block, and whether it lies inside the block's window
+        int dxl[4];
+        bool okx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dxl[i] = 64 * g + lane - 8 * (4 * ih + i);
+            okx[i] = have[i] && (unsigned)dxl[i] < (unsigned)span;
+        }
+        uint32_t best[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        uint32_t acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[i][k] = 0;
+        const unsigned char *colbase = win + (8 * j) * P.pitch + ((64 * g + lane) & ~3);
+        const int n_ry = span + 7;
+        for (int ry8 = 0; ry8 < n_ry; ry8 += 8) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int ry = ry8 + m;
+                if (ry >= n_ry) break;                               // wave-uniform
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(colbase + ry * P.pitch);
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                const uint32_t a0 = __builtin_amdgcn_alignbit(d1, d0, sh), a1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        const int slot = (m - p) & 7;
+                        const uint32_t init = p == 0 ? 0u : acc[i][slot];
+                        acc[i][slot] = __builtin_amdgcn_sad_u8(a1, c[i][p][1], __builtin_amdgcn_sad_u8(a0, c[i][p][0], init));
+                    }
+                const int dy = ry - 7;                               // the candidate row that has now seen all 8 block rows
+                if (dy >= 0) {                                       // wave-uniform
+                    const int fin = (m + 1) & 7;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t cost = acc[i][fin];
+                        const uint32_t idx = (uint32_t)(dy * span + dxl[i]);
+                        const uint32_t key = okx[i] ? ((cost << 16) | idx) : 0xFFFFFFFFu;
+                        best[i] = key < best[i] ? key : best[i];
+                        if (COSTS && okx[i]) {
+                            const size_t blk = (size_t)by * P.blocks_x + (tx * kTileBlocksX + 4 * ih + i);
+                            P.costs[blk * (size_t)(span * span) + idx] = cost;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t v = best[i];
+#pragma unroll
+            for (int mm = 32; mm >= 1; mm >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)v, mm);
+                v = o < v ? o : v;
+            }
+            if (lane == 0 && have[i]) atomicMin(&best_lds[j * kTileBlocksX + 4 * ih + i], v);
+        }
+    }
+    __syncthreads();
+    if (tid < NBLK) {
+        const int bx = tx * kTileBlocksX + (tid % kTileBlocksX), by = ty * TBY + (tid / kTileBlocksX);
+        if (bx < P.blocks_x && by < P.blocks_y) {
+            const uint32_t key = best_lds[tid];
+            const int idx = (int)(key & 0xFFFFu);
+            x266_me_result_t res;
+            res.mvx = (int16_t)(idx % span - R);
+            res.mvy = (int16_t)(idx / span - R);
+            res.cost = key >> 16;
+            P.best[(size_t)by * P.blocks_x + bx] = res;
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
@@ -472,6 +617,35 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
     if (tby == 4)      hipLaunchKernelGGL((satd_search_kernel<4>), grid, block, lds, stream, P);
     else if (tby == 1) hipLaunchKernelGGL((satd_search_kernel<1>), grid, block, lds, stream, P);
     else               hipLaunchKernelGGL((satd_search_kernel<2>), grid, block, lds, stream, P);
+    return hipGetLastError();
+}
+
+}  // namespace x266
+
+namespace x266 {
+
+hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
+                             int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
+                             int tile_rows, hipStream_t stream)
+{
+    MeParams P;
+    P.cur = d_cur; P.ref = d_ref; P.cur_stride = cur_stride; P.ref_stride = ref_stride;
+    P.width = width; P.height = height; P.range = range;
+    P.blocks_x = width / 8; P.blocks_y = height / 8;
+    P.tiles_x = (P.blocks_x + kTileBlocksX - 1) / kTileBlocksX;
+    const int tby = tile_rows == 4 ? 4 : (tile_rows == 1 ? 1 : 2);
+    const int tiles_y = (P.blocks_y + tby - 1) / tby;
+    const int span = 2 * range + 1;
+    P.n_groups = (8 * (kTileBlocksX - 1) + span + 63) / 64;           // 64-column groups (lane = column)
+    P.n_rows = 8 * (tby - 1) + span;
+    P.pitch = 64 * P.n_groups + 12;
+    P.best = d_best; P.costs = d_costs;
+    dim3 grid((unsigned)(P.tiles_x * tiles_y)), block(256);
+    const size_t lds = 128 + (size_t)(P.n_rows + 7) * P.pitch;
+#define X266_SADS(T) do { if (d_costs) hipLaunchKernelGGL((sad_search_kernel<T, true>), grid, block, lds, stream, P); \
+                          else         hipLaunchKernelGGL((sad_search_kernel<T, false>), grid, block, lds, stream, P); } while (0)
+    if (tby == 4) X266_SADS(4); else if (tby == 1) X266_SADS(1); else X266_SADS(2);
+#undef X266_SADS
     return hipGetLastError();
 }
 

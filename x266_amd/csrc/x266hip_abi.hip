@@ -539,6 +539,24 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
     return X266HIP_OK;
 }
 
+int xSad8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride, const uint8_t *d_ref,
+                     intptr_t ref_stride, int width, int height, int range, x266_me_result_t *d_best,
+                     uint32_t *d_costs, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (!d_cur || !d_ref || !d_best) return fail(ctx, X266HIP_EINVAL, "xSad8x8SearchDev: NULL buffer");
+    if (width < 8 || height < 8 || (width & 7) || (height & 7)) return fail(ctx, X266HIP_EINVAL, "xSad8x8SearchDev: frame size must be a multiple of 8");
+    if (range < 1 || range > 64) return fail(ctx, X266HIP_EINVAL, "xSad8x8SearchDev: range must be 1..64");
+    if (cur_stride < width || ref_stride < width + 2 * range) return fail(ctx, X266HIP_EINVAL, "xSad8x8SearchDev: stride too small");
+    if (((uintptr_t)d_cur & 3u) || (cur_stride & 3)) return fail(ctx, X266HIP_EINVAL, "xSad8x8SearchDev: current frame must be 4-byte aligned with a stride multiple of 4");
+    if (((uintptr_t)d_best & 7u) || ((uintptr_t)d_costs & 3u)) return fail(ctx, X266HIP_EINVAL, "xSad8x8SearchDev: unaligned output");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_sad_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
+                                     d_best, d_costs, ctx->me_tile_rows, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "SAD search launch", e);
+    return X266HIP_OK;
+}
+
 // ---- host-pointer batch API --------------------------------------------------
 // Chunks of the batch alternate between two staging slots, each with its own
 // stream: H2D(i+1) and D2H(i-1) overlap kernel(i).
