@@ -338,6 +338,21 @@ def main():
                 "frac_of_v_sad_u16_floor": floor_s / (wall_m / me_steps),
                 "planted_mv_found_fraction": found,
                 "parity": "per-candidate cost pinned by satd8x8 (src_tb/satd.c); harness (order, tie-break, padding) unpinned"}
+            # the same search with the SAD metric
+            for _ in range(me_warm):
+                codec.sad_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(me_steps):
+                codec.sad_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream)
+            barrier()
+            wall_sm = max_over_ranks(time.perf_counter() - t0)
+            mv = best.view(torch.int16).view(nb, 4)[:, :2]
+            also["sad8x8_me_search"] = {
+                "value": world * ncand * me_steps / wall_sm, "unit": "SAD/s", "ms_per_frame": wall_sm / me_steps * 1e3,
+                "frac_of_v_sad_u8_floor": (ncand / 64 * 16 * 4 / (4 * info_cu * 2.4e9)) / (wall_sm / me_steps),
+                "planted_mv_found_fraction": float(((mv[:, 0] == 5) & (mv[:, 1] == -3)).float().mean().item()),
+                "parity": "metric = sad() of riscv/programs/benchmarks/sad/sad.c at n = 8; harness unpinned, as for the SATD search"}
             del big, sm, cur, refp, best
 
         # ---- BASELINE configs[3]: the VVC transform set, 2 GiB of residual per class
