@@ -370,7 +370,7 @@ def main():
                 for n in (4, 8, 16):
                     nblk = (n_dct * 1024) // (n * n)
                     if inverse:
-                        fn = lambda a, b, cnt, st, tt=ttype, nn=n: codec.transform_inv_dev(tt, nn, a, b, cnt, st)
+                        fn = lambda a, b, cnt, st, tt=ttype, nn=n: codec.transform_inv_dev(tt, nn, a, b, cnt, 0, st)
                     else:
                         fn = lambda a, b, cnt, st, tt=ttype, nn=n: codec.transform_fwd_dev(tt, nn, a, b, cnt, 0, st)
                     for _ in range(3):

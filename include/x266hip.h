@@ -120,10 +120,10 @@ int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out,
 int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d_in, int16_t *d_out,
                           size_t n_blocks, const uint32_t *d_offsets, void *stream);
 /* Inverse transforms of the same set (no upstream counterpart): columns first, shifts 7 and 12
- * (8-bit video), int16 clipping after each pass; (DCT-II, 32) is xDct32InvBatchDev.  Contiguous
- * batches only. */
+ * (8-bit video), int16 clipping after each pass; (DCT-II, 32) contiguous is xDct32InvBatchDev.
+ * d_offsets as in the forward call. */
 int xTransformInvBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d_in, int16_t *d_out,
-                          size_t n_blocks, void *stream);
+                          size_t n_blocks, const uint32_t *d_offsets, void *stream);
 /* Full-search motion estimation with the 8x8 SATD cost (BASELINE configs[2]).
  * For every 8x8 block of `cur` (block grid aligned to (0,0); width, height
  * multiples of 8) and every displacement (dx,dy) in [-range, range]^2,

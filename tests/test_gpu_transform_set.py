@@ -110,6 +110,42 @@ def test_mixed_per_ctu_batches(codec, oracle):
         assert np.array_equal(got[idx], want[idx]), (ttype, n)
 
 
+def test_mixed_per_ctu_batches_inverse(codec, oracle):
+    """The inverse over the same kind of offset tables (all seven classes, 32x32 included)."""
+    n_ctus = 200
+    z = np.concatenate([residual_np(n_ctus * 2048, 177), fullrange_np(n_ctus * 2048, 178)])
+    offsets = _random_ctu_partition(4321, n_ctus)
+    want = np.zeros_like(z)
+    din, dout = codec.alloc(z.nbytes), codec.alloc(z.nbytes)
+    din.upload(z)
+    dout.upload(np.zeros_like(z))
+    keep = []
+    for (ttype, n), offs in offsets.items():
+        if not offs:
+            continue
+        offs = np.array(offs, np.uint32)
+        idx = offs[:, None] + np.arange(n * n, dtype=np.uint32)[None, :]
+        want[idx] = oracle.transform_inv(ttype, n, z[idx]) if n < 32 else oracle.dct32_inv(z[idx])
+        doff = codec.alloc(offs.nbytes)
+        doff.upload(offs)
+        keep.append(doff)
+        codec.transform_inv_dev(ttype, n, din.ptr, dout.ptr, len(offs), doff.ptr)
+    codec.stream_sync()
+    assert np.array_equal(dout.download(np.int16, z.size), want)
+
+
+def test_mixed_per_ctu_forward_32_by_offsets(codec, oracle):
+    """(DCT-II, 32) through the offset table directly (no gathering on the host)."""
+    x = residual_np(64 * 1024, 9).reshape(64, 1024)
+    order = np.random.default_rng(3).permutation(64).astype(np.uint32)
+    din, dout, doff = codec.alloc(x.nbytes), codec.alloc(x.nbytes), codec.alloc(order.nbytes)
+    din.upload(x)
+    doff.upload(order * 1024)
+    codec.transform_fwd_dev(0, 32, din.ptr, dout.ptr, 64, doff.ptr)
+    codec.stream_sync()
+    assert np.array_equal(dout.download(np.int16, x.size).reshape(64, 1024), oracle.dct32_fwd(x))
+
+
 def test_argument_errors(codec):
     L = codec.L
     buf = codec.alloc(1 << 16)

@@ -73,7 +73,7 @@ def load_library():
     L.xDct32FwdFromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
     L.xSatd8x8FromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
     L.xSadBatchDev.argtypes = [_P, ctypes.c_int, _P, _P, _P, _SZ, _P]
-    L.xTransformInvBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P]
+    L.xTransformInvBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
     L.xSatd8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, _P, _P, _P]
     L.xSad8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
@@ -313,8 +313,8 @@ class Codec:
         self.stream_sync()
         return do.download(np.uint32, n)
 
-    def transform_inv_dev(self, ttype, size, d_in, d_out, n_blocks, stream=0):
-        self._check(self.L.xTransformInvBatchDev(self.ctx, ttype, size, d_in, d_out, n_blocks, stream), "xTransformInvBatchDev")
+    def transform_inv_dev(self, ttype, size, d_in, d_out, n_blocks, d_offsets=0, stream=0):
+        self._check(self.L.xTransformInvBatchDev(self.ctx, ttype, size, d_in, d_out, n_blocks, d_offsets or None, stream), "xTransformInvBatchDev")
 
     def transform_inv(self, ttype, size, x):
         x = np.ascontiguousarray(x, np.int16)

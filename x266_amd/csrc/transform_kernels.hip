@@ -193,10 +193,10 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
 // after each pass -- DESIGN.md section 10), contiguous batches, same block-diagonal tile idea.  The
 // first contraction runs over the tile's ROW index, so each lane reads its COLUMN out of the staged
 // tile (16 x ds_read_u16), exactly as the staged DCT32 inverse does.
-template <int LOGN, bool NT>
+template <int LOGN, bool NT, bool INDEXED>
 __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
                                                                size_t n_blocks, const DctOps *__restrict__ ops,
-                                                               unsigned tiles_per_wave)
+                                                               const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
 {
     constexpr int N = 1 << LOGN;
     constexpr int PER = 32 / N, PIECES = N >= 16 ? 1 : 16 / N, NSB = PER * PER;
@@ -229,11 +229,26 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
     const unsigned col_base = ((u >> LOGN) * (unsigned)(N * N) + (u & (N - 1))) * 2u + (unsigned)h * 1024u;
 
     for (; t < t_end; ++t) {
-        const size_t base = t * 2048;
-        size_t o0 = base + (size_t)lane * 16, o1 = o0 + 1024;
-        const bool live0 = o0 + 16 <= total_bytes, live1 = o1 + 16 <= total_bytes;
-        if (!live0) o0 = total_bytes - 16;
-        if (!live1) o1 = total_bytes - 16;
+        size_t o0, o1;
+        bool live0, live1;
+        if (INDEXED) {                                                   // as in the forward kernel: chunk -> block of the offset table
+            constexpr int CPB = N * N / 8;
+            size_t b0 = t * NSB + (size_t)(lane / CPB), b1 = t * NSB + (size_t)((lane + 64) / CPB);
+            live0 = b0 < n_blocks;
+            live1 = b1 < n_blocks;
+            if (!live0) b0 = n_blocks - 1;
+            if (!live1) b1 = n_blocks - 1;
+            o0 = ((size_t)offsets[b0] * 2) + (size_t)(lane % CPB) * 16;
+            o1 = ((size_t)offsets[b1] * 2) + (size_t)((lane + 64) % CPB) * 16;
+        } else {
+            const size_t base = t * 2048;
+            o0 = base + (size_t)lane * 16;
+            o1 = o0 + 1024;
+            live0 = o0 + 16 <= total_bytes;
+            live1 = o1 + 16 <= total_bytes;
+            if (!live0) o0 = total_bytes - 16;
+            if (!live1) o1 = total_bytes - 16;
+        }
         const v4i g0 = load16<NT>(reinterpret_cast<const char *>(in) + o0);
         const v4i g1 = load16<NT>(reinterpret_cast<const char *>(in) + o1);
         *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
@@ -316,7 +331,7 @@ hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out
 namespace x266 {
 
 hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
-                                      const LaunchCfg &cfg, hipStream_t stream)
+                                      const uint32_t *d_offsets, const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
     const size_t per_tile = (size_t)(32 >> log2n) * (size_t)(32 >> log2n);
@@ -328,9 +343,10 @@ hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
     dim3 grid((unsigned)wgs), block(tpb);
-#define X266_TRI(L) do { if (cfg.nontemporal & 3) hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, tpw); \
-                         else                     hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, false>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, tpw); } while (0)
-    if (log2n == 2) X266_TRI(2); else if (log2n == 3) X266_TRI(3); else if (log2n == 4) X266_TRI(4);
+#define X266_TRI(L) do { if (d_offsets)                hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, false, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
+                         else if (cfg.nontemporal & 3) hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, true, false>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
+                         else                          hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, false, false>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
+    if (log2n == 2) X266_TRI(2); else if (log2n == 3) X266_TRI(3); else if (log2n == 4) X266_TRI(4); else if (log2n == 5) X266_TRI(5);
     else return hipErrorInvalidValue;
 #undef X266_TRI
     return hipGetLastError();

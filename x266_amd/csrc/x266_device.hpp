@@ -98,7 +98,7 @@ hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out
 hipError_t launch_dct32_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_out,
                                    int width, int height, const DctOps *d_fwd_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
-                                      const LaunchCfg &cfg, hipStream_t stream);
+                                      const uint32_t *d_offsets, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_satd8x8_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, uint32_t *d_out,
                                      int width, int height, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks,

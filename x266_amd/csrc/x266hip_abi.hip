@@ -492,21 +492,24 @@ int xSadBatchDev(x266hip_ctx *ctx, int edge, const uint8_t *d_a, const uint8_t *
     return X266HIP_OK;
 }
 
-int xTransformInvBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d_in, int16_t *d_out, size_t n, void *stream)
+int xTransformInvBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d_in, int16_t *d_out, size_t n,
+                          const uint32_t *d_offsets, void *stream)
 {
     if (!ctx) return X266HIP_EINVAL;
     if (type != X266_TR_DCT2 && type != X266_TR_DST7) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: unknown transform type");
     if (size != 4 && size != 8 && size != 16 && !(size == 32 && type == X266_TR_DCT2))
         return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: size must be 4, 8, 16 (or 32 for DCT-II)");
     if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: NULL or unaligned buffer");
+    if (n && ((uintptr_t)d_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: unaligned offset table");
     X_HIP(ctx, hipSetDevice(ctx->device));
-    if (size == 32) return launch_op(ctx, 1, d_in, d_out, n, (hipStream_t)stream);
+    if (size == 32 && !d_offsets) return launch_op(ctx, 1, d_in, d_out, n, (hipStream_t)stream);
     const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
     LaunchCfg cfg = cfg_for(ctx, 1);
     cfg.units_per_wave = ctx->dct_inv_blocks_per_wave;
     cfg.wg_threads = ctx->dct_inv_wg_threads;
     cfg.lds_bytes_per_wave = ctx->dct_inv_lds_per_wave;
-    hipError_t e = launch_transform_small_inv(l + 2, d_in, d_out, n, ctx->d_tr_inv[type][l], cfg, (hipStream_t)stream);
+    hipError_t e = size == 32 ? launch_transform_small_inv(5, d_in, d_out, n, ctx->d_inv_lds, d_offsets, cfg, (hipStream_t)stream)
+                              : launch_transform_small_inv(l + 2, d_in, d_out, n, ctx->d_tr_inv[type][l], d_offsets, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "inverse transform launch", e);
     return X266HIP_OK;
 }
