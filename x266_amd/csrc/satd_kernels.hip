@@ -24,32 +24,10 @@
 #include <cstdint>
 
 #include "x266_device.hpp"
-#include "x266_tables.hpp"
+#include "x266_mfma_blocks.hpp"
 
 namespace x266 {
 namespace {
-
-__device__ __forceinline__ uint32_t bperm(uint32_t hi_src, uint32_t lo_src, uint32_t sel)
-{
-    return __builtin_amdgcn_perm(hi_src, lo_src, sel);
-}
-
-__device__ __forceinline__ v16i mfma(const v4i &a, const v4i &b, const v16i &c)
-{
-    return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
-}
-
-// 8 dwords of int16 pairs -> low-byte plane (offset to signed) and high-byte plane
-__device__ __forceinline__ void split_planes(const v4i &w0, const v4i &w1, v4i &lo, v4i &hi)
-{
-    const uint32_t w[8] = {(uint32_t)w0[0], (uint32_t)w0[1], (uint32_t)w0[2], (uint32_t)w0[3],
-                           (uint32_t)w1[0], (uint32_t)w1[1], (uint32_t)w1[2], (uint32_t)w1[3]};
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        lo[p] = (int)(bperm(w[2 * p + 1], w[2 * p], 0x06040200u) ^ 0x80808080u);
-        hi[p] = (int)bperm(w[2 * p + 1], w[2 * p], 0x07050301u);
-    }
-}
 
 // sum over 16 accumulators of |(int16)(256*hi + lo)|
 __device__ __forceinline__ uint32_t abs_sum16(const v16i &hi, const v16i &lo, uint32_t sum)

@@ -21,14 +21,10 @@
 #include <cstdint>
 
 #include "x266_device.hpp"
+#include "x266_mfma_blocks.hpp"
 
 namespace x266 {
 namespace {
-
-__device__ __forceinline__ uint32_t bperm(uint32_t hi_src, uint32_t lo_src, uint32_t sel)
-{
-    return __builtin_amdgcn_perm(hi_src, lo_src, sel);
-}
 
 // wave -> (tile row ty, group of 8 tiles, upper / lower half of the tiles); lane -> (row, tile)
 struct TileRow {
