@@ -1,0 +1,40 @@
+"""GPU: bench.py end to end at a small size -- every leg runs, the JSON line carries the contract's fields,
+and the CPU-baseline leg confirms the GPU output bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from _util import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _run(args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                      # exactly one JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_small_run_has_every_leg_and_field():
+    d = _run(["--steps", "3", "--warmup", "1", "--dct-blocks", "8192", "--satd-blocks", "131072"])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["cpu_baseline"]["gpu_output_bit_exact_vs_cpu"] is True and d["cpu_baseline"]["cores"] >= 1
+    for leg in ("dct32_inv", "dct32_fwd_inv_fused", "satd8x8", "satd8x8_me_search", "sad8x8_me_search", "transform_set",
+                "fused_from_tiles", "front_end_and_sad", "intra32"):
+        assert leg in d["also"], leg
+    assert d["also"]["dct32_fwd_inv_fused"]["same_bytes_as_two_kernels"] is True
+    assert d["also"]["satd8x8_me_search"]["planted_mv_found_fraction"] > 0.99
+    assert "error" not in d
