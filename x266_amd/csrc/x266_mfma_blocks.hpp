@@ -123,9 +123,13 @@ __device__ __forceinline__ void fwd_block(const v4i &w0, const v4i &w1, const La
 }
 
 // ---- inverse passes (see dct32_kernels.hip, section "inverse") --------------------------------
-__device__ __forceinline__ int clamp16(int v)
+
+// {clip16(lo), clip16(hi)} packed into one dword: v_cvt_pk_i16_i32 (full rate, profiles/r01_alubench.txt)
+__device__ __forceinline__ uint32_t sat_pack16(int lo, int hi)
 {
-    return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);   // folds to v_med3_i32
+    typedef short v2s __attribute__((ext_vector_type(2)));
+    const v2s r = __builtin_amdgcn_cvt_pk_i16(lo, hi);
+    return __builtin_bit_cast(uint32_t, r);
 }
 
 // passes A and B on column data: zlo / zhi = byte planes of 16 samples of ONE COLUMN per lane
@@ -138,10 +142,16 @@ __device__ __forceinline__ void inv_passes(const v4i &zlo, const v4i &zhi, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)k.c1);
     acc = mfma(zlo, k.p1, acc);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = clamp16(acc[r] >> 7);
+    // shift, clip to int16 and re-pack to byte planes: v_cvt_pk_i16_i32 saturates and packs two
+    // values per instruction (instead of two v_med3 + byte shuffles on 32-bit values)
     v4i tlo2, thi2;
-    pack_planes(acc, tlo2, thi2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t p01 = sat_pack16(acc[4 * q + 0] >> 7, acc[4 * q + 1] >> 7);
+        const uint32_t p23 = sat_pack16(acc[4 * q + 2] >> 7, acc[4 * q + 3] >> 7);
+        tlo2[q] = (int)(bperm(p23, p01, 0x06040200u) ^ 0x80808080u);
+        thi2[q] = (int)bperm(p23, p01, 0x07050301u);
+    }
 
     // pass B (rows): coefficients = A, data = B, per-register constant
     acc = mfma(k.p2, thi2, zero);
@@ -151,10 +161,7 @@ __device__ __forceinline__ void inv_passes(const v4i &zlo, const v4i &zhi, const
 
     uint32_t z[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int a = clamp16(acc[2 * m] >> 12), b = clamp16(acc[2 * m + 1] >> 12);
-        z[m] = bperm((uint32_t)b, (uint32_t)a, 0x05040100u);
-    }
+    for (int m = 0; m < 8; ++m) z[m] = sat_pack16(acc[2 * m] >> 12, acc[2 * m + 1] >> 12);
     o0 = v4i{(int)z[0], (int)z[1], (int)z[2], (int)z[3]};
     o1 = v4i{(int)z[4], (int)z[5], (int)z[6], (int)z[7]};
 }
