@@ -1,0 +1,100 @@
+"""GPU: randomized differential test (hypothesis) -- random batch sizes, data mixes and launch options, every
+kernel against the oracle.  Complements the hand-picked ragged counts of test_gpu_parity.py."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import x266_amd
+from _util import extremes_np, fullrange_np, intra_refs_np, residual_np
+
+pytestmark = pytest.mark.gpu
+
+OPTIONS = {
+    "nontemporal": st.sampled_from([0, 1, 2, 3, 8, 10, 11]),
+    "adaptive_per_wave": st.integers(0, 1),
+    "dct32_lds_stage": st.integers(0, 1),
+    "satd_lds_stage": st.integers(0, 1),
+    "tr_lds_stage": st.integers(0, 1),
+    "dct32_variant": st.integers(0, 2),
+    "satd_variant": st.integers(0, 2),
+    "dct32_blocks_per_wave": st.integers(1, 9),
+    "dct32_inv_blocks_per_wave": st.integers(1, 9),
+    "dct32_fwdinv_blocks_per_wave": st.integers(1, 9),
+    "satd_groups_per_wave": st.integers(1, 9),
+    "tr_tiles_per_wave": st.integers(1, 5),
+    "wg_threads": st.sampled_from([64, 128, 192, 256]),
+    "dct32_wg_threads": st.sampled_from([64, 128, 192, 256]),
+    "dct32_inv_wg_threads": st.sampled_from([64, 128, 192, 256]),
+    "satd_wg_threads": st.sampled_from([64, 128, 192, 256]),
+    "dct32_lds_bytes_per_wave": st.sampled_from([2048, 4096, 8192, 12288]),
+    "satd_lds_bytes_per_wave": st.sampled_from([4096, 6144, 8192]),
+}
+
+
+@pytest.fixture(scope="module")
+def codec():
+    return x266_amd.Codec(0)
+
+
+def _data(kind, n, unit, seed):
+    if n == 0:
+        return np.zeros((0, unit), np.int16)
+    gen = (residual_np, fullrange_np, extremes_np)[kind]
+    return gen(n * unit, seed).reshape(n, unit)
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n=st.integers(0, 2500), kind=st.integers(0, 2), seed=st.integers(1, 1 << 30), opts=st.fixed_dictionaries(OPTIONS))
+def test_dct_and_satd_random_sizes_and_options(codec, oracle, n, kind, seed, opts):
+    saved = {k: codec.get_option(k) for k in opts}
+    try:
+        for k, v in opts.items():
+            codec.set_option(k, v)
+        x = _data(kind, n, 1024, seed)
+        z = oracle.dct32_fwd(x, threads=8) if n else x
+        assert np.array_equal(codec.dct32_fwd(x), z)
+        assert np.array_equal(codec.dct32_inv(z), oracle.dct32_inv(z, threads=8) if n else z)
+        d = _data(kind, n * 5 + (seed % 7), 64, seed + 1)
+        assert np.array_equal(codec.satd8x8(d), oracle.satd8x8(d, threads=8) if d.shape[0] else np.zeros(0, np.uint32))
+        if n:
+            din, dco, dre = codec.alloc(n * 2048), codec.alloc(n * 2048), codec.alloc(n * 2048)
+            din.upload(x)
+            codec.dct32_fwd_inv_dev(din.ptr, dco.ptr, dre.ptr, n)
+            codec.stream_sync()
+            assert np.array_equal(dco.download(np.int16, n * 1024).reshape(n, 1024), z)
+            assert np.array_equal(dre.download(np.int16, n * 1024).reshape(n, 1024), oracle.dct32_inv(z, threads=8))
+    finally:
+        for k, v in saved.items():
+            codec.set_option(k, v)
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(ttype=st.integers(0, 1), size=st.sampled_from([4, 8, 16]), n=st.integers(1, 3000), kind=st.integers(0, 1), seed=st.integers(1, 1 << 30),
+       stage=st.integers(0, 1), tpw=st.integers(1, 4))
+def test_transform_set_random(codec, oracle, ttype, size, n, kind, seed, stage, tpw):
+    saved = {k: codec.get_option(k) for k in ("tr_lds_stage", "tr_tiles_per_wave", "adaptive_per_wave")}
+    try:
+        codec.set_option("tr_lds_stage", stage)
+        codec.set_option("tr_tiles_per_wave", tpw)
+        codec.set_option("adaptive_per_wave", seed & 1)
+        x = _data(kind, n, size * size, seed)
+        fwd = oracle.transform_fwd(ttype, size, x)
+        assert np.array_equal(codec.transform_fwd(ttype, size, x), fwd)
+        assert np.array_equal(codec.transform_inv(ttype, size, fwd), oracle.transform_inv(ttype, size, fwd))
+    finally:
+        for k, v in saved.items():
+            codec.set_option(k, v)
+
+
+@settings(max_examples=15, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n=st.integers(1, 300), seed=st.integers(1, 1 << 30))
+def test_intra_random(codec, oracle, n, seed):
+    refs = intra_refs_np(n, seed)
+    modes = ((np.arange(n) * 13 + seed) % 35).astype(np.uint8)
+    pred = codec.intra32_predict(refs, modes)
+    assert np.array_equal(pred, oracle.intra32_predict(refs, modes))
+    m = min(n, 40)
+    costs, best = codec.intra32_costs(refs[:m], pred[:m])
+    ocosts, obest = oracle.intra32_costs(refs[:m], pred[:m])
+    assert np.array_equal(costs, ocosts) and np.array_equal(best, obest)
+    assert np.all(costs[np.arange(m), modes[:m]] == 0)        # the block predicted by mode k costs nothing under mode k
