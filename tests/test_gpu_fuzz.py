@@ -98,3 +98,25 @@ def test_intra_random(codec, oracle, n, seed):
     ocosts, obest = oracle.intra32_costs(refs[:m], pred[:m])
     assert np.array_equal(costs, ocosts) and np.array_equal(best, obest)
     assert np.all(costs[np.arange(m), modes[:m]] == 0)        # the block predicted by mode k costs nothing under mode k
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(wb=st.integers(1, 14), hb=st.integers(1, 9), rng=st.integers(1, 24), tile_rows=st.sampled_from([1, 2, 4]),
+       row_pairs=st.integers(1, 3), variant=st.integers(1, 2), metric=st.sampled_from(["satd", "sad"]), seed=st.integers(1, 1 << 20))
+def test_motion_search_random(codec, oracle, wb, hb, rng, tile_rows, row_pairs, variant, metric, seed):
+    from _util import me_frames
+    w, h, pad = 8 * wb, 8 * hb, rng + (seed % 4)
+    cur, refp = me_frames(w, h, pad, seed, mv=(min(rng, seed % 5), -min(rng, seed % 3)))
+    saved = {k: codec.get_option(k) for k in ("me_tile_rows", "me_variant", "me_row_pairs")}
+    try:
+        codec.set_option("me_tile_rows", tile_rows)
+        codec.set_option("me_variant", variant)
+        codec.set_option("me_row_pairs", row_pairs)
+        mv, cost, costs = codec.satd_search(cur, refp, pad, rng, want_costs=True, metric=metric)
+        mv2, cost2, _ = codec.satd_search(cur, refp, pad, rng, metric=metric)
+    finally:
+        for k, v in saved.items():
+            codec.set_option(k, v)
+    omv, ocost, ocosts = oracle.satd_search(cur, refp, pad, rng, threads=8, want_costs=True, metric=metric)
+    assert np.array_equal(costs, ocosts) and np.array_equal(cost, ocost) and np.array_equal(mv, omv)
+    assert np.array_equal(cost2, ocost) and np.array_equal(mv2, omv)
