@@ -410,7 +410,20 @@ def main():
             per_ctu = {"value": world * n_ctu / wall_c, "unit": "CTUs/s", "hbm_frac": 4.0 * n_ctu * 4096 / wall_c / HBM_PEAK_BYTES_PER_S,
                        "layout": "64x64 CTUs whose 32x32 quadrants cycle through the seven classes (DCT-II 32/16/8/4, DST-VII 16/8/4), "
                                  "TUs of a quadrant contiguous; 7 calls per pass over offset tables", "ctus": n_ctu}
-            del zt, mixed, q, qbase, qkind
+            # the same buffer in ONE launch: every quadrant is a tile with its own class (xTransformTilesDev)
+            cls_of_kind = torch.tensor([3, 2, 6, 1, 5, 0, 4], device="cuda", dtype=torch.uint8)   # kinds above -> type*4 + log2N-2
+            tile_cls = cls_of_kind[qkind].contiguous()
+            for inv_flag, name in ((0, "per_ctu_one_launch"), (1, "per_ctu_one_launch_inverse")):
+                for _ in range(3):
+                    codec.transform_tiles_dev(inv_flag, x.data_ptr(), zt.data_ptr(), n_ctu * 4, 0, tile_cls.data_ptr(), stream)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(max(2, args.steps // 4)):
+                    codec.transform_tiles_dev(inv_flag, x.data_ptr(), zt.data_ptr(), n_ctu * 4, 0, tile_cls.data_ptr(), stream)
+                barrier()
+                wall_o = max_over_ranks(time.perf_counter() - t0) / max(2, args.steps // 4)
+                per_ctu[name] = {"value": world * n_ctu / wall_o, "unit": "CTUs/s", "hbm_frac": 4.0 * n_ctu * 4096 / wall_o / HBM_PEAK_BYTES_PER_S}
+            del zt, mixed, q, qbase, qkind, tile_cls
             also["transform_set"] = {"classes": ts, "per_ctu_mixed": per_ctu, "parity": "unpinned upstream except DCT-II 32; bit-exact vs this repo's oracle",
                                      "note": "wall-clock rates (launch gaps included); 4*N*N algorithmic bytes per block"}
         # ---- fused front end: tiled cur/pred frames -> coefficients / costs, residual never in HBM

@@ -124,6 +124,15 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
  * d_offsets as in the forward call. */
 int xTransformInvBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d_in, int16_t *d_out,
                           size_t n_blocks, const uint32_t *d_offsets, void *stream);
+/* The whole mixed set in ONE launch (BASELINE configs[3], "batched per CTU").  The buffers are sequences of
+ * 32x32-sample regions ("tiles", 1024 samples); tile t is cut into (32/N)^2 blocks of one (type, size) class,
+ * stored block-major, its class given by d_tile_class[t] = X266_TILE_CLASS(type, size) and its position by
+ * d_tile_offsets[t] (sample offset, a multiple of 8; NULL: tile t at t * 1024, i.e. the buffer is the tiles
+ * in order -- a CTU-ordered residual buffer whose 64x64 CTUs are four such tiles).  inverse = 0 forward,
+ * 1 inverse; results identical to the per-class calls above. */
+#define X266_TILE_CLASS(type, size) ((uint8_t)((type) * 4 + ((size) == 4 ? 0 : (size) == 8 ? 1 : (size) == 16 ? 2 : 3)))
+int xTransformTilesDev(x266hip_ctx *ctx, int inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles,
+                       const uint32_t *d_tile_offsets, const uint8_t *d_tile_class, void *stream);
 /* Full-search motion estimation with the 8x8 SATD cost (BASELINE configs[2]).
  * For every 8x8 block of `cur` (block grid aligned to (0,0); width, height
  * multiples of 8) and every displacement (dx,dy) in [-range, range]^2,

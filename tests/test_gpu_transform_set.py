@@ -146,6 +146,41 @@ def test_mixed_per_ctu_forward_32_by_offsets(codec, oracle):
     assert np.array_equal(dout.download(np.int16, x.size).reshape(64, 1024), oracle.dct32_fwd(x))
 
 
+@pytest.mark.parametrize("n_tiles,with_offsets", [(1, False), (7, False), (403, False), (403, True), (4096, False)])
+def test_mixed_tiles_one_launch(codec, oracle, n_tiles, with_offsets):
+    """xTransformTilesDev: every tile its own (type, size) class, one launch forward and one inverse, equal to the
+    oracle's per-class transforms of the tile's blocks."""
+    rng = np.random.default_rng(n_tiles + 17 * with_offsets)
+    cls_list = [(0, 4), (0, 8), (0, 16), (0, 32), (1, 4), (1, 8), (1, 16)]
+    pick = rng.integers(0, 7, n_tiles)
+    tile_class = np.array([t * 4 + {4: 0, 8: 1, 16: 2, 32: 3}[n] for t, n in (cls_list[p] for p in pick)], np.uint8)
+    n_slots = n_tiles + (5 if with_offsets else 0)
+    x = np.concatenate([residual_np(n_slots * 512, 3), fullrange_np(n_slots * 512, 4)]).astype(np.int16)
+    order = rng.permutation(n_slots)[:n_tiles].astype(np.uint32) if with_offsets else np.arange(n_tiles, dtype=np.uint32)
+    offsets = order * 1024
+    want_f = x.copy() if with_offsets else np.zeros_like(x)
+    want_i = want_f.copy()
+    for t in range(n_tiles):
+        ttype, n = cls_list[pick[t]]
+        blk = x[offsets[t]:offsets[t] + 1024].reshape(-1, n * n)
+        f = oracle.dct32_fwd(blk) if n == 32 else oracle.transform_fwd(ttype, n, blk)
+        want_f[offsets[t]:offsets[t] + 1024] = f.ravel()
+        inv = oracle.dct32_inv(f) if n == 32 else oracle.transform_inv(ttype, n, f)
+        want_i[offsets[t]:offsets[t] + 1024] = inv.ravel()
+    din, dco, dre = codec.alloc(x.nbytes), codec.alloc(x.nbytes), codec.alloc(x.nbytes)
+    din.upload(x)
+    dco.upload(x if with_offsets else np.zeros_like(x))
+    dre.upload(want_f if with_offsets else np.zeros_like(x))
+    dcls, doff = codec.alloc(max(n_tiles, 16)), codec.alloc(n_tiles * 4)
+    dcls.upload(tile_class)
+    doff.upload(offsets)
+    codec.transform_tiles_dev(False, din.ptr, dco.ptr, n_tiles, doff.ptr if with_offsets else 0, dcls.ptr)
+    codec.transform_tiles_dev(True, dco.ptr, dre.ptr, n_tiles, doff.ptr if with_offsets else 0, dcls.ptr)
+    codec.stream_sync()
+    assert np.array_equal(dco.download(np.int16, x.size)[: n_tiles * 1024 if not with_offsets else x.size], want_f[: n_tiles * 1024 if not with_offsets else x.size])
+    assert np.array_equal(dre.download(np.int16, x.size)[: n_tiles * 1024 if not with_offsets else x.size], want_i[: n_tiles * 1024 if not with_offsets else x.size])
+
+
 def test_argument_errors(codec):
     L = codec.L
     buf = codec.alloc(1 << 16)

@@ -74,6 +74,7 @@ def load_library():
     L.xSatd8x8FromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
     L.xSadBatchDev.argtypes = [_P, ctypes.c_int, _P, _P, _P, _SZ, _P]
     L.xTransformInvBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
+    L.xTransformTilesDev.argtypes = [_P, ctypes.c_int, _P, _P, _SZ, _P, _P, _P]
     L.xSatd8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, _P, _P, _P]
     L.xSad8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
@@ -312,6 +313,10 @@ class Codec:
         self.sad_dev(edge, da.ptr, db.ptr, do.ptr, n)
         self.stream_sync()
         return do.download(np.uint32, n)
+
+    def transform_tiles_dev(self, inverse, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, stream=0):
+        self._check(self.L.xTransformTilesDev(self.ctx, int(inverse), d_in, d_out, n_tiles, d_tile_offsets or None, d_tile_class, stream),
+                    "xTransformTilesDev")
 
     def transform_inv_dev(self, ttype, size, d_in, d_out, n_blocks, d_offsets=0, stream=0):
         self._check(self.L.xTransformInvBatchDev(self.ctx, ttype, size, d_in, d_out, n_blocks, d_offsets or None, stream), "xTransformInvBatchDev")

@@ -90,6 +90,56 @@ __global__ __launch_bounds__(256) void tr_fwd_small_kernel(const int16_t *__rest
     }
 }
 
+// One 32x32 tile of (32/N)^2 small blocks, block-major, sitting in a wave-private 2 KiB LDS slot: read the
+// lane's fragment pieces, run the two MFMA passes with the class's operand images, write the results back
+// in place.  Shared by the per-class kernels and the mixed-class tile kernel.
+template <int LOGN>
+__device__ __forceinline__ void fwd_tile_in_slot(unsigned char *slot, int lane, const LaneConsts &k)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int PER = 32 / N, PIECES = N >= 16 ? 1 : 16 / N;
+    constexpr int S1 = LOGN - 1, S2 = LOGN + 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int row = c & (N - 1), tile_row = c >> LOGN;
+    // byte offsets inside the 2 KiB tile of this lane's fragment pieces (block-major tile layout)
+    unsigned frag[PIECES];
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const unsigned sb = N == 32 ? 0u : (unsigned)(tile_row * PER + h * PIECES + q);
+        frag[q] = (sb * (unsigned)(N * N) + (unsigned)row * N + (N == 32 ? 16u * h : 0u)) * 2u;
+    }
+    uint32_t w[8];
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        if (N >= 16) {
+            const v4i a = *reinterpret_cast<const v4i *>(slot + frag[q]), b = *reinterpret_cast<const v4i *>(slot + frag[q] + 16);
+            w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = b[0]; w[5] = b[1]; w[6] = b[2]; w[7] = b[3];
+        } else if (N == 8) {
+            const v4i a = *reinterpret_cast<const v4i *>(slot + frag[q]);
+            w[4 * q] = a[0]; w[4 * q + 1] = a[1]; w[4 * q + 2] = a[2]; w[4 * q + 3] = a[3];
+        } else {
+            const uint2 a = *reinterpret_cast<const uint2 *>(slot + frag[q]);
+            w[2 * q] = a.x; w[2 * q + 1] = a.y;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    v4i r0, r1;
+    fwd_block<S1, S2>(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, k, r0, r1);
+    const uint32_t z[8] = {(uint32_t)r0[0], (uint32_t)r0[1], (uint32_t)r0[2], (uint32_t)r0[3],
+                           (uint32_t)r1[0], (uint32_t)r1[1], (uint32_t)r1[2], (uint32_t)r1[3]};
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        if (N >= 16) {
+            *reinterpret_cast<v4i *>(slot + frag[q]) = r0;
+            *reinterpret_cast<v4i *>(slot + frag[q] + 16) = r1;
+        } else if (N == 8) {
+            *reinterpret_cast<v4i *>(slot + frag[q]) = v4i{(int)z[4 * q], (int)z[4 * q + 1], (int)z[4 * q + 2], (int)z[4 * q + 3]};
+        } else {
+            *reinterpret_cast<uint2 *>(slot + frag[q]) = make_uint2(z[2 * q], z[2 * q + 1]);
+        }
+    }
+}
+
 // LDS-staged variant for contiguous batches: a tile's (32/N)^2 blocks are 2 KiB of consecutive
 // memory, moved with linear 1 KiB instructions (whole 128-byte lines per instruction, see
 // dct32_kernels.hip section "LDS-staged variant") and re-read from a wave-private LDS slot in
@@ -100,28 +150,18 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
                                                                const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
 {
     constexpr int N = 1 << LOGN;
-    constexpr int PER = 32 / N, PIECES = N >= 16 ? 1 : 16 / N, NSB = PER * PER;
-    constexpr int S1 = LOGN - 1, S2 = LOGN + 6;
+    constexpr int PER = 32 / N, NSB = PER * PER;
     extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 2 KiB per wave (+ occupancy padding)
     unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
 
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t n_tiles = (n_blocks + NSB - 1) / NSB;
     size_t t = wave * tiles_per_wave;
     const size_t t_end = t + tiles_per_wave < n_tiles ? t + tiles_per_wave : n_tiles;
     if (t >= t_end) return;
     const LaneConsts k = load_consts(ops, lane);
-    const int row = c & (N - 1), tile_row = c >> LOGN;
     const size_t total_bytes = n_blocks * (size_t)(N * N * 2);
-
-    // byte offsets inside the 2 KiB tile of this lane's fragment pieces (block-major tile layout)
-    unsigned frag[PIECES];
-#pragma unroll
-    for (int q = 0; q < PIECES; ++q) {
-        const unsigned sb = N == 32 ? 0u : (unsigned)(tile_row * PER + h * PIECES + q);
-        frag[q] = (sb * (unsigned)(N * N) + (unsigned)row * N + (N == 32 ? 16u * h : 0u)) * 2u;
-    }
     for (; t < t_end; ++t) {
         size_t o0, o1;
         bool live0, live1;
@@ -150,36 +190,7 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
         *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
         *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
         __builtin_amdgcn_wave_barrier();
-        uint32_t w[8];
-#pragma unroll
-        for (int q = 0; q < PIECES; ++q) {
-            if (N >= 16) {
-                const v4i a = *reinterpret_cast<const v4i *>(slot + frag[q]), b = *reinterpret_cast<const v4i *>(slot + frag[q] + 16);
-                w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = b[0]; w[5] = b[1]; w[6] = b[2]; w[7] = b[3];
-            } else if (N == 8) {
-                const v4i a = *reinterpret_cast<const v4i *>(slot + frag[q]);
-                w[4 * q] = a[0]; w[4 * q + 1] = a[1]; w[4 * q + 2] = a[2]; w[4 * q + 3] = a[3];
-            } else {
-                const uint2 a = *reinterpret_cast<const uint2 *>(slot + frag[q]);
-                w[2 * q] = a.x; w[2 * q + 1] = a.y;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        v4i r0, r1;
-        fwd_block<S1, S2>(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, k, r0, r1);
-        const uint32_t z[8] = {(uint32_t)r0[0], (uint32_t)r0[1], (uint32_t)r0[2], (uint32_t)r0[3],
-                               (uint32_t)r1[0], (uint32_t)r1[1], (uint32_t)r1[2], (uint32_t)r1[3]};
-#pragma unroll
-        for (int q = 0; q < PIECES; ++q) {
-            if (N >= 16) {
-                *reinterpret_cast<v4i *>(slot + frag[q]) = r0;
-                *reinterpret_cast<v4i *>(slot + frag[q] + 16) = r1;
-            } else if (N == 8) {
-                *reinterpret_cast<v4i *>(slot + frag[q]) = v4i{(int)z[4 * q], (int)z[4 * q + 1], (int)z[4 * q + 2], (int)z[4 * q + 3]};
-            } else {
-                *reinterpret_cast<uint2 *>(slot + frag[q]) = make_uint2(z[2 * q], z[2 * q + 1]);
-            }
-        }
+        fwd_tile_in_slot<LOGN>(slot, lane, k);
         __builtin_amdgcn_wave_barrier();
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
@@ -187,6 +198,62 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
         if (live0) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o0, s0);   // NT: "sc1 nt" (x266_device.hpp)
         if (live1) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o1, s1);
     }
+}
+
+// The inverse of fwd_tile_in_slot: the first contraction runs over the tile's ROW index, so each lane reads
+// its COLUMN out of the staged tile (16 x ds_read_u16), exactly as the staged DCT32 inverse does.
+template <int LOGN>
+__device__ __forceinline__ void inv_tile_in_slot(unsigned char *slot, int lane, const LaneConsts &k, const v16i &c2r)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int PER = 32 / N, PIECES = N >= 16 ? 1 : 16 / N;
+    const int c = lane & 31, h = lane >> 5;
+    const int row = c & (N - 1), tile_row = c >> LOGN;
+    unsigned frag[PIECES];                                              // output fragment pieces (as in the forward body)
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const unsigned sb = N == 32 ? 0u : (unsigned)(tile_row * PER + h * PIECES + q);
+        frag[q] = (sb * (unsigned)(N * N) + (unsigned)row * N + (N == 32 ? 16u * h : 0u)) * 2u;
+    }
+    // input column u = kappa(c), rows v = 16h + t: byte offset = col_base + ((t / N) * 64 * N + (t % N) * 2 * N)
+    const unsigned u = (unsigned)kappa(c);
+    const unsigned col_base = ((u >> LOGN) * (unsigned)(N * N) + (u & (N - 1))) * 2u + (unsigned)h * 1024u;
+    uint32_t w[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int t0 = 2 * m, t1 = 2 * m + 1;
+        const unsigned c0 = (unsigned)((t0 >> LOGN) * 64 * N + (t0 & (N - 1)) * 2 * N);
+        const unsigned c1 = (unsigned)((t1 >> LOGN) * 64 * N + (t1 & (N - 1)) * 2 * N);
+        const uint32_t e0 = *reinterpret_cast<const uint16_t *>(slot + col_base + c0);
+        const uint32_t e1 = *reinterpret_cast<const uint16_t *>(slot + col_base + c1);
+        w[m] = e0 | (e1 << 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    v4i lo, hi, r0, r1;
+    split_planes(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, lo, hi);
+    inv_passes(lo, hi, k, c2r, r0, r1);
+    const uint32_t z[8] = {(uint32_t)r0[0], (uint32_t)r0[1], (uint32_t)r0[2], (uint32_t)r0[3],
+                           (uint32_t)r1[0], (uint32_t)r1[1], (uint32_t)r1[2], (uint32_t)r1[3]};
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        if (N >= 16) {
+            *reinterpret_cast<v4i *>(slot + frag[q]) = r0;
+            *reinterpret_cast<v4i *>(slot + frag[q] + 16) = r1;
+        } else if (N == 8) {
+            *reinterpret_cast<v4i *>(slot + frag[q]) = v4i{(int)z[4 * q], (int)z[4 * q + 1], (int)z[4 * q + 2], (int)z[4 * q + 3]};
+        } else {
+            *reinterpret_cast<uint2 *>(slot + frag[q]) = make_uint2(z[2 * q], z[2 * q + 1]);
+        }
+    }
+}
+
+__device__ __forceinline__ v16i load_c2r(const DctOps *__restrict__ ops, int h)
+{
+    const int *__restrict__ s0 = ops->c2r[0], *__restrict__ s1 = ops->c2r[32];
+    v16i c2r;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c2r[r] = h ? s1[r] : s0[r];
+    return c2r;
 }
 
 // Inverse transforms of the set (UNPINNED upstream; columns first, shifts 7 and 12, int16 clipping
@@ -199,35 +266,19 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
                                                                const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
 {
     constexpr int N = 1 << LOGN;
-    constexpr int PER = 32 / N, PIECES = N >= 16 ? 1 : 16 / N, NSB = PER * PER;
+    constexpr int PER = 32 / N, NSB = PER * PER;
     extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
     unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
 
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t n_tiles = (n_blocks + NSB - 1) / NSB;
     size_t t = wave * tiles_per_wave;
     const size_t t_end = t + tiles_per_wave < n_tiles ? t + tiles_per_wave : n_tiles;
     if (t >= t_end) return;
     const LaneConsts k = load_consts(ops, lane);
-    v16i c2r;
-    {
-        const int *__restrict__ s0 = ops->c2r[0], *__restrict__ s1 = ops->c2r[32];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c2r[r] = h ? s1[r] : s0[r];
-    }
-    const int row = c & (N - 1), tile_row = c >> LOGN;
+    const v16i c2r = load_c2r(ops, lane >> 5);
     const size_t total_bytes = n_blocks * (size_t)(N * N * 2);
-    unsigned frag[PIECES];                                              // output fragment pieces (as in the forward kernel)
-#pragma unroll
-    for (int q = 0; q < PIECES; ++q) {
-        const unsigned sb = N == 32 ? 0u : (unsigned)(tile_row * PER + h * PIECES + q);
-        frag[q] = (sb * (unsigned)(N * N) + (unsigned)row * N + (N == 32 ? 16u * h : 0u)) * 2u;
-    }
-    // input column u = kappa(c), rows v = 16h + t: byte offset = col_base + ((t / N) * 64 * N + (t % N) * 2 * N)
-    const unsigned u = (unsigned)kappa(c);
-    const unsigned col_base = ((u >> LOGN) * (unsigned)(N * N) + (u & (N - 1))) * 2u + (unsigned)h * 1024u;
-
     for (; t < t_end; ++t) {
         size_t o0, o1;
         bool live0, live1;
@@ -254,33 +305,7 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
         *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
         *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
         __builtin_amdgcn_wave_barrier();
-        uint32_t w[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int t0 = 2 * m, t1 = 2 * m + 1;
-            const unsigned c0 = (unsigned)((t0 >> LOGN) * 64 * N + (t0 & (N - 1)) * 2 * N);
-            const unsigned c1 = (unsigned)((t1 >> LOGN) * 64 * N + (t1 & (N - 1)) * 2 * N);
-            const uint32_t e0 = *reinterpret_cast<const uint16_t *>(slot + col_base + c0);
-            const uint32_t e1 = *reinterpret_cast<const uint16_t *>(slot + col_base + c1);
-            w[m] = e0 | (e1 << 16);
-        }
-        __builtin_amdgcn_wave_barrier();
-        v4i lo, hi, r0, r1;
-        split_planes(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, lo, hi);
-        inv_passes(lo, hi, k, c2r, r0, r1);
-        const uint32_t z[8] = {(uint32_t)r0[0], (uint32_t)r0[1], (uint32_t)r0[2], (uint32_t)r0[3],
-                               (uint32_t)r1[0], (uint32_t)r1[1], (uint32_t)r1[2], (uint32_t)r1[3]};
-#pragma unroll
-        for (int q = 0; q < PIECES; ++q) {
-            if (N >= 16) {
-                *reinterpret_cast<v4i *>(slot + frag[q]) = r0;
-                *reinterpret_cast<v4i *>(slot + frag[q] + 16) = r1;
-            } else if (N == 8) {
-                *reinterpret_cast<v4i *>(slot + frag[q]) = v4i{(int)z[4 * q], (int)z[4 * q + 1], (int)z[4 * q + 2], (int)z[4 * q + 3]};
-            } else {
-                *reinterpret_cast<uint2 *>(slot + frag[q]) = make_uint2(z[2 * q], z[2 * q + 1]);
-            }
-        }
+        inv_tile_in_slot<LOGN>(slot, lane, k, c2r);
         __builtin_amdgcn_wave_barrier();
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
@@ -288,6 +313,60 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
         if (live0) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o0, s0);   // NT: "sc1 nt" (x266_device.hpp)
         if (live1) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o1, s1);
     }
+}
+
+// ---- mixed classes, one launch (BASELINE configs[3], "batched per CTU") ------------------------------------
+// A CTU's residual is a sequence of 32x32 regions ("tiles", 1024 samples), each cut into (32/N)^2 blocks of ONE
+// (type, size) class, block-major.  The per-class calls above walk the buffer once per class; this kernel walks it
+// once: tile t carries its class in tile_class[t] (type * 4 + log2N - 2) and sits at sample offset tile_offsets[t]
+// (NULL: t * 1024), the wave fetches that class's operand images (L1/L2-resident, 7 x 3.5 KiB) and runs the same
+// staged pipeline.  Consecutive tiles are consecutive memory, so the access stream is that of a contiguous batch.
+struct TileClassOps {
+    const DctOps *p[8];          // index = type * 4 + log2N - 2; [3] = (DCT-II, 32); [7] unused
+};
+
+template <bool INVERSE, bool NT>
+__global__ __launch_bounds__(256) void tr_tiles_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t n_tiles,
+                                                       const uint32_t *__restrict__ tile_offsets,
+                                                       const uint8_t *__restrict__ tile_class, const TileClassOps ops)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
+    unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+    const int lane = threadIdx.x & 63;
+    const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (t >= n_tiles) return;
+    const int cls = __builtin_amdgcn_readfirstlane((int)tile_class[t]) & 7;
+    const size_t base = (tile_offsets ? (size_t)tile_offsets[t] : t * 1024) * 2;
+    const char *src = reinterpret_cast<const char *>(in) + base + lane * 16;
+    const v4i g0 = load16<NT>(src), g1 = load16<NT>(src + 1024);
+    const DctOps *__restrict__ o = ops.p[cls];
+    const LaneConsts k = load_consts(o, lane);
+    *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
+    *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
+    __builtin_amdgcn_wave_barrier();
+    if (INVERSE) {
+        const v16i c2r = load_c2r(o, lane >> 5);
+        switch (cls & 3) {                                              // wave-uniform
+        case 0: inv_tile_in_slot<2>(slot, lane, k, c2r); break;
+        case 1: inv_tile_in_slot<3>(slot, lane, k, c2r); break;
+        case 2: inv_tile_in_slot<4>(slot, lane, k, c2r); break;
+        default: inv_tile_in_slot<5>(slot, lane, k, c2r); break;
+        }
+    } else {
+        switch (cls & 3) {
+        case 0: fwd_tile_in_slot<2>(slot, lane, k); break;
+        case 1: fwd_tile_in_slot<3>(slot, lane, k); break;
+        case 2: fwd_tile_in_slot<4>(slot, lane, k); break;
+        default: fwd_tile_in_slot<5>(slot, lane, k); break;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
+    const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
+    __builtin_amdgcn_wave_barrier();
+    char *dst = reinterpret_cast<char *>(out) + base + lane * 16;
+    store16m<NT ? 2 : 0>(dst, s0);
+    store16m<NT ? 2 : 0>(dst + 1024, s1);
 }
 
 }  // namespace
@@ -349,6 +428,29 @@ hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d
     if (log2n == 2) X266_TRI(2); else if (log2n == 3) X266_TRI(3); else if (log2n == 4) X266_TRI(4); else if (log2n == 5) X266_TRI(5);
     else return hipErrorInvalidValue;
 #undef X266_TRI
+    return hipGetLastError();
+}
+
+}  // namespace x266
+
+namespace x266 {
+
+hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles, const uint32_t *d_tile_offsets,
+                                  const uint8_t *d_tile_class, const DctOps *const class_ops[8], const LaunchCfg &cfg, hipStream_t stream)
+{
+    if (n_tiles == 0) return hipSuccess;
+    TileClassOps ops;
+    for (int i = 0; i < 8; ++i) ops.p[i] = class_ops[i];
+    const unsigned tpb = (unsigned)cfg.wg_threads;
+    const size_t wpw = tpb / 64, wgs = (n_tiles + wpw - 1) / wpw;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
+    dim3 grid((unsigned)wgs), block(tpb);
+    const bool nt = !d_tile_offsets && (cfg.nontemporal & 3);           // streaming hints only when the tiles are the whole buffer in order
+#define X266_TT(INV, NTV) hipLaunchKernelGGL((tr_tiles_kernel<INV, NTV>), grid, block, lds, stream, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, ops)
+    if (inverse) { if (nt) X266_TT(true, true); else X266_TT(true, false); }
+    else         { if (nt) X266_TT(false, true); else X266_TT(false, false); }
+#undef X266_TT
     return hipGetLastError();
 }
 

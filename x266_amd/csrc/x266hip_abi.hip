@@ -405,6 +405,26 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
     return X266HIP_OK;
 }
 
+int xTransformTilesDev(x266hip_ctx *ctx, int inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles,
+                       const uint32_t *d_tile_offsets, const uint8_t *d_tile_class, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (bad_ptrs(d_in, d_out, n_tiles) || (n_tiles && !d_tile_class)) return fail(ctx, X266HIP_EINVAL, "xTransformTilesDev: NULL or unaligned buffer");
+    if (n_tiles && ((uintptr_t)d_tile_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformTilesDev: unaligned offset table");
+    X_HIP(ctx, hipSetDevice(ctx->device));
+    const DctOps *ops[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int type = 0; type < 2; ++type)
+        for (int l = 0; l < 3; ++l) ops[type * 4 + l] = inverse ? ctx->d_tr_inv[type][l] : ctx->d_tr[type][l];
+    ops[3] = inverse ? ctx->d_inv_lds : ctx->d_fwd;
+    ops[7] = ops[3];                                                   // (DST-VII, 32) does not exist; keep the slot valid
+    LaunchCfg cfg = cfg_for(ctx, inverse ? 1 : 0);
+    cfg.wg_threads = inverse ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
+    cfg.lds_bytes_per_wave = 4096;                                      // three dependent fetches per tile (class, images, data): more waves in flight pay here (profiles/r01_tiles_one_launch.txt)
+    hipError_t e = launch_transform_tiles(inverse != 0, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, ops, cfg, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "tile transform launch", e);
+    return X266HIP_OK;
+}
+
 int xConvInputFmtDev(x266hip_ctx *ctx, x266_ref_block_t *d_tiles, const uint8_t *d_y, const uint8_t *d_u, const uint8_t *d_v,
                      intptr_t strdY, int width, int height, void *stream)
 {
