@@ -22,12 +22,18 @@
 //    rows of one column -- exactly the fragment shape of an MFMA *input*
 //    operand.  They are re-packed to bytes in registers and fed to pass 2,
 //    whose constant operand has its K-slots permuted to the accumulator row
-//    order (the contraction does not care about order).  No LDS, no shuffles,
-//    no barriers; the RTL's BRAM corner-turn (src/mkDct32.bsv:176-210,287-325,
-//    src/mkTranspose.bsv) has no counterpart here.
+//    order (the contraction does not care about order).  No shuffles, no
+//    barriers between the passes; the RTL's BRAM corner-turn
+//    (src/mkDct32.bsv:176-210,287-325, src/mkTranspose.bsv) has no counterpart.
+//    (LDS is used by the default kernels further down, but only as a layout
+//    converter so that global loads and stores are 1 KiB-linear.)
 //  * the lane<->frequency assignment of the constant operands is chosen so that
 //    each lane finishes with 16 consecutive coefficients of one output row:
 //    two 16-byte stores per lane, same address pattern as the loads.
+//
+// Kernels in this file: dct32_lds_kernel (default: LDS-staged line-dense traffic, forward / inverse),
+// dct32_fwdinv_lds_kernel (coefficients + reconstruction in one pass), dct32_from_tiles_kernel
+// (residual formation fused in), dct32_kernel (direct fragment loads, streaming or persistent: A/B only).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
