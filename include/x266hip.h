@@ -115,8 +115,10 @@ int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out,
  * d_offsets != NULL: block b lives at sample offset d_offsets[b] (a multiple of 8) in
  * both buffers -- the per-CTU mixed batches: one call per (type, size) class over a
  * shared residual / coefficient buffer pair. */
-#define X266_TR_DCT2 0
-#define X266_TR_DST7 1
+#define X266_TR_DCT2 0            /* DCT-II horizontally and vertically */
+#define X266_TR_DST7 1            /* DST-VII horizontally and vertically */
+#define X266_TR_DST7_DCT2 2       /* DST-VII horizontally (along rows), DCT-II vertically: N = 4, 8, 16 */
+#define X266_TR_DCT2_DST7 3       /* DCT-II horizontally, DST-VII vertically */
 int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d_in, int16_t *d_out,
                           size_t n_blocks, const uint32_t *d_offsets, void *stream);
 /* Inverse transforms of the same set (no upstream counterpart): columns first, shifts 7 and 12

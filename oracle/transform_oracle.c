@@ -76,15 +76,20 @@ static void tr_pass(const int16_t *m, int n, const int16_t *src, int16_t *dst, i
         }
 }
 
+/* type codes of the API: 0 DCT-II both ways, 1 DST-VII both ways, 2 DST-VII along rows (horizontal) + DCT-II
+ * vertically, 3 the other way round.  Pass 1 of the forward transform runs along rows. */
+static int htype_of(int type) { return (type == 1 || type == 2) ? ORC_TR_DST7 : ORC_TR_DCT2; }
+static int vtype_of(int type) { return (type == 1 || type == 3) ? ORC_TR_DST7 : ORC_TR_DCT2; }
+
 int orc_transform_fwd(int type, int n, const int16_t *in, int16_t *out, size_t n_blocks)
 {
-    int16_t m[32 * 32], tmp[32 * 32];
-    if (orc_transform_matrix(type, n, m)) return -1;
+    int16_t m[32 * 32], mv[32 * 32], tmp[32 * 32];
+    if (type < 0 || type > 3 || orc_transform_matrix(htype_of(type), n, m) || orc_transform_matrix(vtype_of(type), n, mv)) return -1;
     int log2n = 0;
     while ((1 << log2n) < n) log2n++;
     for (size_t b = 0; b < n_blocks; b++) {
         tr_pass(m, n, in + b * n * n, tmp, log2n - 1);
-        tr_pass(m, n, tmp, out + b * n * n, log2n + 6);
+        tr_pass(mv, n, tmp, out + b * n * n, log2n + 6);
     }
     return 0;
 }
@@ -107,10 +112,10 @@ static void tr_inv_pass(const int16_t *m, int n, const int16_t *src, int16_t *ds
 
 int orc_transform_inv(int type, int n, const int16_t *in, int16_t *out, size_t n_blocks)
 {
-    int16_t m[32 * 32], tmp[32 * 32];
-    if (orc_transform_matrix(type, n, m)) return -1;
+    int16_t m[32 * 32], mv[32 * 32], tmp[32 * 32];
+    if (type < 0 || type > 3 || orc_transform_matrix(htype_of(type), n, m) || orc_transform_matrix(vtype_of(type), n, mv)) return -1;
     for (size_t b = 0; b < n_blocks; b++) {
-        tr_inv_pass(m, n, in + b * n * n, tmp, 7);
+        tr_inv_pass(mv, n, in + b * n * n, tmp, 7);                   /* columns first: the vertical inverse */
         tr_inv_pass(m, n, tmp, out + b * n * n, 12);
     }
     return 0;

@@ -9,6 +9,8 @@ from _util import extremes_np, fullrange_np, residual_np, splitmix64
 pytestmark = pytest.mark.gpu
 
 CLASSES = [(0, 4), (0, 8), (0, 16), (0, 32), (1, 4), (1, 8), (1, 16)]
+# type 2 = DST-VII along rows + DCT-II vertically, type 3 = the other way round (include/x266hip.h)
+MIXED = [(2, 4), (2, 8), (2, 16), (3, 4), (3, 8), (3, 16)]
 
 
 @pytest.fixture(params=[1, 0], ids=["staged", "direct"])
@@ -18,7 +20,7 @@ def staging(request, codec):
     codec.set_option("tr_lds_stage", 1)
 
 
-@pytest.mark.parametrize("ttype,n", CLASSES)
+@pytest.mark.parametrize("ttype,n", CLASSES + MIXED)
 def test_contiguous_batches(codec, oracle, ttype, n, staging):
     per = n * n
     x = np.concatenate([residual_np(3001 * per, 50 + n), fullrange_np(2000 * per, 51 + n),
@@ -26,14 +28,14 @@ def test_contiguous_batches(codec, oracle, ttype, n, staging):
     assert np.array_equal(codec.transform_fwd(ttype, n, x), oracle.transform_fwd(ttype, n, x))
 
 
-@pytest.mark.parametrize("ttype,n", [c for c in CLASSES if c[1] < 32])
+@pytest.mark.parametrize("ttype,n", [c for c in CLASSES + MIXED if c[1] < 32])
 @pytest.mark.parametrize("count", [1, 2, 3, 5, 15, 16, 17, 63, 64, 65, 127, 129])
 def test_ragged_counts(codec, oracle, ttype, n, count, staging):
     x = fullrange_np(count * n * n, 900 + count + n).reshape(count, n * n)
     assert np.array_equal(codec.transform_fwd(ttype, n, x), oracle.transform_fwd(ttype, n, x))
 
 
-@pytest.mark.parametrize("ttype,n", CLASSES)
+@pytest.mark.parametrize("ttype,n", CLASSES + MIXED)
 def test_inverse_transforms(codec, oracle, ttype, n):
     per = n * n
     r = residual_np(2003 * per, 70 + n).reshape(-1, per)
@@ -47,7 +49,7 @@ def test_inverse_transforms(codec, oracle, ttype, n):
 
 
 def test_edge_blocks(codec, oracle):
-    for ttype, n in CLASSES:
+    for ttype, n in CLASSES + MIXED:
         per = n * n
         blocks = [np.zeros(per), np.full(per, 255), np.full(per, -256), np.full(per, 32767), np.full(per, -32768),
                   np.where(np.arange(per) % 2 == 0, 32767, -32768), (np.arange(per) % n) * 7 - (np.arange(per) // n) * 3]
@@ -151,8 +153,8 @@ def test_mixed_tiles_one_launch(codec, oracle, n_tiles, with_offsets):
     """xTransformTilesDev: every tile its own (type, size) class, one launch forward and one inverse, equal to the
     oracle's per-class transforms of the tile's blocks."""
     rng = np.random.default_rng(n_tiles + 17 * with_offsets)
-    cls_list = [(0, 4), (0, 8), (0, 16), (0, 32), (1, 4), (1, 8), (1, 16)]
-    pick = rng.integers(0, 7, n_tiles)
+    cls_list = CLASSES + MIXED
+    pick = rng.integers(0, len(cls_list), n_tiles)
     tile_class = np.array([t * 4 + {4: 0, 8: 1, 16: 2, 32: 3}[n] for t, n in (cls_list[p] for p in pick)], np.uint8)
     n_slots = n_tiles + (5 if with_offsets else 0)
     x = np.concatenate([residual_np(n_slots * 512, 3), fullrange_np(n_slots * 512, 4)]).astype(np.int16)
@@ -186,6 +188,7 @@ def test_argument_errors(codec):
     buf = codec.alloc(1 << 16)
     assert L.xTransformFwdBatchDev(codec.ctx, 0, 5, buf.ptr, buf.ptr + 4096, 4, None, None) < 0
     assert L.xTransformFwdBatchDev(codec.ctx, 1, 32, buf.ptr, buf.ptr + 4096, 1, None, None) < 0      # no DST-VII 32
-    assert L.xTransformFwdBatchDev(codec.ctx, 2, 8, buf.ptr, buf.ptr + 4096, 4, None, None) < 0
+    assert L.xTransformFwdBatchDev(codec.ctx, 4, 8, buf.ptr, buf.ptr + 4096, 4, None, None) < 0      # types are 0..3
+    assert L.xTransformFwdBatchDev(codec.ctx, 2, 32, buf.ptr, buf.ptr + 4096, 1, None, None) < 0     # size 32 is DCT-II only
     assert L.xTransformFwdBatchDev(codec.ctx, 0, 8, None, buf.ptr, 4, None, None) < 0
     assert L.xTransformFwdBatchDev(codec.ctx, 0, 8, None, None, 0, None, None) == 0

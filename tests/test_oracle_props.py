@@ -125,6 +125,32 @@ def test_transform_set_matches_numpy(oracle):
                 assert np.array_equal(out[b], z)
 
 
+def test_transform_set_mixed_directions(oracle):
+    """Types 2 and 3: DST-VII along rows with DCT-II vertically, and the other way round -- forward and inverse
+    against a numpy statement with two matrices; the pure types are the special case of equal matrices."""
+    for ttype, (th, tv) in ((2, (1, 0)), (3, (0, 1)), (0, (0, 0)), (1, (1, 1))):
+        for n in (4, 8, 16):
+            mh = oracle.transform_matrix(th, n).astype(np.int64)
+            mv = oracle.transform_matrix(tv, n).astype(np.int64)
+            s1, s2 = int(np.log2(n)) - 1, int(np.log2(n)) + 6
+            x = fullrange_np(5 * n * n, 140 + n + ttype).reshape(5, n, n)
+            out = oracle.transform_fwd(ttype, n, x).reshape(5, n, n)
+            for b in range(5):
+                y = ((np.einsum("kc,jc->kj", mh, x[b].astype(np.int64)) + (1 << (s1 - 1))) >> s1).astype(np.int16)   # rows: horizontal
+                z = ((np.einsum("vj,kj->vk", mv, y.astype(np.int64)) + (1 << (s2 - 1))) >> s2).astype(np.int16)      # then vertical
+                assert np.array_equal(out[b], z), (ttype, n)
+            zz = fullrange_np(4 * n * n, 150 + n + ttype).reshape(4, n, n)
+            inv = oracle.transform_inv(ttype, n, zz).reshape(4, n, n)
+            for b in range(4):
+                t = np.clip((np.einsum("kc,kj->jc", mv, zz[b].astype(np.int64)) + 64) >> 7, -32768, 32767)          # columns first: vertical
+                r = np.clip((np.einsum("kc,kj->jc", mh, t) + 2048) >> 12, -32768, 32767)
+                assert np.array_equal(inv[b], r.astype(np.int16)), (ttype, n)
+            r9 = residual_np(300 * n * n, 160 + n).reshape(-1, n * n)
+            rt = oracle.transform_inv(ttype, n, oracle.transform_fwd(ttype, n, r9))
+            assert np.abs(rt.astype(np.int32) - r9.astype(np.int32)).max() <= 6
+    assert oracle.lib.orc_transform_fwd(4, 8, None, None, 0) == -1
+
+
 # ---- frame container (src/x266.cpp:56-63, 415-492) ---------------------------------------
 def _yuv(w, h, seed):
     r = splitmix64(seed, 0, w * h * 3 // 2)

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
 // (NULL: t * 1024), the wave fetches that class's operand images (L1/L2-resident, 7 x 3.5 KiB) and runs the same
 // staged pipeline.  Consecutive tiles are consecutive memory, so the access stream is that of a contiguous batch.
 struct TileClassOps {
-    const DctOps *p[8];          // index = type * 4 + log2N - 2; [3] = (DCT-II, 32); [7] unused
+    const DctOps *p[16];         // index = type * 4 + log2N - 2, type 0..3; [3] = (DCT-II, 32)
 };
 
 template <bool INVERSE, bool NT>
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void tr_tiles_kernel(const int16_t *__restrict
     const int lane = threadIdx.x & 63;
     const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (t >= n_tiles) return;
-    const int cls = __builtin_amdgcn_readfirstlane((int)tile_class[t]) & 7;
+    const int cls = __builtin_amdgcn_readfirstlane((int)tile_class[t]) & 15;
     const size_t base = (tile_offsets ? (size_t)tile_offsets[t] : t * 1024) * 2;
     const char *src = reinterpret_cast<const char *>(in) + base + lane * 16;
     const v4i g0 = load16<NT>(src), g1 = load16<NT>(src + 1024);
@@ -436,11 +436,11 @@ hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d
 namespace x266 {
 
 hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles, const uint32_t *d_tile_offsets,
-                                  const uint8_t *d_tile_class, const DctOps *const class_ops[8], const LaunchCfg &cfg, hipStream_t stream)
+                                  const uint8_t *d_tile_class, const DctOps *const class_ops[16], const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
     TileClassOps ops;
-    for (int i = 0; i < 8; ++i) ops.p[i] = class_ops[i];
+    for (int i = 0; i < 16; ++i) ops.p[i] = class_ops[i];
     const unsigned tpb = (unsigned)cfg.wg_threads;
     const size_t wpw = tpb / 64, wgs = (n_tiles + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;

@@ -209,25 +209,26 @@ inline Matrix32 make_transform_matrix(int type, int n)
 
 // Forward operand images for an arbitrary 32x32 int8 matrix and shift pair
 // (same construction as build_fwd_ops; the byte-plane offset fix uses the row sums).
-inline void build_fwd_ops_general(DctOps &o, const Matrix32 &m, int shift1, int shift2)
+// m1 = matrix of pass 1 (along rows: the horizontal transform), m2 = matrix of pass 2 (vertical).
+inline void build_fwd_ops_general(DctOps &o, const Matrix32 &m1, const Matrix32 &m2, int shift1, int shift2)
 {
-    int rowsum[32] = {};
+    int rowsum1[32] = {}, rowsum2[32] = {};
     for (int k = 0; k < 32; ++k)
-        for (int c = 0; c < 32; ++c) rowsum[k] += m.v[k][c];
+        for (int c = 0; c < 32; ++c) { rowsum1[k] += m1.v[k][c]; rowsum2[k] += m2.v[k][c]; }
     for (int l = 0; l < 64; ++l) {
         const int c = l & 31, h = l >> 5;
         int8_t b1[16], b2[16];
         for (int t = 0; t < 16; ++t) {
-            b1[t] = m.v[kappa(c)][16 * h + t];
-            b2[t] = m.v[c][acc_row(t, h)];
+            b1[t] = m1.v[kappa(c)][16 * h + t];
+            b2[t] = m2.v[c][acc_row(t, h)];
         }
         for (int q = 0; q < 4; ++q) {
             o.lane[l].p1[q] = pack4(b1 + 4 * q);
             o.lane[l].p2[q] = pack4(b2 + 4 * q);
             o.lane[l].tr[q] = 0;
         }
-        o.lane[l].c1 = (1 << (shift1 - 1)) + 128 * rowsum[kappa(c)];
-        o.lane[l].c2 = (1 << (shift2 - 1)) + 128 * rowsum[c];
+        o.lane[l].c1 = (1 << (shift1 - 1)) + 128 * rowsum1[kappa(c)];
+        o.lane[l].c2 = (1 << (shift2 - 1)) + 128 * rowsum2[c];
         o.lane[l].pad[0] = o.lane[l].pad[1] = 0;
         for (int r = 0; r < 16; ++r) o.c2r[l][r] = o.lane[l].c2;
     }
@@ -235,30 +236,35 @@ inline void build_fwd_ops_general(DctOps &o, const Matrix32 &m, int shift1, int 
 
 // Inverse operand images for an arbitrary 32x32 int8 matrix, data operand of pass A in natural row
 // order (the staged kernel reads columns out of LDS); same construction as build_inv_ops(o, true).
-inline void build_inv_ops_general(DctOps &o, const Matrix32 &m)
+// ma = matrix of pass A (the vertical inverse, columns first), mb = matrix of pass B (horizontal).
+inline void build_inv_ops_general(DctOps &o, const Matrix32 &ma, const Matrix32 &mb)
 {
-    int colsum[32] = {};
+    int colsum_a[32] = {}, colsum_b[32] = {};
     for (int c = 0; c < 32; ++c)
-        for (int k = 0; k < 32; ++k) colsum[c] += m.v[k][c];
+        for (int k = 0; k < 32; ++k) { colsum_a[c] += ma.v[k][c]; colsum_b[c] += mb.v[k][c]; }
     for (int l = 0; l < 64; ++l) {
         const int c = l & 31, h = l >> 5;
         int8_t ba[16], ab[16];
         for (int t = 0; t < 16; ++t) {
-            ba[t] = m.v[16 * h + t][c];              // pass A: M[v][y = c]
-            ab[t] = m.v[16 * h + t][kappa(c)];       // pass B: M[u][x = kappa(c)]
+            ba[t] = ma.v[16 * h + t][c];             // pass A: M[v][y = c]
+            ab[t] = mb.v[16 * h + t][kappa(c)];      // pass B: M[u][x = kappa(c)]
         }
         for (int q = 0; q < 4; ++q) {
             o.lane[l].p1[q] = pack4(ba + 4 * q);
             o.lane[l].p2[q] = pack4(ab + 4 * q);
             o.lane[l].tr[q] = 0;
         }
-        o.lane[l].c1 = (1 << 6) + 128 * colsum[c];
+        o.lane[l].c1 = (1 << 6) + 128 * colsum_a[c];
         o.lane[l].c2 = 0;
         o.lane[l].pad[0] = o.lane[l].pad[1] = 0;
-        for (int r = 0; r < 16; ++r) o.c2r[l][r] = (1 << 11) + 128 * colsum[16 * h + r];
+        for (int r = 0; r < 16; ++r) o.c2r[l][r] = (1 << 11) + 128 * colsum_b[16 * h + r];
     }
 }
 
+// transform type codes of the API: 0 DCT-II both ways, 1 DST-VII both ways, 2 horizontal DST-VII + vertical DCT-II,
+// 3 horizontal DCT-II + vertical DST-VII (the implicit-MTS style combinations)
+constexpr int transform_htype(int type) { return (type == 1 || type == 2) ? kTrDst7 : kTrDct2; }
+constexpr int transform_vtype(int type) { return (type == 1 || type == 3) ? kTrDst7 : kTrDct2; }
 constexpr int transform_shift1(int n) { return (n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5) - 1; }   // log2N - 1  (8-bit video)
 constexpr int transform_shift2(int n) { return (n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5) + 6; }   // log2N + 6
 

@@ -25,8 +25,9 @@ struct x266hip_ctx {
     DctOps *d_fwd = nullptr;
     DctOps *d_inv = nullptr;
     DctOps *d_inv_lds = nullptr;                    // inverse operand images for the LDS-staged kernel (column reads)
-    DctOps *d_tr[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // [type][log2N - 2], N = 4, 8, 16
-    DctOps *d_tr_inv[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    static constexpr int kTypes = 4;                // DCT-II, DST-VII, and the two mixed horizontal / vertical pairs
+    DctOps *d_tr[kTypes][3] = {};                   // [type][log2N - 2], N = 4, 8, 16
+    DctOps *d_tr_inv[kTypes][3] = {};
     // options
     int wgs_per_cu_dct = 8;
     int wgs_per_cu_inv = 5;
@@ -175,14 +176,15 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
         ok = hipMalloc((void **)&ctx->d_inv_lds, sizeof(DctOps)) == hipSuccess &&
              hipMemcpy(ctx->d_inv_lds, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
     }
-    for (int type = 0; type < 2 && ok; ++type)
+    for (int type = 0; type < x266hip_ctx::kTypes && ok; ++type)
         for (int l = 0; l < 3 && ok; ++l) {
             const int n = 4 << l;
-            build_fwd_ops_general(*h, make_transform_matrix(type, n), transform_shift1(n), transform_shift2(n));
+            const Matrix32 mh = make_transform_matrix(transform_htype(type), n), mv = make_transform_matrix(transform_vtype(type), n);
+            build_fwd_ops_general(*h, mh, mv, transform_shift1(n), transform_shift2(n));
             ok = hipMalloc((void **)&ctx->d_tr[type][l], sizeof(DctOps)) == hipSuccess &&
                  hipMemcpy(ctx->d_tr[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
             if (!ok) break;
-            build_inv_ops_general(*h, make_transform_matrix(type, n));
+            build_inv_ops_general(*h, mv, mh);
             ok = hipMalloc((void **)&ctx->d_tr_inv[type][l], sizeof(DctOps)) == hipSuccess &&
                  hipMemcpy(ctx->d_tr_inv[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
         }
@@ -204,7 +206,7 @@ void xHipCodecFree(x266hip_ctx *ctx)
         if (ctx->d_stage_out[i]) (void)hipFree(ctx->d_stage_out[i]);
         if (ctx->stage_stream[i]) (void)hipStreamDestroy(ctx->stage_stream[i]);
     }
-    for (int type = 0; type < 2; ++type)
+    for (int type = 0; type < x266hip_ctx::kTypes; ++type)
         for (int l = 0; l < 3; ++l) {
             if (ctx->d_tr[type][l]) (void)hipFree(ctx->d_tr[type][l]);
             if (ctx->d_tr_inv[type][l]) (void)hipFree(ctx->d_tr_inv[type][l]);
@@ -377,7 +379,7 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
                           const uint32_t *d_offsets, void *stream)
 {
     if (!ctx) return X266HIP_EINVAL;
-    if (type != X266_TR_DCT2 && type != X266_TR_DST7) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: unknown transform type");
+    if (type < 0 || type >= x266hip_ctx::kTypes) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: unknown transform type");
     if (size != 4 && size != 8 && size != 16 && !(size == 32 && type == X266_TR_DCT2))
         return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: size must be 4, 8, 16 (or 32 for DCT-II)");
     if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: NULL or unaligned buffer");
@@ -412,11 +414,11 @@ int xTransformTilesDev(x266hip_ctx *ctx, int inverse, const int16_t *d_in, int16
     if (bad_ptrs(d_in, d_out, n_tiles) || (n_tiles && !d_tile_class)) return fail(ctx, X266HIP_EINVAL, "xTransformTilesDev: NULL or unaligned buffer");
     if (n_tiles && ((uintptr_t)d_tile_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformTilesDev: unaligned offset table");
     X_HIP(ctx, hipSetDevice(ctx->device));
-    const DctOps *ops[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    for (int type = 0; type < 2; ++type)
+    const DctOps *ops[16];
+    for (int type = 0; type < x266hip_ctx::kTypes; ++type) {
         for (int l = 0; l < 3; ++l) ops[type * 4 + l] = inverse ? ctx->d_tr_inv[type][l] : ctx->d_tr[type][l];
-    ops[3] = inverse ? ctx->d_inv_lds : ctx->d_fwd;
-    ops[7] = ops[3];                                                   // (DST-VII, 32) does not exist; keep the slot valid
+        ops[type * 4 + 3] = inverse ? ctx->d_inv_lds : ctx->d_fwd;     // size 32 exists for DCT-II only; the other slots stay valid
+    }
     LaunchCfg cfg = cfg_for(ctx, inverse ? 1 : 0);
     cfg.wg_threads = inverse ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
     cfg.lds_bytes_per_wave = 4096;                                      // three dependent fetches per tile (class, images, data): more waves in flight pay here (profiles/r01_tiles_one_launch.txt)
@@ -516,7 +518,7 @@ int xTransformInvBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
                           const uint32_t *d_offsets, void *stream)
 {
     if (!ctx) return X266HIP_EINVAL;
-    if (type != X266_TR_DCT2 && type != X266_TR_DST7) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: unknown transform type");
+    if (type < 0 || type >= x266hip_ctx::kTypes) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: unknown transform type");
     if (size != 4 && size != 8 && size != 16 && !(size == 32 && type == X266_TR_DCT2))
         return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: size must be 4, 8, 16 (or 32 for DCT-II)");
     if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: NULL or unaligned buffer");
