@@ -289,6 +289,9 @@ void               satd8x8_genNew(void);                  /* src_tb/satd.c:124  
 /* one row (8 x int16 = 4 words) per call                                     */
 void               satd8x8_getDiff(unsigned int res[]);   /* src_tb/satd.c:143  */
 unsigned int       satd8x8_getSatd(void);                 /* src_tb/satd.c:149  */
+/* Per-call twin of the RISC-V benchmark's sad() (riscv/programs/benchmarks/sad/sad.c:28-39): same arguments and
+ * result, on the GPU, through the same lazily created context; n in {4, 8, 16, 32, 64}, -1 otherwise. */
+int                x266_sad(const unsigned char *input_data1, const unsigned char *input_data2, size_t n);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,21 @@ def test_reference_known_answer(codec):
         assert int(codec.sad(edge, a, b).sum()) == 344807
 
 
+def test_per_call_twin_of_the_benchmark_function(codec):
+    """x266_sad(a, b, n): same arguments and result as sad() of riscv/programs/benchmarks/sad/sad.c:28-39."""
+    import ctypes
+    L = codec.L
+    L.x266_sad.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.x266_sad.restype = ctypes.c_int
+    g = np.load(os.path.join(GOLDEN_DIR, "sad64.npz"))
+    a, b = np.ascontiguousarray(g["a"], np.uint8).ravel(), np.ascontiguousarray(g["b"], np.uint8).ravel()
+    assert L.x266_sad(a.ctypes.data, b.ctypes.data, 64) == 344807                     # the benchmark's own check value
+    for n in (4, 8, 16, 32):
+        x, y = a[: n * n], b[: n * n]
+        assert L.x266_sad(x.ctypes.data, y.ctypes.data, n) == int(np.abs(x.astype(np.int64) - y.astype(np.int64)).sum())
+    assert L.x266_sad(a.ctypes.data, b.ctypes.data, 5) == -1 and L.x266_sad(None, b.ctypes.data, 8) == -1
+
+
 @pytest.mark.parametrize("edge", [4, 8, 16, 32, 64])
 @pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 63, 64, 65, 1000, 4097])
 def test_random_batches(codec, edge, n):

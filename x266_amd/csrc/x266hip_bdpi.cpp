@@ -152,4 +152,27 @@ void satd8x8_getDiff(unsigned int res[])
 
 unsigned int satd8x8_getSatd(void) { return s_satd_val; }
 
+// Per-call twin of sad() (riscv/programs/benchmarks/sad/sad.c:28-39: same arguments, same result), computed on
+// the GPU through the lazily created context of the shims above.  n must be 4, 8, 16, 32 or 64.
+int x266_sad(const unsigned char *input_data1, const unsigned char *input_data2, size_t n)
+{
+    if (!input_data1 || !input_data2 || !(n == 4 || n == 8 || n == 16 || n == 32 || n == 64)) return -1;
+    static void *d_buf = nullptr;                                  // two 64x64 blocks + the result, kept for the process
+    x266hip_ctx *ctx = bdpi_ctx();
+    RandStateGuard keep_rand_sequence;                             // as for the BDPI shims: the runtime may draw from rand()
+    if (!d_buf) {
+        const int rc = xHipMalloc(ctx, &d_buf, 2 * 4096 + 16);
+        if (rc != X266HIP_OK) die("xHipMalloc", rc);
+    }
+    unsigned char *a = static_cast<unsigned char *>(d_buf), *b = a + 4096;
+    uint32_t *d_out = reinterpret_cast<uint32_t *>(a + 8192);
+    uint32_t out = 0;
+    int rc = xHipMemcpyH2D(ctx, a, input_data1, n * n);
+    if (rc == X266HIP_OK) rc = xHipMemcpyH2D(ctx, b, input_data2, n * n);
+    if (rc == X266HIP_OK) rc = xSadBatchDev(ctx, (int)n, a, b, d_out, 1, nullptr);
+    if (rc == X266HIP_OK) rc = xHipMemcpyD2H(ctx, &out, d_out, sizeof(out));
+    if (rc != X266HIP_OK) die("x266_sad", rc);
+    return (int)out;
+}
+
 }  // extern "C"
