@@ -56,6 +56,8 @@ typedef struct x266hip_ctx x266hip_ctx;     /* opaque, one per (thread, device) 
  * of the coefficient matrix (g_t32, src_tb/dct32.c:30-64).  Fails with
  * X266HIP_EDEVICE when the device is not a gfx950 part. */
 int  xHipCodecInit(x266hip_ctx **ctx, int device_id);
+/* Number of HIP devices visible to the process (0 when there is none or the runtime fails). */
+int  xHipDeviceCount(void);
 void xHipCodecFree(x266hip_ctx *ctx);
 /* Last error text of this context (never NULL; "" when none). */
 const char *xHipLastError(const x266hip_ctx *ctx);
@@ -258,6 +260,101 @@ void xHipGraphFree(x266hip_ctx *ctx, x266hip_graph *graph);
  * op: 0 = dct32 fwd, 1 = dct32 inv, 2 = satd8x8 (buffers as in the Dev calls). */
 int xHipTimeKernel(x266hip_ctx *ctx, int op, const void *d_in, void *d_out,
                    size_t n_blocks, int reps, void *stream, double *ms_per_launch);
+/* HIP events for hosts without HIP headers, so that ANY sequence of the ...Dev calls can be timed on the
+ * stream it is launched on (record an event before every launch and one after the last: consecutive
+ * differences are per-launch durations).  xHipEventElapsedMs waits for `stop` and returns stop - start. */
+int xHipEventCreate(x266hip_ctx *ctx, void **event);
+int xHipEventDestroy(x266hip_ctx *ctx, void *event);
+int xHipEventRecord(x266hip_ctx *ctx, void *event, void *stream);
+int xHipEventElapsedMs(x266hip_ctx *ctx, void *start, void *stop, double *ms);
+
+/* ------------------------------------------------------------------------ */
+/* one node, several GPUs (BASELINE configs[4])                    */
+/*                                                                          */
+/* Blocks are independent (src_tb/dct32.c:75,167-168; satd8x8 is a pure      */
+/* function, src_tb/satd.c:31-118), so the only multi-GPU traffic is moving   */
+/* shards: the root rank (rank 0) owns the frame, every rank gets a           */
+/* contiguous shard of each batch, transforms it, and returns the results.    */
+/* Transport is RCCL point-to-point: ONE ncclGroupStart/End of               */
+/* ncclSend/ncclRecv per step, so that all of the root's xGMI links and both  */
+/* directions of each are busy at once; librccl.so.1 is opened on first use   */
+/* (dlopen), so hosts that never create a node do not load it.  Two process    */
+/* models, same calls afterwards:                                             */
+/*   xHipNodeInit      one process drives n devices (ncclCommInitAll)         */
+/*   xHipNodeInitRank  one process per GPU (ncclCommInitRank); every rank     */
+/*                     makes the same sequence of xNode... calls              */
+/* ------------------------------------------------------------------------ */
+#define X266HIP_ECOMM    (-4)   /* RCCL unavailable or a communication call failed */
+#define X266HIP_NODE_ID_BYTES 128
+typedef struct x266hip_node x266hip_node;
+typedef struct x266hip_nstream x266hip_nstream;
+
+/* Host-only planning (no device needed; also what the CPU tests of the N > 1 logic call).
+ * xShardRange: rank's contiguous [begin, end) of n_units; the first n_units % world ranks take one extra.
+ * xMeStripePlan: motion search partition into horizontal stripes of 8-pixel block rows -- stripe's block
+ * rows [*block_row_begin, *block_row_end) and the reference rows [*ref_row_begin, *ref_row_end) it reads
+ * (frame row coordinates of the padded reference: may be negative / exceed height by up to `range`; the
+ * halo is read-only input that travels with the scatter, there is no exchange step).  Returns 0 / EINVAL. */
+int  xShardRange(size_t n_units, int rank, int world, size_t *begin, size_t *end);
+int  xMeStripePlan(int height, int range, int stripe, int n_stripes, int *block_row_begin, int *block_row_end,
+                   int *ref_row_begin, int *ref_row_end);
+
+int  xHipNodeInit(x266hip_node **node, const int *devices, int n_devices);       /* devices NULL: 0..n-1 */
+int  xHipNodeUniqueId(void *id /* X266HIP_NODE_ID_BYTES, from rank 0, handed to every rank by the host */);
+int  xHipNodeInitRank(x266hip_node **node, int device, int rank, int world, const void *id);
+void xHipNodeFree(x266hip_node *node);
+int  xHipNodeWorld(const x266hip_node *node);
+int  xHipNodeLocalCount(const x266hip_node *node);                               /* ranks driven by this process */
+int  xHipNodeLocalRank(const x266hip_node *node, int local_index);               /* their global ranks */
+x266hip_ctx *xHipNodeCtx(x266hip_node *node, int local_index);                   /* owned by the node */
+const char *xHipNodeLastError(const x266hip_node *node);
+/* "transport": 0 RCCL send/recv groups (default), 1 hipMemcpyPeerAsync (single-process nodes only);
+ * "me_local_copy": 1 = the root's own motion-search stripes also go through stripe buffers (what a peer
+ * receives) instead of being searched in place -- exercises the halo logic on one GPU (default 0). */
+int  xHipNodeSetOption(x266hip_node *node, const char *key, int value);
+/* Communication self-check: every rank sends a pattern to the next rank and receives from the previous
+ * one inside one RCCL group (with one rank: to itself), then all ranks all-reduce a checksum. */
+int  xHipNodeSelfTest(x266hip_node *node);
+
+/* A stream of frames, each a fixed set of "lanes" (one batch per lane).  op: 0 = DCT32 forward
+ * (2048 B in / 2048 B out per unit), 1 = DCT32 inverse, 2 = 8x8 SATD (128 B in / 4 B out).
+ * xNodeFrameStreamCreate: the two lanes of BASELINE configs[4] for a width x height luma frame:
+ * (width/32)*(height/32) DCT32 blocks and (width/8)*(height/8) SATD blocks. */
+int  xNodeStreamCreate(x266hip_node *node, int n_lanes, const int *ops, const size_t *max_units, x266hip_nstream **s);
+int  xNodeFrameStreamCreate(x266hip_node *node, int width, int height, x266hip_nstream **s);
+void xNodeStreamFree(x266hip_nstream *s);
+/* Step t (the t-th Push/Flush step of this stream), pipelined and asynchronous: one RCCL group moves
+ * frame t's shards root -> peers AND frame t-2's results peers -> root, then every rank's kernels for
+ * frame t are enqueued; so while frame t is transformed, frame t+1's inputs and frame t-1's outputs
+ * are on the links.  d_in[lane] / d_out[lane]: on the process that drives the root rank, device
+ * pointers on the root's device of the lane's input units and of the caller-owned buffer that receives
+ * its results (zero-copy: the root transforms its own shard in place, peers' shards are sent from /
+ * received into these buffers directly); ignored on other processes (may be NULL).  units[lane]
+ * (NULL: the stream's max_units) must be the same on every rank.  producer_stream: the root-device
+ * stream the inputs were produced on (ordering by event; NULL = the default stream).
+ * Inputs of a step may be overwritten, and its ticket waited for, once two later steps have been issued
+ * (Push or Flush).  *ticket (may be NULL) receives t. */
+int  xNodeStreamPush(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units,
+                     void *producer_stream, long *ticket);
+/* Issues the two draining steps and blocks until every pushed frame's results are in place. */
+int  xNodeStreamFlush(x266hip_nstream *s);
+/* Blocks the host until the results of step `ticket` are complete in their d_out buffers (root), or
+ * the step's shard has left (peers).  No communication; EINVAL when fewer than two later steps exist. */
+int  xNodeStreamWait(x266hip_nstream *s, long ticket);
+/* One batch through the same machinery (SURVEY 8e "end-to-end scatter -> compute -> gather"): the batch
+ * is cut into chunks of chunk_units (0: 4096 DCT blocks / 65536 SATD blocks), pushed as frames, flushed.
+ * Synchronous.  d_in / d_out on the root as above. */
+int  xNodeBatchScatterGather(x266hip_node *node, int op, const void *d_in, void *d_out, size_t n_units,
+                             size_t chunk_units);
+/* Full-search motion estimation of one frame over the node (xSatd8x8SearchDev semantics and argument
+ * meaning; d_cur / d_ref / d_best on the root's device, NULL elsewhere): the frame is cut into
+ * n_stripes horizontal stripes (0: one per rank) dealt to the ranks in contiguous runs; the root sends
+ * each stripe of `cur` and the stripe's rows +- range of the padded reference, every rank searches its
+ * stripes, the (mv, cost) records return to d_best.  Results are identical to the single-device call
+ * for any n_stripes.  Synchronous. */
+int  xNodeSatd8x8Search(x266hip_node *node, const uint8_t *d_cur, intptr_t cur_stride, const uint8_t *d_ref,
+                        intptr_t ref_stride, int width, int height, int range, int n_stripes,
+                        x266_me_result_t *d_best);
 
 /* ------------------------------------------------------------------------ */
 /* host-only utilities (no device needed)                                     */

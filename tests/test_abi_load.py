@@ -78,3 +78,31 @@ def test_product_does_not_link_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 text = open(os.path.join(root, f)).read()
                 assert "liborc" not in text and "oracle/" not in text.replace("oracle/ ", ""), f
+
+
+def test_only_the_header_surface_is_exported(lib):
+    """the library is linked into third-party executables -- nothing but the C ABI of
+    include/x266hip.h (plus g_t32) may be visible (version script libx266hip.map)."""
+    import subprocess
+    declared = set(_declared_symbols()) | {"g_t32"}
+    out = subprocess.check_output(["nm", "-D", "--defined-only", x266_amd.lib_path()]).decode()
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert exported <= declared, "exported but not declared in include/x266hip.h: %s" % sorted(exported - declared)
+    assert not [s for s in exported if s.startswith("_Z")]
+
+
+def test_node_layer_without_a_gpu(lib):
+    """The multi-GPU layer: planning functions are host-only; a node cannot be made without devices
+    (no CPU path), NULL handles are rejected, and RCCL is NOT a link-time dependency of the drop-in."""
+    import subprocess
+    import torch
+    from x266_amd.node import Node, me_stripe_plan, shard_range
+    assert shard_range(10, 0, 3) == (0, 4) and shard_range(10, 2, 3) == (7, 10)
+    assert me_stripe_plan(2160, 64, 0, 8) == ((0, 34), (-64, 34 * 8 + 64))
+    assert "rccl" not in subprocess.check_output(["ldd", x266_amd.lib_path()]).decode()
+    assert lib.xNodeStreamFlush(None) < 0 and lib.xNodeStreamWait(None, 0) < 0
+    assert lib.xHipNodeSelfTest(None) < 0 and lib.xNodeBatchScatterGather(None, 0, None, None, 4, 0) < 0
+    if not torch.cuda.is_available():
+        assert lib.xHipDeviceCount() == 0
+        with pytest.raises(x266_amd.X266Error):
+            Node.single_process([0])

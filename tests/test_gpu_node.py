@@ -1,0 +1,177 @@
+"""GPU: the node part of the C ABI (include/x266hip.h "one node, several GPUs") -- BASELINE configs[4].
+
+On the one-GPU test box a node has one rank: the RCCL communicator, the send/recv groups and the
+all-reduce still execute (xHipNodeSelfTest sends to / receives from itself inside a group), the pipelined
+schedule runs with its streams and events, and the frame is transformed in place.  What cannot run here is
+a transfer between two devices; its plan (shards, stripes, ordering) is covered by the gloo tests and by
+host/stream8k.c, which validates any number of devices against the single-device result."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import x266_amd
+from x266_amd.node import Node, OP_DCT32_FWD, OP_DCT32_INV, OP_SATD8X8
+from _util import me_frames
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def node():
+    n = Node.single_process([0])
+    yield n
+    n.close()
+
+
+def test_rccl_executes_on_this_box(node):
+    assert node.world == 1 and node.local_ranks == [0] and node.drives_root
+    node.self_test()                                  # ncclCommInitAll + group{send, recv} + all-reduce, checked word by word
+
+
+def test_process_per_gpu_init_with_unique_id():
+    uid = Node.unique_id()
+    n = Node.for_rank(0, 0, 1, uid)                   # the call sequence bench.py --gpus N makes on every rank
+    n.self_test()
+    n.close()
+
+
+def _frame(oracle, geo_blocks, seed, f):
+    return oracle.fill_residual(geo_blocks, seed, f * 10 ** 7)
+
+
+@pytest.mark.parametrize("w,h,n_frames", [(96, 160, 7), (7680, 4320, 4)])
+def test_frame_stream_is_bit_exact(node, oracle, w, h, n_frames):
+    """configs[4] at its own size: 7680x4320 = 32 400 DCT32 + 518 400 SATD blocks per frame, pipelined
+    (two frames in flight, slots reused), every frame compared whole with the oracle."""
+    n_d, n_s = (w // 32) * (h // 32), (w // 8) * (h // 8)
+    st = node.frame_stream(w, h)
+    dev = torch.device("cuda", 0)
+    xin = [(torch.from_numpy(_frame(oracle, n_d * 1024, 0x266, f)).to(dev), torch.from_numpy(_frame(oracle, n_s * 64, 0x267, f)).to(dev))
+           for f in range(n_frames)]
+    out = [(torch.zeros(n_d * 1024, dtype=torch.int16, device=dev), torch.zeros(n_s, dtype=torch.int32, device=dev)) for _ in range(n_frames)]
+    torch.cuda.synchronize()
+    tickets = []
+    for f in range(n_frames):
+        tickets.append(st.push([xin[f][0].data_ptr(), xin[f][1].data_ptr()], [out[f][0].data_ptr(), out[f][1].data_ptr()]))
+        if f >= 2:
+            st.wait(tickets[f - 2])                   # complete two steps later, without a flush
+            assert np.array_equal(out[f - 2][0].cpu().numpy(), oracle.dct32_fwd(xin[f - 2][0].cpu().numpy(), threads=32).ravel()), f - 2
+    with pytest.raises(x266_amd.X266Error):
+        st.wait(tickets[-1])                          # its results have not travelled yet
+    st.flush()
+    for f in range(n_frames):
+        assert np.array_equal(out[f][0].cpu().numpy(), oracle.dct32_fwd(xin[f][0].cpu().numpy(), threads=32).ravel()), f
+        assert np.array_equal(out[f][1].cpu().numpy(), oracle.satd8x8(xin[f][1].cpu().numpy(), threads=32).astype(np.int32)), f
+    st.close()
+
+
+def test_stream_takes_ragged_unit_counts_and_inverse_lane(node, oracle):
+    dev = torch.device("cuda", 0)
+    st = node.stream([OP_DCT32_INV, OP_SATD8X8, OP_DCT32_FWD], [40, 1000, 40])
+    z = torch.from_numpy(oracle.fill_residual(40 * 1024, 5)).to(dev)
+    d = torch.from_numpy(oracle.fill_residual(1000 * 64, 6)).to(dev)
+    for units in ([40, 1000, 40], [17, 999, 0], [1, 1, 40]):
+        o0 = torch.zeros(40 * 1024, dtype=torch.int16, device=dev)
+        o1 = torch.zeros(1000, dtype=torch.int32, device=dev)
+        o2 = torch.zeros(40 * 1024, dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        st.push([z.data_ptr(), d.data_ptr(), z.data_ptr()], [o0.data_ptr(), o1.data_ptr(), o2.data_ptr()], units)
+        st.flush()
+        a, b, c = units
+        assert np.array_equal(o0.cpu().numpy()[: a * 1024], oracle.dct32_inv(z.cpu().numpy()[: a * 1024]).ravel())
+        assert not o0.cpu().numpy()[a * 1024:].any()
+        assert np.array_equal(o1.cpu().numpy()[:b], oracle.satd8x8(d.cpu().numpy()[: b * 64]).astype(np.int32))
+        assert np.array_equal(o2.cpu().numpy()[: c * 1024], oracle.dct32_fwd(z.cpu().numpy()[: c * 1024]).ravel())
+    with pytest.raises(x266_amd.X266Error):
+        st.push([z.data_ptr(), d.data_ptr(), z.data_ptr()], [o0.data_ptr(), o1.data_ptr(), o2.data_ptr()], [41, 1, 1])
+    st.close()
+
+
+@pytest.mark.parametrize("op,n,chunk", [(OP_DCT32_FWD, 10000, 0), (OP_SATD8X8, 200001, 4096), (OP_DCT32_INV, 5, 2)])
+def test_batch_scatter_gather(node, oracle, op, n, chunk):
+    dev = torch.device("cuda", 0)
+    unit = 64 if op == OP_SATD8X8 else 1024
+    x = oracle.fill_residual(n * unit, 77)
+    tin = torch.from_numpy(x).to(dev)
+    tout = torch.zeros(n if op == OP_SATD8X8 else n * 1024, dtype=torch.int32 if op == OP_SATD8X8 else torch.int16, device=dev)
+    torch.cuda.synchronize()
+    node.batch_scatter_gather(op, tin.data_ptr(), tout.data_ptr(), n, chunk)
+    want = {OP_DCT32_FWD: lambda: oracle.dct32_fwd(x, threads=16).ravel(), OP_DCT32_INV: lambda: oracle.dct32_inv(x, threads=16).ravel(),
+            OP_SATD8X8: lambda: oracle.satd8x8(x, threads=16).astype(np.int32)}[op]()
+    assert np.array_equal(tout.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("w,h,rng", [(256, 200, 16), (136, 72, 64)])
+def test_sharded_motion_search_gives_identical_winners(node, codec, w, h, rng):
+    """A frame searched as 1, 2 and 5 stripes (and more stripes than block rows) gives the records of the
+    single-device call; with me_local_copy the stripes go through stripe buffers holding exactly what a peer
+    would receive (stripe of cur, stripe +- range rows of the reference), so a wrong halo shows up."""
+    cur, refp = me_frames(w, h, rng, 0x51, mv=(3, -2))
+    mv0, cost0, _ = codec.satd_search(cur, refp, rng, rng)
+    dev = torch.device("cuda", 0)
+    tc, tr = torch.from_numpy(cur).to(dev), torch.from_numpy(refp).to(dev)
+    nb = (h // 8) * (w // 8)
+    origin = tr.data_ptr() + rng * tr.stride(0) + rng
+    for local_copy in (0, 1):
+        node.set_option("me_local_copy", local_copy)
+        for n_stripes in (0, 1, 2, 5, h // 8 + 3):
+            best = torch.zeros(nb * 2, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            node.satd_search(tc.data_ptr(), tc.stride(0), origin, tr.stride(0), w, h, rng, n_stripes, best.data_ptr())
+            raw = best.cpu().numpy()
+            mv = raw.view(np.int16).reshape(nb, 4)[:, :2]
+            cost = raw.view(np.uint32).reshape(nb, 2)[:, 1]
+            assert np.array_equal(mv, mv0) and np.array_equal(cost, cost0), (local_copy, n_stripes)
+    node.set_option("me_local_copy", 0)
+
+
+def test_plain_c_host_stream8k():
+    """host/stream8k.c: the node API from a C host with no HIP headers, all visible devices, 7680x4320;
+    it validates every frame against the single-device calls before timing."""
+    exe = os.path.join(ROOT, "host", "stream8k")
+    assert os.path.exists(exe), "host/stream8k is not built (make -C host)"
+    r = subprocess.run([exe, "0", "50"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["bit_exact_vs_single_device"] is True and line["frames_per_s"] > 100
+
+
+def test_calls_restore_the_callers_device(codec):
+    """entry points run on the context's device and put the caller's current device back."""
+    assert torch.cuda.current_device() == 0
+    x = torch.zeros(1024, dtype=torch.int16, device="cuda")
+    codec.dct32_fwd_dev(x.data_ptr(), x.clone().data_ptr(), 1)
+    torch.cuda.synchronize()
+    assert torch.cuda.current_device() == 0
+
+
+def test_searches_on_two_streams_do_not_share_scratch(codec, oracle):
+    """the search's coefficient scratch is per stream -- two searches of different frames
+    enqueued on two streams at once give what they give alone."""
+    rng = 8
+    frames = [me_frames(512, 256, rng, seed, mv=(1 + seed % 3, -1)) for seed in (11, 12)]
+    alone = [codec.satd_search(c, r, rng, rng)[:2] for c, r in frames]
+    dev = torch.device("cuda", 0)
+    streams = [codec.stream_create() for _ in frames]
+    bufs = []
+    for c, r in frames:
+        tc, tr = torch.from_numpy(c).to(dev), torch.from_numpy(r).to(dev)
+        bufs.append((tc, tr, torch.zeros((256 // 8) * (512 // 8) * 2, dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    for _ in range(8):                                # interleaved launches, both streams busy at once
+        for (tc, tr, best), s in zip(bufs, streams):
+            codec.satd_search_dev(tc.data_ptr(), tc.stride(0), tr.data_ptr() + rng * tr.stride(0) + rng, tr.stride(0), 512, 256, rng,
+                                  best.data_ptr(), 0, s)
+    for s in streams:
+        codec.stream_sync(s)
+    for (tc, tr, best), (mv0, cost0) in zip(bufs, alone):
+        raw = best.cpu().numpy()
+        assert np.array_equal(raw.view(np.int16).reshape(-1, 4)[:, :2], mv0)
+        assert np.array_equal(raw.view(np.uint32).reshape(-1, 2)[:, 1], cost0)
+    for s in streams:
+        codec.stream_destroy(s)

@@ -28,14 +28,79 @@ def test_shard_range_partitions():
 
 
 def test_me_stripes_cover_with_halo():
-    rows = 270                                       # 2160 / 8 block rows
-    for world in (1, 2, 4, 8):
-        covered = 0
-        for r in range(world):
-            (b, e), (p0, p1) = me_stripe(rows, r, world, 64, 2160)
-            covered += e - b
-            assert p0 <= max(0, b * 8 - 64) and p1 >= min(2160, e * 8 + 64)
-        assert covered == rows
+    height, rng = 2160, 64                           # 270 block rows
+    for n_stripes in (1, 2, 4, 5, 8, 270, 300):
+        nxt = 0
+        for s in range(n_stripes):
+            (b, e), (r0, r1) = me_stripe(height, rng, s, n_stripes)
+            assert b == nxt and e >= b               # contiguous, in order
+            nxt = e
+            assert (r0, r1) == (b * 8 - rng, e * 8 + rng)      # every row a candidate of the stripe's blocks can touch
+        assert nxt == height // 8
+    with pytest.raises(ValueError):
+        me_stripe(2161, 64, 0, 2)
+
+
+def _me_worker(rank, world, port, w, h, rng, n_stripes, tmpdir):
+    """Sharded motion search over gloo: the root sends every stripe of `cur` and the stripe's halo rows of the
+    padded reference to its owner, owners search ONLY what they received (so a short halo shows up as a wrong
+    winner), records return to the root.  Partition = the C library's plan, compute = the oracle."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from _util import Oracle, me_frames
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = Oracle()
+    cur = refp = None
+    if rank == 0:
+        cur, refp = me_frames(w, h, rng, 0x3E, mv=(4, -3))
+    mv_all = np.zeros(((h // 8) * (w // 8), 2), np.int16)
+    cost_all = np.zeros((h // 8) * (w // 8), np.uint32)
+    bw = w // 8
+    for s in range(n_stripes):
+        owner = [r for r in range(world) if shard_range(n_stripes, r, world)[0] <= s < shard_range(n_stripes, r, world)[1]][0]
+        (b, e), (r0, r1) = me_stripe(h, rng, s, n_stripes)
+        if e == b:
+            continue
+        if rank == 0:
+            c = torch.from_numpy(cur[b * 8:e * 8].copy())
+            r = torch.from_numpy(refp[r0 + rng:r1 + rng].copy())          # padded array row = frame row + rng
+            if owner != 0:
+                dist.send(c, owner)
+                dist.send(r, owner)
+        elif rank == owner:
+            c = torch.empty(((e - b) * 8, w), dtype=torch.uint8)
+            r = torch.empty((r1 - r0, w + 2 * rng), dtype=torch.uint8)
+            dist.recv(c, 0)
+            dist.recv(r, 0)
+        if rank == owner:
+            mv, cost, _ = orc.satd_search(c.numpy(), r.numpy(), rng, rng)
+            out = torch.from_numpy(np.concatenate([mv.astype(np.int32).ravel(), cost.astype(np.int64).astype(np.int32)]))
+            if owner != 0:
+                dist.send(out, 0)
+        if rank == 0:
+            if owner != 0:
+                out = torch.empty((e - b) * bw * 3, dtype=torch.int32)
+                dist.recv(out, owner)
+            o = out.numpy()
+            n = (e - b) * bw
+            mv_all[b * bw:e * bw] = o[: 2 * n].reshape(n, 2)
+            cost_all[b * bw:e * bw] = o[2 * n:].astype(np.uint32)
+    if rank == 0:
+        np.save(os.path.join(tmpdir, "me_mv.npy"), mv_all)
+        np.save(os.path.join(tmpdir, "me_cost.npy"), cost_all)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_stripes", [(2, 2), (2, 5)])
+def test_two_rank_sharded_motion_search_matches_whole_frame(oracle, tmp_path, world, n_stripes):
+    from _util import me_frames
+    w, h, rng = 48, 40, 6                             # 5 block rows: ragged stripes
+    mp.spawn(_me_worker, args=(world, _free_port(), w, h, rng, n_stripes, str(tmp_path)), nprocs=world, join=True)
+    cur, refp = me_frames(w, h, rng, 0x3E, mv=(4, -3))
+    mv, cost, _ = oracle.satd_search(cur, refp, rng, rng)
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "me_mv.npy")), mv)
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "me_cost.npy")), cost)
 
 
 def _free_port():

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/x266hip.h"
 #include "x266_device.hpp"
@@ -44,8 +45,16 @@ struct x266hip_ctx {
     int me_tile_rows = 4;                           // block rows per ME tile (1, 2 or 4)
     int me_row_pairs = 2;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
     int me_variant = 2;                             // 1 = LDS coefficients, 2 = scalar coefficients (me_kernels.hip)
-    uint32_t *d_me_coef = nullptr;                  // variant 2 scratch: 128 B per 8x8 block of the current frame
-    size_t me_coef_bytes = 0;
+    // variant 2 scratch (128 B per 8x8 block of the current frame), ONE PER STREAM: searches enqueued on
+    // different streams never share it, and a buffer that a recorded graph may reference is never freed
+    // before the context is (outgrown buffers are retired, not released)
+    struct MeScratch {
+        hipStream_t stream;
+        uint32_t *p;
+        size_t bytes;
+    };
+    std::vector<MeScratch> me_scratch;
+    std::vector<void *> me_retired;
     int tr_lds_stage = 1;                           // transform set, contiguous batches: stage tiles through LDS
     int tr_tiles_per_wave = 1;                      // transform set: 32x32 tiles per wave
     int tr32_simple = 0;                            // diagnostic: run DCT-II 32 through the transform-set kernel
@@ -85,6 +94,24 @@ int fail(x266hip_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess
         hipError_t e_ = (call);                                              \
         if (e_ != hipSuccess) return fail((ctx), X266HIP_EDEVICE, #call, e_); \
     } while (0)
+
+// Every entry point runs on the context's device and puts the caller's current device back on return
+// (a host that also drives other GPUs, or torch with another current device, is not retargeted).
+struct DeviceScope {
+    int prev = -1;
+    hipError_t status;
+    explicit DeviceScope(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        status = prev == dev ? hipSuccess : hipSetDevice(dev);
+        if (prev == dev) prev = -1;                                    // nothing to restore
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+#define X_DEV(ctx)                                                            \
+    DeviceScope dev_scope_((ctx)->device);                                    \
+    if (dev_scope_.status != hipSuccess) return fail((ctx), X266HIP_EDEVICE, "hipSetDevice", dev_scope_.status)
 
 LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
 {
@@ -136,6 +163,12 @@ extern "C" {
 
 const char *xHipVersion(void) { return "x266hip 0.1 (gfx950)"; }
 
+int xHipDeviceCount(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
 int xHipCodecInit(x266hip_ctx **out, int device_id)
 {
     if (!out) return X266HIP_EINVAL;
@@ -149,7 +182,8 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
     x266hip_ctx *ctx = new (std::nothrow) x266hip_ctx;
     if (!ctx) return X266HIP_ENOMEM;
     ctx->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess) {
+    DeviceScope dev_scope_(device_id);
+    if (dev_scope_.status != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess) {
         delete ctx;
         return X266HIP_EDEVICE;
     }
@@ -200,7 +234,7 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
 void xHipCodecFree(x266hip_ctx *ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceScope dev_scope_(ctx->device);
     for (int i = 0; i < x266hip_ctx::kSlots; ++i) {
         if (ctx->d_stage_in[i]) (void)hipFree(ctx->d_stage_in[i]);
         if (ctx->d_stage_out[i]) (void)hipFree(ctx->d_stage_out[i]);
@@ -211,7 +245,8 @@ void xHipCodecFree(x266hip_ctx *ctx)
             if (ctx->d_tr[type][l]) (void)hipFree(ctx->d_tr[type][l]);
             if (ctx->d_tr_inv[type][l]) (void)hipFree(ctx->d_tr_inv[type][l]);
         }
-    if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
+    for (const x266hip_ctx::MeScratch &m : ctx->me_scratch) (void)hipFree(m.p);
+    for (void *q : ctx->me_retired) (void)hipFree(q);
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
     if (ctx->d_inv) (void)hipFree(ctx->d_inv);
     if (ctx->d_inv_lds) (void)hipFree(ctx->d_inv_lds);
@@ -305,7 +340,7 @@ int xDct32FwdBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out, siz
 {
     if (!ctx) return X266HIP_EINVAL;
     if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xDct32FwdBatchDev: NULL or unaligned buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     return launch_op(ctx, 0, d_in, d_out, n, (hipStream_t)stream);
 }
 
@@ -313,7 +348,7 @@ int xDct32InvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out, siz
 {
     if (!ctx) return X266HIP_EINVAL;
     if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xDct32InvBatchDev: NULL or unaligned buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     return launch_op(ctx, 1, d_in, d_out, n, (hipStream_t)stream);
 }
 
@@ -322,7 +357,7 @@ int xDct32FwdInvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_coef,
     if (!ctx) return X266HIP_EINVAL;
     if (bad_ptrs(d_in, d_recon, n) || (n && d_coef && ((uintptr_t)d_coef & 15u)))
         return fail(ctx, X266HIP_EINVAL, "xDct32FwdInvBatchDev: NULL or unaligned buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     LaunchCfg cfg = cfg_for(ctx, 1);
     cfg.units_per_wave = ctx->dct_fwdinv_blocks_per_wave;
     hipError_t e = launch_dct32_fwdinv(d_in, d_coef, d_recon, n, ctx->d_fwd, ctx->d_inv_lds, cfg, (hipStream_t)stream);
@@ -335,7 +370,7 @@ int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out, s
     if (!ctx) return X266HIP_EINVAL;
     if (n && (!d_diff || !d_out || ((uintptr_t)d_diff & 15u) || ((uintptr_t)d_out & 3u)))
         return fail(ctx, X266HIP_EINVAL, "xSatd8x8BatchDev: NULL or unaligned buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     return launch_op(ctx, 2, d_diff, d_out, n, (hipStream_t)stream);
 }
 
@@ -345,7 +380,7 @@ int xIntra32PredictDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const u
     if (!ctx) return X266HIP_EINVAL;
     if (n && (!d_refs || !d_modes || !d_pred || (((uintptr_t)d_refs | (uintptr_t)d_pred) & 15u) || ((uintptr_t)d_ref_index & 3u)))
         return fail(ctx, X266HIP_EINVAL, "xIntra32PredictDev: NULL or unaligned buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     hipError_t e = launch_intra32_predict(d_refs, d_modes, d_ref_index, d_pred, n, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "intra launch", e);
     return X266HIP_OK;
@@ -357,7 +392,7 @@ int xIntra32CostsDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const uin
     if (!ctx) return X266HIP_EINVAL;
     if (n && (!d_refs || !d_src || !d_costs || (((uintptr_t)d_refs | (uintptr_t)d_src) & 15u) || ((uintptr_t)d_costs & 3u)))
         return fail(ctx, X266HIP_EINVAL, "xIntra32CostsDev: NULL or unaligned buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     hipError_t e = launch_intra32_costs(d_refs, d_src, d_costs, d_best_mode, n, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "intra decision launch", e);
     return X266HIP_OK;
@@ -369,7 +404,7 @@ int xFillResidualDev(x266hip_ctx *ctx, int16_t *d_dst, size_t n_samples, uint64_
     if (!ctx) return X266HIP_EINVAL;
     if (n_samples && (!d_dst || ((uintptr_t)d_dst & 15u)))
         return fail(ctx, X266HIP_EINVAL, "xFillResidualDev: NULL or unaligned buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     hipError_t e = launch_fill_residual(d_dst, n_samples, seed, first_index, cfg_for(ctx, 0), (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fill launch", e);
     return X266HIP_OK;
@@ -384,7 +419,7 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
         return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: size must be 4, 8, 16 (or 32 for DCT-II)");
     if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: NULL or unaligned buffer");
     if (n && ((uintptr_t)d_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: unaligned offset table");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     if (size == 32) {
         if (!d_offsets && !ctx->tr32_simple) return launch_op(ctx, 0, d_in, d_out, n, (hipStream_t)stream);
         LaunchCfg cfg32 = cfg_for(ctx, 0);
@@ -413,7 +448,7 @@ int xTransformTilesDev(x266hip_ctx *ctx, int inverse, const int16_t *d_in, int16
     if (!ctx) return X266HIP_EINVAL;
     if (bad_ptrs(d_in, d_out, n_tiles) || (n_tiles && !d_tile_class)) return fail(ctx, X266HIP_EINVAL, "xTransformTilesDev: NULL or unaligned buffer");
     if (n_tiles && ((uintptr_t)d_tile_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformTilesDev: unaligned offset table");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     const DctOps *ops[16];
     for (int type = 0; type < x266hip_ctx::kTypes; ++type) {
         for (int l = 0; l < 3; ++l) ops[type * 4 + l] = inverse ? ctx->d_tr_inv[type][l] : ctx->d_tr[type][l];
@@ -435,7 +470,7 @@ int xConvInputFmtDev(x266hip_ctx *ctx, x266_ref_block_t *d_tiles, const uint8_t 
     if (!d_tiles || !d_y || !d_u || !d_v) return fail(ctx, X266HIP_EINVAL, "xConvInputFmtDev: NULL buffer");
     if (strdY < width || (strdY & 15) || (((uintptr_t)d_y | (uintptr_t)d_tiles) & 15u) || (((uintptr_t)d_u | (uintptr_t)d_v) & 7u))
         return fail(ctx, X266HIP_EINVAL, "xConvInputFmtDev: stride / alignment");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     hipError_t e = launch_tile_convert(true, d_tiles, const_cast<uint8_t *>(d_y), const_cast<uint8_t *>(d_u), const_cast<uint8_t *>(d_v),
                                        (long long)strdY, (long long)(strdY >> 1), width, height, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "tile pack launch", e);
@@ -451,7 +486,7 @@ int xConvOutput420Dev(x266hip_ctx *ctx, const x266_ref_block_t *d_tiles, uint8_t
     if (strdY < width || strdC < width / 2 || (strdY & 15) || (strdC & 7) || (((uintptr_t)d_y | (uintptr_t)d_tiles) & 15u) ||
         (((uintptr_t)d_u | (uintptr_t)d_v) & 7u))
         return fail(ctx, X266HIP_EINVAL, "xConvOutput420Dev: stride / alignment");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     hipError_t e = launch_tile_convert(false, const_cast<x266_ref_block_t *>(d_tiles), d_y, d_u, d_v, (long long)strdY, (long long)strdC,
                                        width, height, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "tile unpack launch", e);
@@ -467,7 +502,7 @@ int xResidualLumaDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266
     if (width <= 0 || height <= 0 || (width & mask) || (height & mask)) return fail(ctx, X266HIP_EINVAL, "xResidualLumaDev: frame size");
     if (!d_cur || !d_pred || !d_residual || ((((uintptr_t)d_cur | (uintptr_t)d_pred | (uintptr_t)d_residual)) & 15u))
         return fail(ctx, X266HIP_EINVAL, "xResidualLumaDev: NULL or unaligned buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     hipError_t e = launch_residual_luma(block_edge, d_cur, d_pred, d_residual, width, height, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "residual launch", e);
     return X266HIP_OK;
@@ -480,7 +515,7 @@ int xDct32FwdFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const
     if (width <= 0 || height <= 0 || (width & 31) || (height & 31)) return fail(ctx, X266HIP_EINVAL, "xDct32FwdFromTilesDev: width/height must be multiples of 32");
     if (!d_cur || !d_pred || !d_coef || ((((uintptr_t)d_cur | (uintptr_t)d_pred | (uintptr_t)d_coef)) & 15u))
         return fail(ctx, X266HIP_EINVAL, "xDct32FwdFromTilesDev: NULL or unaligned buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     LaunchCfg cfg = cfg_for(ctx, 0);
     cfg.wg_threads = ctx->dct_wg_threads;
     cfg.lds_bytes_per_wave = ctx->dct_lds_per_wave;
@@ -496,7 +531,7 @@ int xSatd8x8FromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const 
     if (width <= 0 || height <= 0 || (width & 15) || (height & 15)) return fail(ctx, X266HIP_EINVAL, "xSatd8x8FromTilesDev: width/height must be multiples of 16");
     if (!d_cur || !d_pred || !d_out || ((((uintptr_t)d_cur | (uintptr_t)d_pred)) & 15u) || ((uintptr_t)d_out & 3u))
         return fail(ctx, X266HIP_EINVAL, "xSatd8x8FromTilesDev: NULL or unaligned buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     hipError_t e = launch_satd8x8_from_tiles(d_cur, d_pred, d_out, width, height, cfg_for(ctx, 2), (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fused satd launch", e);
     return X266HIP_OK;
@@ -508,7 +543,7 @@ int xSadBatchDev(x266hip_ctx *ctx, int edge, const uint8_t *d_a, const uint8_t *
     if (edge != 4 && edge != 8 && edge != 16 && edge != 32 && edge != 64) return fail(ctx, X266HIP_EINVAL, "xSadBatchDev: edge must be 4, 8, 16, 32 or 64");
     if (n && (!d_a || !d_b || !d_out || (((uintptr_t)d_a | (uintptr_t)d_b) & 15u) || ((uintptr_t)d_out & 3u)))
         return fail(ctx, X266HIP_EINVAL, "xSadBatchDev: NULL or unaligned buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     hipError_t e = launch_sad(edge, d_a, d_b, d_out, n, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "sad launch", e);
     return X266HIP_OK;
@@ -523,7 +558,7 @@ int xTransformInvBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
         return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: size must be 4, 8, 16 (or 32 for DCT-II)");
     if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: NULL or unaligned buffer");
     if (n && ((uintptr_t)d_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: unaligned offset table");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     if (size == 32 && !d_offsets) return launch_op(ctx, 1, d_in, d_out, n, (hipStream_t)stream);
     const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
     LaunchCfg cfg = cfg_for(ctx, 1);
@@ -546,20 +581,30 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
     if (range < 1 || range > 64) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: range must be 1..64");
     if (cur_stride < width || ref_stride < width + 2 * range) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: stride too small");
     if (((uintptr_t)d_best & 7u) || ((uintptr_t)d_costs & 3u)) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: unaligned output");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     // tile-major table: whole search tiles (8 x up to 4 blocks), partial edge tiles padded (tile heights 1, 2, 4, 8 all fit)
     const size_t need = (size_t)((width / 8 + 7) / 8) * 8 * (size_t)((height / 8 + 7) / 8) * 8 * 128;
-    if (ctx->me_variant == 2 && need > ctx->me_coef_bytes) {          // grow-only scratch (not stream-ordered: sync first)
-        X_HIP(ctx, hipDeviceSynchronize());
-        if (ctx->d_me_coef) (void)hipFree(ctx->d_me_coef);
-        ctx->d_me_coef = nullptr;
-        ctx->me_coef_bytes = 0;
-        if (hipMalloc((void **)&ctx->d_me_coef, need) != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "ME coefficient scratch");
-        ctx->me_coef_bytes = need;
+    uint32_t *d_me_coef = nullptr;
+    if (ctx->me_variant == 2) {
+        x266hip_ctx::MeScratch *slot = nullptr;
+        for (x266hip_ctx::MeScratch &m : ctx->me_scratch)
+            if (m.stream == (hipStream_t)stream) slot = &m;
+        if (!slot) {
+            ctx->me_scratch.push_back({(hipStream_t)stream, nullptr, 0});
+            slot = &ctx->me_scratch.back();
+        }
+        if (need > slot->bytes) {                                     // must not happen inside a stream capture (hipMalloc)
+            void *fresh = nullptr;
+            if (hipMalloc(&fresh, need) != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "ME coefficient scratch");
+            if (slot->p) ctx->me_retired.push_back(slot->p);          // earlier launches / recorded graphs may still use it
+            slot->p = (uint32_t *)fresh;
+            slot->bytes = need;
+        }
+        d_me_coef = slot->p;
     }
     (void)hipGetLastError();
     hipError_t e = launch_satd_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
-                                      d_best, d_costs, ctx->me_tile_rows, ctx->me_variant, ctx->me_row_pairs, ctx->d_me_coef, (hipStream_t)stream);
+                                      d_best, d_costs, ctx->me_tile_rows, ctx->me_variant, ctx->me_row_pairs, d_me_coef, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "search launch", e);
     return X266HIP_OK;
 }
@@ -575,7 +620,7 @@ int xSad8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride
     if (cur_stride < width || ref_stride < width + 2 * range) return fail(ctx, X266HIP_EINVAL, "xSad8x8SearchDev: stride too small");
     if (((uintptr_t)d_cur & 3u) || (cur_stride & 3)) return fail(ctx, X266HIP_EINVAL, "xSad8x8SearchDev: current frame must be 4-byte aligned with a stride multiple of 4");
     if (((uintptr_t)d_best & 7u) || ((uintptr_t)d_costs & 3u)) return fail(ctx, X266HIP_EINVAL, "xSad8x8SearchDev: unaligned output");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     hipError_t e = launch_sad_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
                                      d_best, d_costs, ctx->me_tile_rows, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "SAD search launch", e);
@@ -613,7 +658,7 @@ static int host_batch(x266hip_ctx *ctx, int op, const void *in, void *out, size_
     if (!ctx) return X266HIP_EINVAL;
     if (n == 0) return X266HIP_OK;
     if (!in || !out) return fail(ctx, X266HIP_EINVAL, "NULL host buffer");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     const size_t chunk_bytes = (size_t)32 << 20;                       // 32 MiB of input per chunk
     size_t chunk = chunk_bytes / in_unit;
     if (chunk > n) chunk = n;
@@ -621,18 +666,28 @@ static int host_batch(x266hip_ctx *ctx, int op, const void *in, void *out, size_
     if (rc) return rc;
     size_t done = 0;
     int slot = 0;
-    while (done < n) {
+    hipError_t e = hipSuccess;
+    const char *what = "";
+#define STAGE(call) do { if (e == hipSuccess && rc == X266HIP_OK) { e = (call); what = #call; } } while (0)
+    while (done < n && e == hipSuccess && rc == X266HIP_OK) {
         const size_t cnt = (n - done < chunk) ? n - done : chunk;
         hipStream_t s = ctx->stage_stream[slot];
-        X_HIP(ctx, hipStreamSynchronize(s));                           // slot's previous chunk fully drained
-        X_HIP(ctx, hipMemcpyAsync(ctx->d_stage_in[slot], (const char *)in + done * in_unit, cnt * in_unit, hipMemcpyHostToDevice, s));
-        rc = launch_op(ctx, op, ctx->d_stage_in[slot], ctx->d_stage_out[slot], cnt, s);
-        if (rc) return rc;
-        X_HIP(ctx, hipMemcpyAsync((char *)out + done * out_unit, ctx->d_stage_out[slot], cnt * out_unit, hipMemcpyDeviceToHost, s));
+        STAGE(hipStreamSynchronize(s));                               // slot's previous chunk fully drained
+        STAGE(hipMemcpyAsync(ctx->d_stage_in[slot], (const char *)in + done * in_unit, cnt * in_unit, hipMemcpyHostToDevice, s));
+        if (e == hipSuccess) rc = launch_op(ctx, op, ctx->d_stage_in[slot], ctx->d_stage_out[slot], cnt, s);
+        STAGE(hipMemcpyAsync((char *)out + done * out_unit, ctx->d_stage_out[slot], cnt * out_unit, hipMemcpyDeviceToHost, s));
         done += cnt;
         slot ^= 1;
     }
-    for (int i = 0; i < x266hip_ctx::kSlots; ++i) X_HIP(ctx, hipStreamSynchronize(ctx->stage_stream[i]));
+#undef STAGE
+    // Drain BOTH staging streams on every path: after a failure an already enqueued D2H copy must not still be
+    // writing the caller's `out` once this function has returned (the caller may free it).
+    for (int i = 0; i < x266hip_ctx::kSlots; ++i) {
+        const hipError_t es = hipStreamSynchronize(ctx->stage_stream[i]);
+        if (e == hipSuccess && es != hipSuccess) { e = es; what = "hipStreamSynchronize(stage)"; }
+    }
+    if (rc != X266HIP_OK) return rc;
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, what, e);
     return X266HIP_OK;
 }
 
@@ -644,7 +699,7 @@ int xSatd8x8Batch(x266hip_ctx *ctx, const int16_t *diff, uint32_t *out, size_t n
 int xHipMalloc(x266hip_ctx *ctx, void **d_ptr, size_t bytes)
 {
     if (!ctx || !d_ptr) return X266HIP_EINVAL;
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     *d_ptr = nullptr;
     if (bytes == 0) return X266HIP_OK;
     hipError_t e = hipMalloc(d_ptr, bytes);
@@ -656,7 +711,7 @@ int xHipFree(x266hip_ctx *ctx, void *d_ptr)
 {
     if (!ctx) return X266HIP_EINVAL;
     if (!d_ptr) return X266HIP_OK;
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     X_HIP(ctx, hipFree(d_ptr));
     return X266HIP_OK;
 }
@@ -664,7 +719,7 @@ int xHipFree(x266hip_ctx *ctx, void *d_ptr)
 int xHipMemcpyH2D(x266hip_ctx *ctx, void *d_dst, const void *src, size_t bytes)
 {
     if (!ctx || (bytes && (!d_dst || !src))) return X266HIP_EINVAL;
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     X_HIP(ctx, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
     return X266HIP_OK;
 }
@@ -672,7 +727,7 @@ int xHipMemcpyH2D(x266hip_ctx *ctx, void *d_dst, const void *src, size_t bytes)
 int xHipMemcpyD2H(x266hip_ctx *ctx, void *dst, const void *d_src, size_t bytes)
 {
     if (!ctx || (bytes && (!dst || !d_src))) return X266HIP_EINVAL;
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     X_HIP(ctx, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
     return X266HIP_OK;
 }
@@ -680,7 +735,7 @@ int xHipMemcpyD2H(x266hip_ctx *ctx, void *dst, const void *d_src, size_t bytes)
 int xHipStreamSync(x266hip_ctx *ctx, void *stream)
 {
     if (!ctx) return X266HIP_EINVAL;
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     X_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     return X266HIP_OK;
 }
@@ -688,7 +743,7 @@ int xHipStreamSync(x266hip_ctx *ctx, void *stream)
 int xHipStreamCreate(x266hip_ctx *ctx, void **stream)
 {
     if (!ctx || !stream) return X266HIP_EINVAL;
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     hipStream_t s = nullptr;
     X_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *stream = (void *)s;
@@ -699,6 +754,7 @@ int xHipStreamDestroy(x266hip_ctx *ctx, void *stream)
 {
     if (!ctx) return X266HIP_EINVAL;
     if (!stream) return X266HIP_OK;
+    X_DEV(ctx);
     X_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
     return X266HIP_OK;
 }
@@ -712,7 +768,7 @@ int xHipGraphBegin(x266hip_ctx *ctx, void *stream)
 {
     if (!ctx) return X266HIP_EINVAL;
     if (!stream) return fail(ctx, X266HIP_EINVAL, "xHipGraphBegin: capture needs a stream of its own, not the NULL stream");
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     X_HIP(ctx, hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
     return X266HIP_OK;
 }
@@ -721,6 +777,7 @@ int xHipGraphEnd(x266hip_ctx *ctx, void *stream, x266hip_graph **graph)
 {
     if (!ctx || !graph || !stream) return X266HIP_EINVAL;
     *graph = nullptr;
+    X_DEV(ctx);
     hipGraph_t g = nullptr;
     X_HIP(ctx, hipStreamEndCapture((hipStream_t)stream, &g));
     if (!g) return fail(ctx, X266HIP_EDEVICE, "xHipGraphEnd: the capture was invalidated");
@@ -745,25 +802,63 @@ int xHipGraphEnd(x266hip_ctx *ctx, void *stream, x266hip_graph **graph)
 int xHipGraphLaunch(x266hip_ctx *ctx, x266hip_graph *graph, void *stream)
 {
     if (!ctx || !graph || !graph->exec) return X266HIP_EINVAL;
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     X_HIP(ctx, hipGraphLaunch(graph->exec, (hipStream_t)stream));
     return X266HIP_OK;
 }
 
 void xHipGraphFree(x266hip_ctx *ctx, x266hip_graph *graph)
 {
-    (void)ctx;
     if (!graph) return;
+    DeviceScope dev_scope_(ctx ? ctx->device : 0);
     if (graph->exec) (void)hipGraphExecDestroy(graph->exec);
     if (graph->graph) (void)hipGraphDestroy(graph->graph);
     delete graph;
+}
+
+int xHipEventCreate(x266hip_ctx *ctx, void **event)
+{
+    if (!ctx || !event) return X266HIP_EINVAL;
+    X_DEV(ctx);
+    hipEvent_t e = nullptr;
+    X_HIP(ctx, hipEventCreate(&e));
+    *event = (void *)e;
+    return X266HIP_OK;
+}
+
+int xHipEventDestroy(x266hip_ctx *ctx, void *event)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (!event) return X266HIP_OK;
+    X_DEV(ctx);
+    X_HIP(ctx, hipEventDestroy((hipEvent_t)event));
+    return X266HIP_OK;
+}
+
+int xHipEventRecord(x266hip_ctx *ctx, void *event, void *stream)
+{
+    if (!ctx || !event) return X266HIP_EINVAL;
+    X_DEV(ctx);
+    X_HIP(ctx, hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return X266HIP_OK;
+}
+
+int xHipEventElapsedMs(x266hip_ctx *ctx, void *start, void *stop, double *ms)
+{
+    if (!ctx || !start || !stop || !ms) return X266HIP_EINVAL;
+    X_DEV(ctx);
+    X_HIP(ctx, hipEventSynchronize((hipEvent_t)stop));
+    float f = 0.f;
+    X_HIP(ctx, hipEventElapsedTime(&f, (hipEvent_t)start, (hipEvent_t)stop));
+    *ms = (double)f;
+    return X266HIP_OK;
 }
 
 int xHipTimeKernel(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n, int reps, void *stream,
                    double *ms_per_launch)
 {
     if (!ctx || !ms_per_launch || reps < 1) return X266HIP_EINVAL;
-    X_HIP(ctx, hipSetDevice(ctx->device));
+    X_DEV(ctx);
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0, e1;
     X_HIP(ctx, hipEventCreate(&e0));

@@ -65,7 +65,15 @@ private:
     char *prev_ = nullptr;
 };
 
-void release_ctx() { xHipCodecFree(g_ctx); g_ctx = nullptr; }
+void *g_sad_buf = nullptr;                  // x266_sad's device scratch, released with the context
+
+void release_ctx()
+{
+    if (g_sad_buf) (void)xHipFree(g_ctx, g_sad_buf);
+    g_sad_buf = nullptr;
+    xHipCodecFree(g_ctx);
+    g_ctx = nullptr;
+}
 
 x266hip_ctx *bdpi_ctx()
 {
@@ -157,14 +165,15 @@ unsigned int satd8x8_getSatd(void) { return s_satd_val; }
 int x266_sad(const unsigned char *input_data1, const unsigned char *input_data2, size_t n)
 {
     if (!input_data1 || !input_data2 || !(n == 4 || n == 8 || n == 16 || n == 32 || n == 64)) return -1;
-    static void *d_buf = nullptr;                                  // two 64x64 blocks + the result, kept for the process
+    // Like the BDPI shims: stateful, single-threaded by contract.  The guard comes first -- opening the
+    // context initialises the HIP runtime, which draws from rand().
+    RandStateGuard keep_rand_sequence;
     x266hip_ctx *ctx = bdpi_ctx();
-    RandStateGuard keep_rand_sequence;                             // as for the BDPI shims: the runtime may draw from rand()
-    if (!d_buf) {
-        const int rc = xHipMalloc(ctx, &d_buf, 2 * 4096 + 16);
+    if (!g_sad_buf) {                                              // two 64x64 blocks + the result; freed by release_ctx at exit
+        const int rc = xHipMalloc(ctx, &g_sad_buf, 2 * 4096 + 16);
         if (rc != X266HIP_OK) die("xHipMalloc", rc);
     }
-    unsigned char *a = static_cast<unsigned char *>(d_buf), *b = a + 4096;
+    unsigned char *a = static_cast<unsigned char *>(g_sad_buf), *b = a + 4096;
     uint32_t *d_out = reinterpret_cast<uint32_t *>(a + 8192);
     uint32_t out = 0;
     int rc = xHipMemcpyH2D(ctx, a, input_data1, n * n);

@@ -1,8 +1,11 @@
-"""Host logic for the multi-GPU path: independent blocks shard contiguously
-across ranks -- no data-path collective.  One process
-per GPU; the only cross-rank traffic is the barrier / max-time reduction and an
-optional 8-byte checksum reduction used to validate a sharded run."""
+"""Partitioning of the multi-GPU path: independent blocks shard contiguously
+across ranks, motion search shards into horizontal stripes with a read-only halo -- no data-path
+collective, no exchange step.  The arithmetic lives in the C library (xShardRange, xMeStripePlan in
+x266_amd/csrc/x266hip_node.cpp: host-only, no device needed) so that the C node layer, bench.py and the
+CPU (gloo) tests of the N > 1 logic all partition with the same code; this module is the binding."""
 from typing import Tuple
+
+from .node import me_stripe_plan, shard_range as _shard_range
 
 
 def shard_range(n_units: int, rank: int, world: int) -> Tuple[int, int]:
@@ -11,16 +14,13 @@ def shard_range(n_units: int, rank: int, world: int) -> Tuple[int, int]:
         raise ValueError("bad rank/world: %d/%d" % (rank, world))
     if n_units < 0:
         raise ValueError("negative unit count")
-    base, extra = divmod(n_units, world)
-    begin = rank * base + min(rank, extra)
-    return begin, begin + base + (1 if rank < extra else 0)
+    return _shard_range(n_units, rank, world)
 
 
-def me_stripe(n_block_rows: int, rank: int, world: int, halo_rows: int, total_rows: int):
-    """Motion-search partition: horizontal stripes of block rows plus a read-only
-    halo of reference rows above and below (sent with the scatter; no exchange)."""
-    b, e = shard_range(n_block_rows, rank, world)
-    return (b, e), (max(0, b * 8 - halo_rows), min(total_rows, e * 8 + halo_rows))
+def me_stripe(height: int, rng: int, stripe: int, n_stripes: int):
+    """Motion-search partition: stripe's block rows [b, e) and the rows [r0, r1) of the padded reference it
+    reads (frame coordinates: r0 may be negative, r1 may exceed height, by up to rng)."""
+    return me_stripe_plan(height, rng, stripe, n_stripes)
 
 
 def combine_checksums(values):
