@@ -11,17 +11,28 @@ Workload = BASELINE.json configs[1]: 1,048,576 synthetic 9-bit residual blocks o
 uniform bytes -- the reference's stimulus distribution, src_tb/dct32.c:191-193 --
 from SplitMix64 seed 0x266).  A "step" is one forward 2-D DCT32 pass over the
 batch (xDct32FwdBatchDev through the C ABI).  `value` is whole-job forward
-blocks/s over all ranks; the inverse transform and the 8x8 SATD residual batch
-(2^24 blocks, seed 0x267) are measured the same way and reported under "also".
+blocks/s over all ranks; every other leg (inverse, fused forward+inverse, the 8x8
+SATD residual batch of 2^24 blocks, motion search, the transform set, the
+8K frame stream of configs[4], ...) is measured the same way under "also".
+
+How every leg is timed (`timed_leg`): its own clock pre-warm (the chip needs ~50 ms
+of load to reach steady clocks, profiles/r01_clock_warmup.txt), W untimed launches,
+then K launches between barrier + synchronize on both sides; a HIP event is
+recorded ON THE LAUNCHING STREAM before every one of those K launches and after the
+last, so `kernel_ms_mean` / `kernel_ms_median` come from the very launches whose
+wall-clock is `ms_per_step` (the former can never exceed the latter).
 
 Independent blocks shard across ranks with no data-path collective (weak
 scaling: every rank owns its own 1 Mi-block slice of the one seeded stream);
-torch.distributed (RCCL) carries only the barrier, the max-over-ranks time and a
-checksum reduction.
+torch.distributed (RCCL) carries the barrier, the max-over-ranks time, a
+checksum reduction and the broadcast of the node's RCCL id.  The end-to-end
+scatter -> transform -> gather figures (8K frame stream, batch scatter-gather,
+sharded motion search) go through the node layer of the C ABI
+(x266_amd/csrc/x266hip_node.cpp: RCCL send/recv groups) at every N, N = 1 included.
 
 "roofline": algorithmic bytes per launch (4096 B per DCT block, 132 B per SATD
-block) / mean kernel duration measured with HIP events on
-the launching stream, against the 8 TB/s HBM3E peak.
+block) / mean launch duration from the events above,
+against the 8 TB/s HBM3E peak.
 "cpu_baseline": the reference C path on this node's host cores (oracle/_ref =
 the real src_tb/dct32.c when its prebuilt .so is present, else the oracle's
 restatement), bounded sample, rank 0 at N = 1 only.  The oracle is used here and
@@ -31,6 +42,7 @@ import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
 import threading
 import time
@@ -41,28 +53,115 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_BYTES_PER_S = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+XGMI_LINK_BYTES_PER_S = 153e9          # per direction, per peer link
 DCT_BLOCKS_PER_GPU = 1 << 20           # BASELINE configs[1]
 SATD_BLOCKS_PER_GPU = 1 << 24          # 2 GiB of 8x8 residual blocks
 DCT_BYTES_PER_BLOCK = 4096             # 2048 read + 2048 written   
 SATD_BYTES_PER_BLOCK = 132             # 128 read + 4 written
 DCT_SEED, SATD_SEED = 0x266, 0x267
+PREWARM_SECONDS = 0.08
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=100,
-                    help="untimed launches first; the chip needs ~50 ms of load to reach steady clocks (profiles/r01_clock_warmup.txt)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dct-blocks", type=int, default=DCT_BLOCKS_PER_GPU)
     ap.add_argument("--satd-blocks", type=int, default=SATD_BLOCKS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the inverse / SATD legs")
-    ap.add_argument("--stream8k", type=int, default=0, metavar="FRAMES",
-                    help="also time BASELINE configs[4]: 7680x4320 frames, DCT32+SATD batches scattered from rank 0 and gathered back")
-    ap.add_argument("--no-me", action="store_true", help="skip the motion-search leg")
-    ap.add_argument("--no-transform-set", action="store_true", help="skip the transform-set leg")
+    ap.add_argument("--no-also", action="store_true", help="headline leg only")
+    ap.add_argument("--stream8k", type=int, default=200, metavar="FRAMES",
+                    help="frames of the BASELINE configs[4] leg (7680x4320 stream through the node layer); 0 skips it")
+    ap.add_argument("--no-me", action="store_true", help="skip the motion-search legs")
+    ap.add_argument("--no-transform-set", action="store_true", help="skip the transform-set / front-end / intra legs")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (checker leg: the only place bench.py touches oracle/)
+# ------------------------------------------------------------------------------------------------
+def host_cpu_facts():
+    model, flags = "unknown", []
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            if line.startswith("flags") and not flags:
+                have = set(line.split(":", 1)[1].split())
+                flags = [f for f in ("avx2", "avx512f", "avx512bw", "avx512_vnni", "amx_int8") if f in have]
+    except OSError:
+        pass
+    return model, flags
+
+
+def usable_cpus():
+    """(hardware threads this process may run on, CPUs the container's cgroup quota pays for).  A box can show
+    256 hardware threads and grant 16 CPUs of quota: threads beyond the quota only add throttling."""
+    hw = len(os.sched_getaffinity(0))
+    quota = float(hw)
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    return hw, quota
+
+
+def best_thread_count(n_units, work, make_local):
+    """Thread count for the all-cores figure: the cgroup quota and a few multiples of it up to the hardware
+    thread count, each timed on a quarter of the sample; the fastest wins."""
+    hw, quota = usable_cpus()
+    q = max(1, min(hw, int(round(quota))))
+    cands = sorted({c for c in (q, 2 * q, 4 * q, hw) if 1 <= c <= hw})
+    trial = {}
+    for c in cands:
+        dt, _, _ = run_pinned(max(n_units // 4, c), c, work, make_local)
+        trial[c] = max(n_units // 4, c) / dt
+    return max(trial, key=trial.get), hw, quota, trial
+
+
+def run_pinned(n_units, cores, work, make_local):
+    """One pinned thread per core, one contiguous shard each.  Every thread first builds its OWN copy of
+    its input shard and pre-touches its output shard (first touch => NUMA-local pages, no page faults in
+    the timed region), then all start together.  Returns (seconds from the common start to the last
+    finisher, list of per-thread outputs)."""
+    bounds = np.linspace(0, n_units, cores + 1).astype(np.int64)
+    cpus = sorted(os.sched_getaffinity(0))
+    ready, go = threading.Barrier(cores + 1), threading.Barrier(cores + 1)
+    ends = [0.0] * cores
+    outs = [None] * cores
+
+    def body(i):
+        try:
+            os.sched_setaffinity(0, {cpus[i % len(cpus)]})                # this thread only
+        except OSError:
+            pass
+        b, e = int(bounds[i]), int(bounds[i + 1])
+        loc_in, loc_out = make_local(b, e)
+        outs[i] = loc_out
+        ready.wait()
+        go.wait()
+        if e > b:
+            work(loc_in, loc_out, e - b)
+        ends[i] = time.perf_counter()
+
+    ths = [threading.Thread(target=body, args=(i,)) for i in range(cores)]
+    for th in ths:
+        th.start()
+    ready.wait()
+    t0 = time.perf_counter()
+    go.wait()
+    for th in ths:
+        th.join()
+    return max(ends) - t0, outs, bounds
 
 
 def cpu_baseline_dct(x_host, gpu_out_host):
@@ -72,41 +171,33 @@ def cpu_baseline_dct(x_host, gpu_out_host):
     from _util import Oracle, Reference, ref_path
 
     orc = Oracle()
-    cores = orc.hw_threads()
     n = x_host.shape[0]
-    # single thread, small sample
-    n1 = min(n, 16384)
-    t = time.perf_counter()
-    orc.dct32_fwd(x_host[:n1], threads=1)
-    single = n1 / (time.perf_counter() - t)
-
     have_ref = os.path.exists(ref_path())
-    out = np.empty_like(x_host)
-    if have_ref:
-        ref = Reference()
-        bounds = np.linspace(0, n, cores + 1).astype(np.int64)
+    ref = Reference() if have_ref else None
 
-        def work(i):
-            b, e = int(bounds[i]), int(bounds[i + 1])
-            if e > b:
-                ref.lib.ref_dct32_fwd(ctypes.c_void_p(x_host[b:e].ctypes.data), ctypes.c_void_p(out[b:e].ctypes.data),
-                                      ctypes.c_ulong(e - b))
+    def call(fn_ref, fn_orc):
+        def work(loc_in, loc_out, cnt):
+            if have_ref:
+                fn_ref(ctypes.c_void_p(loc_in.ctypes.data), ctypes.c_void_p(loc_out.ctypes.data), ctypes.c_ulong(cnt))
+            else:
+                fn_orc(ctypes.c_void_p(loc_in.ctypes.data), ctypes.c_void_p(loc_out.ctypes.data), ctypes.c_size_t(cnt), 1)
+        return work
 
-        ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-        t = time.perf_counter()
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-        dt = time.perf_counter() - t
-        kind = "reference"
-    else:
-        t = time.perf_counter()
-        out = orc.dct32_fwd(x_host, threads=cores)
-        dt = time.perf_counter() - t
-        kind = "port"
-    exact = bool(np.array_equal(out, gpu_out_host))
-    # secondary figure: the same restatement built -O3 -march=native ON THIS HOST
+    work = call(ref.lib.ref_dct32_fwd if have_ref else None, orc.lib.orc_dct32_fwd_mt)
+
+    def make_local(b, e):
+        loc_in = x_host[b:e].copy()
+        loc_out = np.zeros_like(loc_in)
+        return loc_in, loc_out
+
+    # single pinned thread, bounded sample, same code path
+    n1 = min(n, 32768)
+    dt1, _, _ = run_pinned(n1, 1, work, make_local)
+    single = n1 / dt1
+    cores, hw, quota, trial = best_thread_count(n, work, make_local)
+    dt, outs, bounds = run_pinned(n, cores, work, make_local)
+    exact = all(np.array_equal(outs[i], gpu_out_host[int(bounds[i]):int(bounds[i + 1])]) for i in range(cores))
+    # secondary figure: the restatement built -O3 -march=native ON THIS HOST
     native = None
     try:
         import glob
@@ -117,29 +208,41 @@ def cpu_baseline_dct(x_host, gpu_out_host):
         subprocess.check_call(["gcc", "-O3", "-march=native", "-std=gnu11", "-fPIC", "-shared", "-o", so] + srcs + ["-lpthread"],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
         nat = ctypes.CDLL(so)
-        tmp = np.empty_like(x_host)
-        t = time.perf_counter()
-        nat.orc_dct32_fwd_mt(ctypes.c_void_p(x_host.ctypes.data), ctypes.c_void_p(tmp.ctypes.data), ctypes.c_size_t(n), cores)
-        dt_n = time.perf_counter() - t
-        if np.array_equal(tmp, out):
+
+        def work_n(loc_in, loc_out, cnt):
+            nat.orc_dct32_fwd_mt(ctypes.c_void_p(loc_in.ctypes.data), ctypes.c_void_p(loc_out.ctypes.data), ctypes.c_size_t(cnt), 1)
+        dt_n, outs_n, _ = run_pinned(n, cores, work_n, make_local)
+        if all(np.array_equal(a, b) for a, b in zip(outs_n, outs)):
             native = n / dt_n
         os.unlink(so)
     except Exception:
         native = None
+    model, flags = host_cpu_facts()
     return {
-        "value": n / dt, "unit": "blocks/s", "cores": cores, "kind": kind,
-        "sample": "%d of the %d blocks of the GPU batch (same inputs), one contiguous shard per thread, -O2" % (n, n),
+        "value": n / dt, "unit": "blocks/s", "cores": cores, "kind": "reference" if have_ref else "port",
+        "sample": "all %d blocks of the GPU batch (same inputs): %d pinned threads, one contiguous shard each, "
+                  "thread-local input copy and pre-touched output (no page faults, NUMA-local), -O2" % (n, cores),
         "single_thread_blocks_per_s": single,
+        "parallel_efficiency": (n / dt) / (min(cores, quota) * single),
+        "host_hw_threads": hw, "container_cpu_quota": quota,
+        "thread_count_trials_blocks_per_s": {str(k): v for k, v in trial.items()},
         "port_O3_march_native_all_cores_blocks_per_s": native,
+        "host_cpu": model, "host_cpu_flags": flags,
         "gpu_output_bit_exact_vs_cpu": exact,
     }, exact
 
 
 def main():
     args = parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # stdout carries exactly ONE line, the JSON: libraries that chat on stdout (RCCL prints a version banner
+    # when a communicator is created) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import x266_amd
-    from x266_amd._lib import OP_DCT32_FWD, OP_DCT32_INV, OP_SATD8X8
+    from x266_amd.node import Node, OP_DCT32_FWD
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -151,7 +254,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libx266hip has no CPU path")
     # Test hook (never set by the driver): X266_BENCH_SHARE_GPU=1 lets several ranks share the visible
     # GPUs with the control-plane collectives on gloo, so that the N > 1 code path -- shard offsets,
-    # max-over-ranks timing, checksum reduction -- can be exercised on a one-GPU box.
+    # max-over-ranks timing, checksum reduction -- can be exercised on a one-GPU box (the node-layer legs
+    # are skipped there: RCCL refuses two ranks on one device).
     share = os.environ.get("X266_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = local_rank % torch.cuda.device_count()
@@ -171,6 +275,7 @@ def main():
     info_cu = codec.device_info()["cu_count"]
     stream = torch.cuda.current_stream().cuda_stream           # the stream every launch and event uses
     n_dct, n_satd = args.dct_blocks, args.satd_blocks
+    K, W = args.steps, args.warmup
 
     def barrier():
         torch.cuda.synchronize()
@@ -185,64 +290,86 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    events = [codec.event_create() for _ in range(max(K, 8) + 1)]
+
+    def timed_leg(fn, steps=None, warmup=None):
+        """fn() enqueues one step on `stream`.  Returns dict(wall_s, ms_per_step, kernel_ms_mean, kernel_ms_median)."""
+        steps = K if steps is None else max(1, min(steps, len(events) - 1))
+        warmup = W if warmup is None else warmup
+        # clock pre-warm: a few launches to size one step, then ~PREWARM_SECONDS of load
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        per = max((time.perf_counter() - t0) / 2, 1e-6)
+        pre = min(2000, int(PREWARM_SECONDS / per))
+        for _ in range(pre + warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            codec.event_record(events[i], stream)
+            fn()
+        codec.event_record(events[steps], stream)
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        d = [codec.event_elapsed_ms(events[i], events[i + 1]) for i in range(steps)]
+        return {"wall_s": wall, "steps": steps, "ms_per_step": wall / steps * 1e3, "kernel_ms_mean": sum(d) / steps,
+                "kernel_ms_median": statistics.median(d), "clock_prewarm_launches": pre}
+
+    def rate(leg, units_per_step):
+        return world * units_per_step * leg["steps"] / leg["wall_s"]
+
+    def hbm(leg, bytes_per_step):
+        """fraction of the HBM peak from the mean launch duration of the timed launches"""
+        return bytes_per_step / (leg["kernel_ms_mean"] * 1e-3) / HBM_PEAK_BYTES_PER_S
+
+    def roofline(leg, bytes_per_unit, n_units, traffic=None, traffic_source=None):
+        achieved = bytes_per_unit * n_units / (leg["kernel_ms_mean"] * 1e-3)
+        return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel_ms_per_launch": leg["kernel_ms_mean"], "kernel_ms_median": leg["kernel_ms_median"],
+                "frac_at_median": bytes_per_unit * n_units / (leg["kernel_ms_median"] * 1e-3) / HBM_PEAK_BYTES_PER_S,
+                "algorithmic_bytes_per_launch": bytes_per_unit * n_units}
+
+    def brief(leg):
+        return {k: leg[k] for k in ("ms_per_step", "kernel_ms_mean", "kernel_ms_median")}
+
     # ---- inputs resident in HBM: this rank's slice of the one seeded stream -----------------
     x = torch.empty(n_dct * 1024, dtype=torch.int16, device="cuda")
     z = torch.empty_like(x)
     codec.fill_residual_dev(x.data_ptr(), n_dct * 1024, DCT_SEED, rank * n_dct * 1024, stream)
     torch.cuda.synchronize()
 
-    def run_leg(op, fn, d_in, d_out, n_units, steps, warmup):
-        for _ in range(warmup):
-            fn(d_in, d_out, n_units, stream)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn(d_in, d_out, n_units, stream)
-        barrier()
-        wall = max_over_ranks(time.perf_counter() - t0)
-        # per-launch kernel duration: HIP events recorded on the launching stream itself
-        kernel_ms = codec.time_kernel(op, d_in, d_out, n_units, steps, stream)
-        return wall, kernel_ms
+    head = timed_leg(lambda: codec.dct32_fwd_dev(x.data_ptr(), z.data_ptr(), n_dct, stream))
+    value = rate(head, n_dct)
 
-    # Clock pre-warm, separate from the W warm-up steps of the contract: the chip needs ~50 ms of load to reach
-    # steady clocks (profiles/r01_clock_warmup.txt).  With a small --warmup the timed steps would otherwise sit
-    # on the ramp; with the default W = 100 this adds nothing.
-    prewarm = max(0, 100 - args.warmup)
-    for _ in range(prewarm):
-        codec.dct32_fwd_dev(x.data_ptr(), z.data_ptr(), n_dct, stream)
-    wall, k_ms = run_leg(OP_DCT32_FWD, codec.dct32_fwd_dev, x.data_ptr(), z.data_ptr(), n_dct, args.steps, args.warmup)
-    value = world * n_dct * args.steps / wall
-
-    def roofline(bytes_per_unit, n_units, kernel_ms, traffic=None):
-        achieved = bytes_per_unit * n_units / (kernel_ms * 1e-3)
-        return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": traffic,
-                "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_unit * n_units}
-
-    # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected
-    # with this same command on this workload; FETCH_SIZE x2 gfx950 correction applied there).
-    # They only describe the default workload size.
-    pmc = {}
+    # HBM bytes per launch: NOT measured in this run -- replayed from the rocprofv3 PMC passes committed under
+    # profiles/ (same command, same workload size; FETCH_SIZE x2 gfx950 correction applied there), and labelled so.
+    pmc, pmc_src = {}, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and n_dct == DCT_BLOCKS_PER_GPU and n_satd == SATD_BLOCKS_PER_GPU:
         try:
             pmc = json.load(open(tpath))
+            pmc_src = "replayed from %s (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command); not measured in this run" % pmc.get("_source", "profiles/traffic.json")
         except Exception:
             pmc = {}
-    traffic = pmc.get("dct32_fwd_bytes_per_launch")
 
     result = {
         "metric": "dct32_fwd_blocks_per_s", "value": value, "unit": "blocks/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "i32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: batched 32x32 forward DCT, %d random 9-bit residual blocks per GPU "
-                               "resident in HBM (inverse + 8x8 SATD legs under 'also')" % n_dct,
+                               "resident in HBM (inverse, fused fwd+inv, 8x8 SATD and the other configs under 'also')" % n_dct,
                    "blocks_per_gpu": n_dct, "block_bytes_in_plus_out": DCT_BYTES_PER_BLOCK,
                    "arithmetic": "int16 data as two int8 planes x int8 coefficients on v_mfma_i32_32x32x32_i8, int32 accumulate",
                    "sharding": "contiguous shard per rank, no data-path collective",
-                   "clock_prewarm_launches": prewarm},
-        "roofline": roofline(DCT_BYTES_PER_BLOCK, n_dct, k_ms, traffic),
+                   "clock_prewarm_launches": head["clock_prewarm_launches"],
+                   "timing": "every leg: own clock pre-warm, W warm-up launches, K launches barrier-to-barrier; kernel_ms_* from HIP "
+                             "events recorded on the launching stream around those same K launches"},
+        "roofline": roofline(head, DCT_BYTES_PER_BLOCK, n_dct, pmc.get("dct32_fwd_bytes_per_launch"), pmc_src),
     }
 
     # ---- checksum of the forward output across ranks (validates the sharded run) ----------------
@@ -253,56 +380,49 @@ def main():
         csum = int(t.item())
     result["output_checksum_sum_i16"] = csum
 
-    # ---- also: inverse DCT32 and SATD residual batch ---------------------------------------------
     if not args.no_also:
         also = {}
+        # ---- inverse DCT32 ----------------------------------------------------------------------------
         r = torch.empty_like(x)
-        wall_i, k_ms_i = run_leg(OP_DCT32_INV, codec.dct32_inv_dev, z.data_ptr(), r.data_ptr(), n_dct, args.steps, args.warmup)
-        also["dct32_inv"] = {"value": world * n_dct * args.steps / wall_i, "unit": "blocks/s",
-                             "ms_per_step": wall_i / args.steps * 1e3,
-                             "roofline": roofline(DCT_BYTES_PER_BLOCK, n_dct, k_ms_i, pmc.get("dct32_inv_bytes_per_launch")),
-                             "parity": "unpinned (no inverse in the reference); bit-exact vs this repo's oracle"}
+        leg = timed_leg(lambda: codec.dct32_inv_dev(z.data_ptr(), r.data_ptr(), n_dct, stream))
+        also["dct32_inv"] = dict(value=rate(leg, n_dct), unit="blocks/s", **brief(leg),
+                                 roofline=roofline(leg, DCT_BYTES_PER_BLOCK, n_dct, pmc.get("dct32_inv_bytes_per_launch"), pmc_src),
+                                 parity="unpinned (no inverse in the reference); bit-exact vs this repo's oracle")
         err = (r[: 4096 * 1024].to(torch.int32) - x[: 4096 * 1024].to(torch.int32)).abs().max().item()
         also["dct32_inv"]["roundtrip_max_abs_err"] = int(err)
-        # fused forward + inverse: coefficients and reconstruction from one pass (6144 B per block)
+        # ---- fused forward + inverse: coefficients and reconstruction from one pass (6144 B per block)
         z2 = torch.empty_like(x)
-
-        def fused(d_in, d_out, n_units, st):
-            codec.dct32_fwd_inv_dev(d_in, z2.data_ptr(), d_out, n_units, st)
-        for _ in range(args.warmup):
-            fused(x.data_ptr(), r.data_ptr(), n_dct, stream)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fused(x.data_ptr(), r.data_ptr(), n_dct, stream)
-        barrier()
-        wall_f = max_over_ranks(time.perf_counter() - t0)
-        also["dct32_fwd_inv_fused"] = {"value": world * n_dct * args.steps / wall_f, "unit": "blocks/s",
-                                       "ms_per_step": wall_f / args.steps * 1e3,
-                                       "hbm_frac": 6144.0 * n_dct * args.steps / wall_f / HBM_PEAK_BYTES_PER_S,
-                                       "same_bytes_as_two_kernels": bool(torch.equal(z2, z)),
-                                       "note": "wall-clock (launch gaps included); 2 KiB in, 2 + 2 KiB out per block"}
+        leg = timed_leg(lambda: codec.dct32_fwd_inv_dev(x.data_ptr(), z2.data_ptr(), r.data_ptr(), n_dct, stream))
+        also["dct32_fwd_inv_fused"] = dict(value=rate(leg, n_dct), unit="blocks/s", **brief(leg), hbm_frac=hbm(leg, 6144.0 * n_dct),
+                                           same_bytes_as_two_kernels=bool(torch.equal(z2, z)),
+                                           note="2 KiB in, 2 + 2 KiB out per block; hbm_frac from the HIP-event mean of the timed launches")
         del r, z2
+        # ---- 8x8 SATD residual batch ----------------------------------------------------------------
         d = torch.empty(n_satd * 64, dtype=torch.int16, device="cuda")
         s = torch.empty(n_satd, dtype=torch.int32, device="cuda")
         codec.fill_residual_dev(d.data_ptr(), n_satd * 64, SATD_SEED, rank * n_satd * 64, stream)
-        wall_s, k_ms_s = run_leg(OP_SATD8X8, codec.satd8x8_dev, d.data_ptr(), s.data_ptr(), n_satd, args.steps, args.warmup)
-        also["satd8x8"] = {"value": world * n_satd * args.steps / wall_s, "unit": "blocks/s",
-                           "ms_per_step": wall_s / args.steps * 1e3, "blocks_per_gpu": n_satd,
-                           "roofline": roofline(SATD_BYTES_PER_BLOCK, n_satd, k_ms_s, pmc.get("satd8x8_bytes_per_launch"))}
+        leg = timed_leg(lambda: codec.satd8x8_dev(d.data_ptr(), s.data_ptr(), n_satd, stream))
+        also["satd8x8"] = dict(value=rate(leg, n_satd), unit="blocks/s", blocks_per_gpu=n_satd, **brief(leg),
+                               roofline=roofline(leg, SATD_BYTES_PER_BLOCK, n_satd, pmc.get("satd8x8_bytes_per_launch"), pmc_src))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from _util import Oracle
             orc = Oracle()
-            ns = min(n_satd, 1 << 22)
-            dh = d[: ns * 64].cpu().numpy()
-            t0 = time.perf_counter()
-            ref_s = orc.satd8x8(dh, threads=orc.hw_threads())
-            dt = time.perf_counter() - t0
+            ns = min(n_satd, 1 << 23)
+            dh = d[: ns * 64].cpu().numpy().reshape(ns, 64)
+            gpu_s = s[:ns].cpu().numpy()
+
+            def satd_work(loc_in, loc_out, cnt):
+                orc.lib.orc_satd8x8_batch_mt(ctypes.c_void_p(loc_in.ctypes.data), ctypes.c_void_p(loc_out.ctypes.data), ctypes.c_size_t(cnt), 1)
+            mk = lambda b, e: (dh[b:e].copy(), np.zeros(e - b, np.uint32))
+            cores_s, _, _, _ = best_thread_count(ns, satd_work, mk)
+            dt, outs, bounds = run_pinned(ns, cores_s, satd_work, mk)
             also["satd8x8"]["cpu_baseline"] = {
-                "value": ns / dt, "unit": "blocks/s", "cores": orc.hw_threads(), "kind": "port",
-                "sample": "first %d blocks of the GPU batch" % ns,
-                "gpu_output_bit_exact_vs_cpu": bool(np.array_equal(ref_s.astype(np.int32), s[:ns].cpu().numpy()))}
+                "value": ns / dt, "unit": "blocks/s", "cores": cores_s, "kind": "port",
+                "sample": "first %d blocks of the GPU batch, %d pinned threads, pre-touched thread-local buffers" % (ns, cores_s),
+                "gpu_output_bit_exact_vs_cpu": all(np.array_equal(outs[i].astype(np.int32), gpu_s[int(bounds[i]):int(bounds[i + 1])])
+                                                   for i in range(len(outs)))}
+            del dh, gpu_s
         del d, s
 
         # ---- BASELINE configs[2]: full-search SATD motion estimation, one 3840x2160 luma frame, window +-64
@@ -320,75 +440,62 @@ def main():
             nb = (w // 8) * (h // 8)
             best = torch.empty(nb * 2, dtype=torch.int32, device="cuda")
             origin = refp.data_ptr() + pad * refp.stride(0) + pad
-
-            def me(_a, _b, _n, st):
-                codec.satd_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, st)
-
-            me_steps, me_warm = max(2, args.steps // 10), 2
-            for _ in range(me_warm):
-                me(0, 0, 0, stream)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(me_steps):
-                me(0, 0, 0, stream)
-            barrier()
-            wall_m = max_over_ranks(time.perf_counter() - t0)
             ncand = nb * (2 * rng + 1) ** 2
+            me_steps = max(4, K // 4)
+            leg = timed_leg(lambda: codec.satd_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream),
+                            steps=me_steps, warmup=2)
             mv = best.view(torch.int16).view(nb, 4)[:, :2]
             found = float(((mv[:, 0] == 5) & (mv[:, 1] == -3)).float().mean().item())
             # VALU floor: 32 x v_sad_u16 (4 cycles per wave64 instruction, tools/alubench) per 64 candidates
             floor_s = ncand / 64 * 32 * 4 / (4 * info_cu * 2.4e9)
-            also["satd8x8_me_search"] = {
-                "value": world * ncand * me_steps / wall_m, "unit": "SATD/s", "ms_per_frame": wall_m / me_steps * 1e3,
-                "frame": "%dx%d luma, 8x8 blocks, window +-%d (%d candidates per block)" % (w, h, rng, (2 * rng + 1) ** 2),
-                "bound": "VALU issue (v_sad_u16), not HBM: ~18 MB of compulsory traffic per frame",
-                "frac_of_v_sad_u16_floor": floor_s / (wall_m / me_steps),
-                "planted_mv_found_fraction": found,
-                "parity": "per-candidate cost pinned by satd8x8 (src_tb/satd.c); harness (order, tie-break, padding) unpinned"}
+            also["satd8x8_me_search"] = dict(
+                value=rate(leg, ncand), unit="SATD/s", ms_per_frame=leg["ms_per_step"], **brief(leg),
+                frame="%dx%d luma, 8x8 blocks, window +-%d (%d candidates per block)" % (w, h, rng, (2 * rng + 1) ** 2),
+                bound="VALU issue (v_sad_u16), not HBM: ~18 MB of compulsory traffic per frame",
+                frac_of_v_sad_u16_floor=floor_s / (leg["kernel_ms_mean"] * 1e-3),
+                frac_of_v_sad_u16_floor_wallclock=floor_s / (leg["ms_per_step"] * 1e-3),
+                planted_mv_found_fraction=found,
+                parity="per-candidate cost pinned by satd8x8 (src_tb/satd.c); harness (order, tie-break, padding) unpinned")
             # the same search with the SAD metric
-            for _ in range(me_warm):
-                codec.sad_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(me_steps):
-                codec.sad_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream)
-            barrier()
-            wall_sm = max_over_ranks(time.perf_counter() - t0)
+            leg = timed_leg(lambda: codec.sad_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream),
+                            steps=me_steps, warmup=2)
             mv = best.view(torch.int16).view(nb, 4)[:, :2]
-            also["sad8x8_me_search"] = {
-                "value": world * ncand * me_steps / wall_sm, "unit": "SAD/s", "ms_per_frame": wall_sm / me_steps * 1e3,
-                "frac_of_v_sad_u8_floor": (ncand / 64 * 16 * 4 / (4 * info_cu * 2.4e9)) / (wall_sm / me_steps),
-                "planted_mv_found_fraction": float(((mv[:, 0] == 5) & (mv[:, 1] == -3)).float().mean().item()),
-                "parity": "metric = sad() of riscv/programs/benchmarks/sad/sad.c at n = 8; harness unpinned, as for the SATD search"}
-            del big, sm, cur, refp, best
+            floor_sad = ncand / 64 * 16 * 4 / (4 * info_cu * 2.4e9)
+            also["sad8x8_me_search"] = dict(
+                value=rate(leg, ncand), unit="SAD/s", ms_per_frame=leg["ms_per_step"], **brief(leg),
+                frac_of_v_sad_u8_floor=floor_sad / (leg["kernel_ms_mean"] * 1e-3),
+                planted_mv_found_fraction=float(((mv[:, 0] == 5) & (mv[:, 1] == -3)).float().mean().item()),
+                parity="metric = sad() of riscv/programs/benchmarks/sad/sad.c at n = 8; harness unpinned, as for the SATD search")
+            del big, sm
 
         # ---- BASELINE configs[3]: the VVC transform set, 2 GiB of residual per class
         if not args.no_transform_set:
             ts = {}
             zt = torch.empty_like(x)                       # own output buffer: z still holds the headline leg's result
+            short = max(4, K // 4)
             for ttype, tname, inverse in ((0, "dct2", False), (1, "dst7", False), (0, "dct2_inv", True), (1, "dst7_inv", True)):
                 for n in (4, 8, 16):
                     nblk = (n_dct * 1024) // (n * n)
                     if inverse:
-                        fn = lambda a, b, cnt, st, tt=ttype, nn=n: codec.transform_inv_dev(tt, nn, a, b, cnt, 0, st)
+                        fn = lambda tt=ttype, nn=n, cnt=nblk: codec.transform_inv_dev(tt, nn, x.data_ptr(), zt.data_ptr(), cnt, 0, stream)
                     else:
-                        fn = lambda a, b, cnt, st, tt=ttype, nn=n: codec.transform_fwd_dev(tt, nn, a, b, cnt, 0, st)
-                    for _ in range(3):
-                        fn(x.data_ptr(), zt.data_ptr(), nblk, stream)
-                    barrier()
-                    t0 = time.perf_counter()
-                    for _ in range(args.steps):
-                        fn(x.data_ptr(), zt.data_ptr(), nblk, stream)
-                    barrier()
-                    wall_t = max_over_ranks(time.perf_counter() - t0)
-                    ts["%s_%dx%d" % (tname, n, n)] = {
-                        "value": world * nblk * args.steps / wall_t, "unit": "blocks/s",
-                        "hbm_frac": 4.0 * n * n * nblk / (wall_t / args.steps) / HBM_PEAK_BYTES_PER_S}
-            # per-CTU mixed batches: every 64x64 CTU's quadrants cycle through the four TU sizes; one call per
-            # (type, size) class over an offset table into the shared residual / coefficient buffers
+                        fn = lambda tt=ttype, nn=n, cnt=nblk: codec.transform_fwd_dev(tt, nn, x.data_ptr(), zt.data_ptr(), cnt, 0, stream)
+                    leg = timed_leg(fn, steps=short, warmup=3)
+                    ts["%s_%dx%d" % (tname, n, n)] = dict(value=rate(leg, nblk), unit="blocks/s", hbm_frac=hbm(leg, 4.0 * n * n * nblk), **brief(leg))
+            # per-CTU mixed batch: every 64x64 CTU's 32x32 quadrants cycle through the seven (type, size) classes
             n_ctu = (n_dct * 1024) // 4096
             q = torch.arange(n_ctu * 4, device="cuda", dtype=torch.int64)
-            qbase, qkind = q * 1024, (q + q // 4) % 7          # quadrant -> one of the seven (type, size) classes
+            qbase, qkind = q * 1024, (q + q // 4) % 7          # quadrant -> one of the seven classes
+            cls_of_kind = torch.tensor([3, 2, 6, 1, 5, 0, 4], device="cuda", dtype=torch.uint8)   # kinds -> type*4 + log2N-2
+            tile_cls = cls_of_kind[qkind].contiguous()
+            per_ctu = {"layout": "64x64 CTUs whose 32x32 quadrants cycle through the seven classes (DCT-II 32/16/8/4, DST-VII 16/8/4), "
+                                 "TUs of a quadrant contiguous", "ctus": n_ctu}
+            # the whole CTU-ordered buffer in ONE launch: every quadrant is a tile with its own class (xTransformTilesDev)
+            for inv_flag, name in ((0, "per_ctu_one_launch"), (1, "per_ctu_one_launch_inverse")):
+                leg = timed_leg(lambda f=inv_flag: codec.transform_tiles_dev(f, x.data_ptr(), zt.data_ptr(), n_ctu * 4, 0, tile_cls.data_ptr(), stream),
+                                steps=short, warmup=3)
+                per_ctu[name] = dict(value=rate(leg, n_ctu), unit="CTUs/s", hbm_frac=hbm(leg, 4.0 * n_ctu * 4096), **brief(leg))
+            # comparison only: the same buffer as seven per-class calls over offset tables
             mixed = []
             for kind, (tt, n) in enumerate(((0, 32), (0, 16), (1, 16), (0, 8), (1, 8), (0, 4), (1, 4))):
                 base = qbase[qkind == kind]
@@ -399,35 +506,14 @@ def main():
             def ctu_pass():
                 for tt, nn, o in mixed:
                     codec.transform_fwd_dev(tt, nn, x.data_ptr(), zt.data_ptr(), o.numel(), o.data_ptr(), stream)
-            for _ in range(3):
-                ctu_pass()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(max(2, args.steps // 4)):
-                ctu_pass()
-            barrier()
-            wall_c = max_over_ranks(time.perf_counter() - t0) / max(2, args.steps // 4)
-            per_ctu = {"value": world * n_ctu / wall_c, "unit": "CTUs/s", "hbm_frac": 4.0 * n_ctu * 4096 / wall_c / HBM_PEAK_BYTES_PER_S,
-                       "layout": "64x64 CTUs whose 32x32 quadrants cycle through the seven classes (DCT-II 32/16/8/4, DST-VII 16/8/4), "
-                                 "TUs of a quadrant contiguous; 7 calls per pass over offset tables", "ctus": n_ctu}
-            # the same buffer in ONE launch: every quadrant is a tile with its own class (xTransformTilesDev)
-            cls_of_kind = torch.tensor([3, 2, 6, 1, 5, 0, 4], device="cuda", dtype=torch.uint8)   # kinds above -> type*4 + log2N-2
-            tile_cls = cls_of_kind[qkind].contiguous()
-            for inv_flag, name in ((0, "per_ctu_one_launch"), (1, "per_ctu_one_launch_inverse")):
-                for _ in range(3):
-                    codec.transform_tiles_dev(inv_flag, x.data_ptr(), zt.data_ptr(), n_ctu * 4, 0, tile_cls.data_ptr(), stream)
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(max(2, args.steps // 4)):
-                    codec.transform_tiles_dev(inv_flag, x.data_ptr(), zt.data_ptr(), n_ctu * 4, 0, tile_cls.data_ptr(), stream)
-                barrier()
-                wall_o = max_over_ranks(time.perf_counter() - t0) / max(2, args.steps // 4)
-                per_ctu[name] = {"value": world * n_ctu / wall_o, "unit": "CTUs/s", "hbm_frac": 4.0 * n_ctu * 4096 / wall_o / HBM_PEAK_BYTES_PER_S}
+            leg = timed_leg(ctu_pass, steps=short, warmup=3)
+            per_ctu["seven_calls_over_offset_tables"] = dict(value=rate(leg, n_ctu), unit="CTUs/s", hbm_frac=hbm(leg, 4.0 * n_ctu * 4096),
+                                                             note="comparison only; the one-launch form above is the configs[3] path", **brief(leg))
             del zt, mixed, q, qbase, qkind, tile_cls
             also["transform_set"] = {"classes": ts, "per_ctu_mixed": per_ctu, "parity": "unpinned upstream except DCT-II 32; bit-exact vs this repo's oracle",
-                                     "note": "wall-clock rates (launch gaps included); 4*N*N algorithmic bytes per block"}
-        # ---- fused front end: tiled cur/pred frames -> coefficients / costs, residual never in HBM
-        if not args.no_transform_set:
+                                     "note": "4*N*N algorithmic bytes per block; hbm_frac from the HIP-event mean of the timed launches"}
+
+            # ---- fused front end: tiled cur/pred frames -> coefficients / costs, residual never in HBM
             # 32768^2 luma: exactly 2^20 DCT32 blocks and 2^24 SATD blocks, i.e. the two-kernel legs launch the
             # headline kernels at the headline sizes (keeps rocprofv3's per-kernel averages comparable)
             fw, fh = 32768, 32768
@@ -452,24 +538,16 @@ def main():
                  lambda: (codec.residual_luma_dev(tcur.data_ptr(), tpred.data_ptr(), fw, fh, 8, fres.data_ptr(), stream),
                           codec.satd8x8_dev(fres.data_ptr(), fcost.data_ptr(), fw * fh // 64, stream))))
             for name, units, bytes_per_unit, fn in legs:
-                for _ in range(3):
-                    fn()
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    fn()
-                barrier()
-                wall_f = max_over_ranks(time.perf_counter() - t0)
-                fused[name] = {"value": world * units * args.steps / wall_f, "unit": "blocks/s"}
+                leg = timed_leg(fn, steps=short, warmup=3)
+                fused[name] = dict(value=rate(leg, units), unit="blocks/s", **brief(leg))
                 if bytes_per_unit:
-                    fused[name]["hbm_frac"] = bytes_per_unit * units / (wall_f / args.steps) / HBM_PEAK_BYTES_PER_S
+                    fused[name]["hbm_frac"] = hbm(leg, bytes_per_unit * units)
             fused["note"] = ("%dx%d tiled frame pair (x266.cpp ref_block_t); fused kernels are bit-identical to the two-kernel paths "
                              "listed next to them (tests/test_gpu_tiles.py)" % (fw, fh))
             also["fused_from_tiles"] = fused
             del tcur, tpred, fcoef, fcost, fres
 
-        # ---- frame container conversion, residual formation, SAD -- pure data movement, HBM-bound
-        if not args.no_transform_set:
+            # ---- frame container conversion, residual formation, SAD -- pure data movement, HBM-bound
             fw2, fh2 = 16384, 16384                                      # 256 Mi luma samples
             npx = fw2 * fh2
             g = torch.Generator(device="cuda")
@@ -489,24 +567,15 @@ def main():
                     ("sad_8x8", 2.0 * npx + 4.0 * (npx // 64), lambda: codec.sad_dev(8, ypl.data_ptr(), t_b.data_ptr(), sad_o.data_ptr(), npx // 64, stream)),
                     ("sad_16x16", 2.0 * npx + 4.0 * (npx // 256), lambda: codec.sad_dev(16, ypl.data_ptr(), t_b.data_ptr(), sad_o.data_ptr(), npx // 256, stream)),
                     ("sad_64x64", 2.0 * npx + 4.0 * (npx // 4096), lambda: codec.sad_dev(64, ypl.data_ptr(), t_b.data_ptr(), sad_o.data_ptr(), npx // 4096, stream))):
-                steps_f = max(2, args.steps // 4)
-                for _ in range(5):
-                    fn()
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(steps_f):
-                    fn()
-                barrier()
-                wall_ff = max_over_ranks(time.perf_counter() - t0) / steps_f
-                front[name] = {"GBps": world * nbytes / wall_ff / 1e9, "hbm_frac": nbytes / wall_ff / HBM_PEAK_BYTES_PER_S,
-                               "samples_per_s": world * npx / wall_ff}
+                leg = timed_leg(fn, steps=short, warmup=3)
+                front[name] = dict(GBps=world * nbytes * leg["steps"] / leg["wall_s"] / 1e9, hbm_frac=hbm(leg, nbytes),
+                                   samples_per_s=world * npx * leg["steps"] / leg["wall_s"], **brief(leg))
             front["note"] = ("%dx%d frame; bytes = planes read + tile bytes written (conv), luma of both tile frames + int16 residual "
                              "(residual), both blocks + 4-byte result (sad)" % (fw2, fh2))
             also["front_end_and_sad"] = front
             del ypl, upl, vpl, t_a, t_b, res2, sad_o
 
-        # ---- 32x32 intra prediction and mode decision (HEVC 35 modes; parity unpinned upstream)
-        if not args.no_transform_set:
+            # ---- 32x32 intra prediction and mode decision (HEVC 35 modes; parity unpinned upstream)
             g = torch.Generator(device="cuda")
             g.manual_seed(0x32 + rank)
             n_sets = 59918                                              # x 35 modes = 2 GiB of predictions
@@ -514,70 +583,120 @@ def main():
             modes_t = torch.arange(35, device="cuda", dtype=torch.uint8).repeat(n_sets)
             index_t = torch.arange(n_sets, device="cuda", dtype=torch.int32).repeat_interleave(35)
             pred_t = torch.empty(n_sets * 35 * 1024, dtype=torch.uint8, device="cuda")
-            n_dec = 1 << 17
+            n_dec = min(1 << 17, n_sets)
             src_t = torch.randint(0, 256, (n_dec * 1024,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
             cost_t = torch.empty(n_dec * 35, dtype=torch.int32, device="cuda")
             bestm_t = torch.empty(n_dec, dtype=torch.uint8, device="cuda")
             intra = {}
-            for name, units, fn in (
-                    ("predict", n_sets * 35, lambda: codec.intra32_predict_dev(refs_t.data_ptr(), modes_t.data_ptr(), index_t.data_ptr(),
-                                                                             pred_t.data_ptr(), n_sets * 35, stream)),
-                    ("decide_35_modes", n_dec, lambda: codec.intra32_costs_dev(refs_t.data_ptr(), src_t.data_ptr(), cost_t.data_ptr(),
-                                                                             bestm_t.data_ptr(), min(n_dec, n_sets), stream))):
-                steps_i = max(2, args.steps // 4)
-                for _ in range(5):
-                    fn()
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(steps_i):
-                    fn()
-                barrier()
-                wall_i2 = max_over_ranks(time.perf_counter() - t0)
-                units = units if name == "predict" else min(n_dec, n_sets)
-                intra[name] = {"value": world * units * steps_i / wall_i2, "unit": "predictions/s" if name == "predict" else "blocks/s"}
-            intra["predict"]["written_hbm_frac"] = 1024.0 * intra["predict"]["value"] / world / HBM_PEAK_BYTES_PER_S
-            intra["decide_35_modes"]["satd8x8_per_s"] = intra["decide_35_modes"]["value"] * 35 * 16
+            leg = timed_leg(lambda: codec.intra32_predict_dev(refs_t.data_ptr(), modes_t.data_ptr(), index_t.data_ptr(), pred_t.data_ptr(), n_sets * 35, stream),
+                            steps=short, warmup=3)
+            intra["predict"] = dict(value=rate(leg, n_sets * 35), unit="predictions/s", written_hbm_frac=hbm(leg, 1024.0 * n_sets * 35), **brief(leg))
+            leg = timed_leg(lambda: codec.intra32_costs_dev(refs_t.data_ptr(), src_t.data_ptr(), cost_t.data_ptr(), bestm_t.data_ptr(), n_dec, stream),
+                            steps=short, warmup=3)
+            intra["decide_35_modes"] = dict(value=rate(leg, n_dec), unit="blocks/s", satd8x8_per_s=rate(leg, n_dec) * 35 * 16, **brief(leg))
             intra["parity"] = "unpinned upstream (src/mkIntra32-wip.bsv is a sketch without a model); bit-exact vs this repo's oracle"
             also["intra32"] = intra
             del refs_t, modes_t, index_t, pred_t, src_t, cost_t, bestm_t
 
-        # ---- BASELINE configs[4] (on request): 8K frame stream, scatter -> kernels -> gather over RCCL
-        if args.stream8k > 0 and ctrl == "cuda":
-            from x266_amd.stream import FrameGeometry, PipelinedFrameStream
-            geo = FrameGeometry(7680, 4320)
-            dev = torch.device("cuda", local_rank)
-            cur_stream = lambda: torch.cuda.current_stream().cuda_stream
-            st8 = PipelinedFrameStream(
-                geo, dev,
-                lambda tin, tout, nblk: codec.dct32_fwd_dev(tin.data_ptr(), tout.data_ptr(), nblk, cur_stream()),
-                lambda tin, tout, nblk: codec.satd8x8_dev(tin.data_ptr(), tout.data_ptr(), nblk, cur_stream()),
-                dist=dist)
-            fd = fs = None
+        # ---- the node layer of the C ABI: BASELINE configs[4] and the other end-to-end scatter/gather figures
+        if ctrl == "cuda" and args.stream8k > 0:
+            uid = [Node.unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(uid, src=0, device=torch.device("cuda", local_rank))
+            node = Node.for_rank(local_rank, rank, world, uid[0])      # xHipNodeInitRank: one process per GPU, also at N = 1
+            node.self_test()                                            # RCCL ring send/recv + all-reduce, checked
+            fw8, fh8 = 7680, 4320
+            nd8, ns8 = (fw8 // 32) * (fh8 // 32), (fw8 // 8) * (fh8 // 8)
+            IN_RING, OUT_RING = 3, 4
+            fin = fout = None
             if rank == 0:
-                fd = torch.empty(geo.dct_blocks * 1024, dtype=torch.int16, device=dev)
-                fs = torch.empty(geo.satd_blocks * 64, dtype=torch.int16, device=dev)
-                codec.fill_residual_dev(fd.data_ptr(), fd.numel(), DCT_SEED, 0, stream)
-                codec.fill_residual_dev(fs.data_ptr(), fs.numel(), SATD_SEED, 0, stream)
-            sums = []
+                fin = [(torch.empty(nd8 * 1024, dtype=torch.int16, device="cuda"), torch.empty(ns8 * 64, dtype=torch.int16, device="cuda")) for _ in range(IN_RING)]
+                fout = [(torch.zeros(nd8 * 1024, dtype=torch.int16, device="cuda"), torch.zeros(ns8, dtype=torch.int32, device="cuda")) for _ in range(OUT_RING)]
+                for i, (a, b) in enumerate(fin):
+                    codec.fill_residual_dev(a.data_ptr(), a.numel(), DCT_SEED, i * 100000007, stream)
+                    codec.fill_residual_dev(b.data_ptr(), b.numel(), SATD_SEED, i * 100000007, stream)
+            torch.cuda.synchronize()
+            st8 = node.frame_stream(fw8, fh8)
 
-            def sink8(f, coef, cost):
-                if f == args.stream8k - 1:
-                    sums.append(int(coef.to(torch.int64).sum().item()) + int(cost.to(torch.int64).sum().item()))
-            st8.run(3, lambda f: (fd, fs), None)
+            def push8(f):
+                if rank == 0:
+                    a, b = fin[f % IN_RING]
+                    c, e = fout[f % OUT_RING]
+                    st8.push([a.data_ptr(), b.data_ptr()], [c.data_ptr(), e.data_ptr()])
+                else:
+                    st8.push()
+            F = args.stream8k
+            for f in range(8):
+                push8(f)
+            st8.flush()
             barrier()
             t0 = time.perf_counter()
-            st8.run(args.stream8k, lambda f: (fd, fs), sink8)
+            for f in range(F):
+                push8(f)
+            st8.flush()
             barrier()
             wall8 = max_over_ranks(time.perf_counter() - t0)
+            exact8 = None
+            if rank == 0:                                               # last frame against the plain single-device calls
+                a, b = fin[(F - 1) % IN_RING]
+                c, e = fout[(F - 1) % OUT_RING]
+                c1, e1 = torch.empty_like(c), torch.empty_like(e)
+                codec.dct32_fwd_dev(a.data_ptr(), c1.data_ptr(), nd8, stream)
+                codec.satd8x8_dev(b.data_ptr(), e1.data_ptr(), ns8, stream)
+                torch.cuda.synchronize()
+                exact8 = bool(torch.equal(c, c1) and torch.equal(e, e1))
+            peers = world - 1
+            link_bytes = (nd8 * 2048 + ns8 * 128) / world              # one peer's input shard of a frame, over one link
             also["stream8k"] = {
-                "frames_per_s": args.stream8k / wall8, "ms_per_frame": wall8 / args.stream8k * 1e3,
-                "frame": "7680x4320: %d DCT32 blocks (66.4 MB) + %d SATD blocks (66.4 MB)" % (geo.dct_blocks, geo.satd_blocks),
-                "path": "rank 0 sends every peer its shard of frame f+1 and receives frame f-1's coefficients and costs "
-                        "(batched isend/irecv on a side stream) while all ranks transform frame f"
-                        if world > 1 else "single rank: device copies + kernels, no transfer",
-                "link_bound": "one xGMI link ~153 GB/s => <= 7.5e7 DCT32 input blocks/s per peer (SURVEY.md 8e)"}
+                "frames_per_s": F / wall8, "ms_per_frame": wall8 / F * 1e3, "frames": F,
+                "dct32_blocks_per_s": nd8 * F / wall8, "satd8x8_blocks_per_s": ns8 * F / wall8,
+                "frame": "7680x4320: %d DCT32 blocks (66.4 MB) + %d SATD blocks (66.4 MB)" % (nd8, ns8),
+                "path": "C ABI node layer (xNodeStreamPush / Flush): per step one RCCL group carries frame t's shards root -> peers and "
+                        "frame t-2's coefficients and costs peers -> root on a communication stream while every rank transforms frame t"
+                        if world > 1 else "C ABI node layer, one rank: the root transforms the frame in place, no transfer (RCCL only in the self-test)",
+                "bit_exact_vs_single_device": exact8,
+                "link_bound_frames_per_s": (XGMI_LINK_BYTES_PER_S / link_bytes) if peers else None,
+                "link_bound": "each peer's input shard crosses ONE xGMI link (~153 GB/s per direction): <= 7.5e7 DCT32 blocks/s per peer (SURVEY.md 8e)"}
+            st8.close()
+            # one resident batch, scattered and gathered (SURVEY 8e "end-to-end scatter -> compute -> gather")
+            nsg = min(1 << 18, n_dct)
+            xin = xout = None
             if rank == 0:
-                also["stream8k"]["output_checksum"] = sums[0] if sums else None
+                xin, xout = x[: nsg * 1024], z[: nsg * 1024]
+            torch.cuda.synchronize()
+            node.batch_scatter_gather(OP_DCT32_FWD, xin.data_ptr() if rank == 0 else 0, xout.data_ptr() if rank == 0 else 0, nsg, 0)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                node.batch_scatter_gather(OP_DCT32_FWD, xin.data_ptr() if rank == 0 else 0, xout.data_ptr() if rank == 0 else 0, nsg, 0)
+            barrier()
+            wall_sg = max_over_ranks(time.perf_counter() - t0) / 4
+            also["dct32_scatter_gather"] = {"value": nsg / wall_sg, "unit": "blocks/s", "blocks": nsg,
+                                            "note": "root-resident batch cut into 4096-block chunks, pipelined through the node stream "
+                                                    "(xNodeBatchScatterGather); at N = 1 no transfer"}
+            if not args.no_me:
+                # sharded motion search: stripes + halo from the root, records back (xNodeSatd8x8Search)
+                nstr = max(world, 1)
+                node.satd_search(cur.data_ptr() if rank == 0 else 0, cur.stride(0), origin if rank == 0 else 0, refp.stride(0), 3840, 2160, 64, nstr,
+                                 best.data_ptr() if rank == 0 else 0)
+                ref_best = None
+                if rank == 0:
+                    ref_best = best.clone()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    node.satd_search(cur.data_ptr() if rank == 0 else 0, cur.stride(0), origin if rank == 0 else 0, refp.stride(0), 3840, 2160, 64, nstr,
+                                     best.data_ptr() if rank == 0 else 0)
+                barrier()
+                wall_ms = max_over_ranks(time.perf_counter() - t0) / 3
+                same = None
+                if rank == 0:
+                    codec.satd_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), 3840, 2160, 64, best.data_ptr(), 0, stream)
+                    torch.cuda.synchronize()
+                    same = bool(torch.equal(best, ref_best))
+                also["satd8x8_me_search_sharded"] = {"ms_per_frame": wall_ms * 1e3, "stripes": nstr, "identical_to_single_device": same,
+                                                     "note": "synchronous call incl. scatter of cur stripes + reference halo and gather of (mv, cost)"}
+            node.close()
         result["also"] = also
         # BASELINE.json quotes two figures, 32x32 DCT blocks/s and 8x8 SATD blocks/s: the second one, lifted to the top level
         result["secondary"] = {"metric": "satd8x8_blocks_per_s", "value": also["satd8x8"]["value"], "unit": "blocks/s",
@@ -585,6 +704,9 @@ def main():
 
     # ---- CPU baseline for the headline leg (rank 0, N = 1 only) ------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if not args.no_also:                                            # z was reused as scatter-gather output: same values, recompute to be explicit
+            codec.dct32_fwd_dev(x.data_ptr(), z.data_ptr(), n_dct, stream)
+            torch.cuda.synchronize()
         base, exact = cpu_baseline_dct(x.cpu().numpy().reshape(n_dct, 1024), z.cpu().numpy().reshape(n_dct, 1024))
         result["cpu_baseline"] = base
         if not exact:
@@ -595,7 +717,8 @@ def main():
     if rank == 0:
         info = codec.device_info()
         result["device"] = info["name"].strip()
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

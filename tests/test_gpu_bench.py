@@ -33,8 +33,16 @@ def test_bench_small_run_has_every_leg_and_field():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["cpu_baseline"]["gpu_output_bit_exact_vs_cpu"] is True and d["cpu_baseline"]["cores"] >= 1
     for leg in ("dct32_inv", "dct32_fwd_inv_fused", "satd8x8", "satd8x8_me_search", "sad8x8_me_search", "transform_set",
-                "fused_from_tiles", "front_end_and_sad", "intra32"):
+                "fused_from_tiles", "front_end_and_sad", "intra32", "stream8k", "dct32_scatter_gather", "satd8x8_me_search_sharded"):
         assert leg in d["also"], leg
+    # kernel time and wall-clock come from the same launches: the former can never exceed the latter
+    assert r["kernel_ms_per_launch"] <= d["ms_per_step"] * 1.0001
+    for leg in ("dct32_inv", "dct32_fwd_inv_fused", "satd8x8", "satd8x8_me_search"):
+        assert d["also"][leg]["kernel_ms_mean"] <= d["also"][leg]["ms_per_step"] * 1.0001, leg
+    assert r["traffic"] is None or "replayed" in r["traffic_source"]
+    assert d["also"]["stream8k"]["bit_exact_vs_single_device"] is True          # BASELINE configs[4] through the C node layer
+    assert d["also"]["satd8x8_me_search_sharded"]["identical_to_single_device"] is True
+    assert 0 < d["cpu_baseline"]["parallel_efficiency"] <= 1.5 and d["cpu_baseline"]["host_cpu"]
     assert d["also"]["dct32_fwd_inv_fused"]["same_bytes_as_two_kernels"] is True
     assert d["also"]["satd8x8_me_search"]["planted_mv_found_fraction"] > 0.99
     assert "error" not in d

@@ -88,6 +88,10 @@ def load_library():
     L.xHipStreamSync.argtypes = [_P, _P]
     L.xHipTimeKernel.argtypes = [_P, ctypes.c_int, _P, _P, _SZ, ctypes.c_int, _P,
                                  ctypes.POINTER(ctypes.c_double)]
+    L.xHipEventCreate.argtypes = [_P, ctypes.POINTER(_P)]
+    L.xHipEventDestroy.argtypes = [_P, _P]
+    L.xHipEventRecord.argtypes = [_P, _P, _P]
+    L.xHipEventElapsedMs.argtypes = [_P, _P, _P, ctypes.POINTER(ctypes.c_double)]
     L.xDct32PackDiffRows.argtypes = [_P, ctypes.c_int, _P]
     L.xDct32PackDiffRows.restype = None
     L.xDct32PackDctWord.argtypes = [_P, ctypes.c_int]
@@ -395,6 +399,23 @@ class Codec:
         ms = ctypes.c_double()
         self._check(self.L.xHipTimeKernel(self.ctx, op, d_in, d_out, n_blocks, reps, stream, ctypes.byref(ms)),
                     "xHipTimeKernel")
+        return ms.value
+
+    # -- HIP events on the launching stream (per-launch durations of any sequence of calls) -------
+    def event_create(self):
+        e = _P()
+        self._check(self.L.xHipEventCreate(self.ctx, ctypes.byref(e)), "xHipEventCreate")
+        return e.value
+
+    def event_destroy(self, event):
+        self._check(self.L.xHipEventDestroy(self.ctx, event), "xHipEventDestroy")
+
+    def event_record(self, event, stream=0):
+        self._check(self.L.xHipEventRecord(self.ctx, event, stream), "xHipEventRecord")
+
+    def event_elapsed_ms(self, start, stop):
+        ms = ctypes.c_double()
+        self._check(self.L.xHipEventElapsedMs(self.ctx, start, stop, ctypes.byref(ms)), "xHipEventElapsedMs")
         return ms.value
 
     def alloc(self, nbytes):
