@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Developer probe: ME search timing at 4K (GPU box)."""
-import os, sys, time, ctypes
+"""Developer probe: full-search timing at 4K (GPU box), HIP events per launch.
+usage: gpu_me_probe.py [satd|sad|all]"""
+import os, sys, statistics
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import x266_amd
 from _util import me_frames
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
 cd = x266_amd.Codec(0)
 w, h, rng, pad = 3840, 2160, 64, 64
 cur, refp = me_frames(w, h, pad, 2160, mv=(5, -3), noise=4)
@@ -14,20 +16,32 @@ dc = torch.from_numpy(cur).cuda(); dr = torch.from_numpy(refp).cuda()
 nb = (w // 8) * (h // 8)
 best = torch.empty(nb * 2, dtype=torch.int32, device="cuda")
 org = dr.data_ptr() + pad * refp.strides[0] + pad
-for var, tr, rp in ((1, 2, 1), (2, 2, 2), (2, 4, 1), (2, 4, 2), (2, 4, 3), (2, 4, 2)):
-    cd.set_option("me_tile_rows", tr); cd.set_option("me_variant", var); cd.set_option("me_row_pairs", rp)
-    cd.satd_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr()); torch.cuda.synchronize()
-    t = time.perf_counter(); reps = 5
-    for _ in range(reps): cd.satd_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr())
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
-    ncand = nb * (2 * rng + 1) ** 2
-    print("variant=%d tile_rows=%d row_pairs=%d: %.3f ms/frame  %.3e SATD/s" % (var, tr, rp, dt * 1e3, ncand / dt), flush=True)
+ncand = nb * (2 * rng + 1) ** 2
+ev = [cd.event_create() for _ in range(21)]
 
-for tr in (2, 4):
-    cd.set_option("me_tile_rows", tr)
-    cd.sad_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr()); torch.cuda.synchronize()
-    t = time.perf_counter(); reps = 5
-    for _ in range(reps): cd.sad_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr())
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
-    print("SAD search tile_rows=%d: %.3f ms/frame  %.3e SAD/s" % (tr, dt * 1e3, ncand / dt), flush=True)
-cd.set_option("me_tile_rows", 4)
+def timed(fn, reps=20):
+    for _ in range(30): fn()                       # clocks
+    torch.cuda.synchronize()
+    for i in range(reps):
+        cd.event_record(ev[i]); fn()
+    cd.event_record(ev[reps])
+    d = [cd.event_elapsed_ms(ev[i], ev[i + 1]) for i in range(reps)]
+    return statistics.median(d), min(d)
+
+ref = None
+if what in ("satd", "all"):
+    for var, tr, rp, wg, sp in ((2, 4, 2, 0, 0), (3, 4, 2, 0, 1), (4, 4, 2, 0, 0), (4, 2, 2, 0, 0), (4, 4, 2, 192, 0), (4, 4, 2, 0, 0)):
+        cd.set_option("me_tile_rows", tr); cd.set_option("me_variant", var); cd.set_option("me_row_pairs", rp); cd.set_option("me_wg_threads", wg); cd.set_option("me_splits", sp)
+        fn = lambda: cd.satd_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr())
+        med, mn = timed(fn)
+        res = best.clone()
+        if ref is None: ref = res
+        print("satd variant=%d tile_rows=%d units=%d wg=%3d splits=%d: median %.3f ms (min %.3f)  %.3e SATD/s  frac_of_floor %.3f  same_result=%s"
+              % (var, tr, rp, wg, sp, med, mn, ncand / med * 1e3, 1.7554 / med, bool(torch.equal(res, ref))), flush=True)
+    cd.set_option("me_tile_rows", 4); cd.set_option("me_variant", 4); cd.set_option("me_row_pairs", 2); cd.set_option("me_wg_threads", 0); cd.set_option("me_splits", 0)
+if what in ("sad", "all"):
+    for tr in (2, 4):
+        cd.set_option("me_tile_rows", tr)
+        med, mn = timed(lambda: cd.sad_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr()))
+        print("SAD search tile_rows=%d: median %.3f ms (min %.3f)  %.3e SAD/s  frac_of_floor %.3f" % (tr, med, mn, ncand / med * 1e3, 0.8777 / med), flush=True)
+    cd.set_option("me_tile_rows", 4)

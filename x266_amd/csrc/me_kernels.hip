@@ -55,6 +55,13 @@ __device__ __forceinline__ uint32_t sad16(const uint32_t (&p)[16], const uint32_
     return s;
 }
 
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 struct MeParams {
     const uint8_t *cur;
     const uint8_t *ref;           // pixel (0,0); valid for x,y in [-range, dim + range)
@@ -67,6 +74,8 @@ struct MeParams {
     int pitch;                    // LDS bytes per window row
     x266_me_result_t *best;
     uint32_t *costs;              // optional [block][(2R+1)^2]
+    uint32_t *keys;               // variant 3: per-block running minimum (cost << 16 | window position), merged with atomicMin
+    int splits;                   // variant 3: workgroups per tile (each takes a band of the tile's candidate rows)
 };
 
 template <int TBY>
@@ -235,11 +244,12 @@ __global__ __launch_bounds__(256) void satd_search_kernel(const MeParams P)
 // the search kernel addresses all blocks of its tile from one scalar base with immediate offsets.
 __global__ __launch_bounds__(256) void me_coef_kernel(const uint8_t *__restrict__ cur, long long cur_stride,
                                                       int blocks_x, int n_blocks, int tiles_x, int tby,
-                                                      uint32_t *__restrict__ coef)
+                                                      uint32_t *__restrict__ coef, uint32_t *__restrict__ keys)
 {
     const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
     const int group = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (group * 32 >= n_blocks) return;
+    if (keys && half == 0 && group * 32 + n < n_blocks) keys[group * 32 + n] = 0xFFFFFFFFu;   // variant 3 merges into these
     int blk = group * 32 + n;
     const bool live = blk < n_blocks;
     if (!live) blk = n_blocks - 1;
@@ -430,6 +440,433 @@ __global__ __launch_bounds__(256) void satd_search_kernel_v2(const MeParams P, c
 }
 
 // ============================================================================
+// Variant 3 (default).  Same algorithm as variant 2 -- transform every candidate POSITION once,
+// exchange the coefficient halves so that a lane owns all 64 coefficients of one position, score
+// against block coefficients held in SGPRs -- with the instruction count cut where the SQ counters
+// of variant 2 showed it going (profiles/r01_pmc_sq_counters.csv: VALU 90 % busy at 1.84x the
+// v_sad_u16 floor's instruction count):
+//   * unit geometry 16 columns x 4 rows instead of 32 x 2: a block's window (2R+1 wide, starting at
+//     a multiple of 8) is covered by 16-column groups with at most 15 + 7 idle columns instead of
+//     31 + 24, and by 4-row units with at most 3 idle rows: 87 % of the scored lanes are valid
+//     candidates at R = 64 (81 % before);
+//   * the running minimum is keyed by POSITION, (cost << 16) | (window row << 8 | window column):
+//     the same for every block, so it is formed once per unit instead of once per (unit, block),
+//     and raster order of positions is raster order of candidates for any block;
+//     per (unit, block): v_and, v_lshl_or and half a v_min3 (was ~10 instructions);
+//   * window-edge units take a separate path with per-lane validity; full units have none;
+//   * 192-thread workgroups when that fills the chip in fewer, fuller rounds (the kernel needs
+//     ~150 VGPRs = 3 waves per SIMD: 4080 tiles of a 4K frame over 768 four-wave slots are 5.3
+//     rounds, over 1024 three-wave slots 3.98).
+// ============================================================================
+template <int TBY, int U, bool COSTS>
+__global__ __launch_bounds__(256, (U == 1 ? 4 : 3)) void satd_search_kernel_v3(const MeParams P, const uint32_t *__restrict__ coef)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NBLK = kTileBlocksX * TBY;
+    const int R = P.range, span = 2 * R + 1;
+    const int n_units_y = (P.n_rows + 3) / 4;                          // 4-row units
+    const int n_items_y = (n_units_y + U - 1) / U;
+    // this workgroup's band of the tile's item rows (P.splits workgroups per tile: finer dispatch granularity,
+    // so that the last round of resident workgroups is not mostly empty -- profiles/r02_me_tail.txt)
+    const int tile = blockIdx.x / P.splits, split = blockIdx.x - tile * P.splits;
+    const int iy_begin = (n_items_y * split) / P.splits, iy_end = (n_items_y * (split + 1)) / P.splits;
+    const int row_begin = 4 * U * iy_begin;                            // first window row this band reads
+    const int win_rows = 4 * U * (iy_end - iy_begin) + 7;
+    uint32_t *best_lds = reinterpret_cast<uint32_t *>(smem);
+    unsigned char *win = smem + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, n_waves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, half = lane >> 5;
+    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const int x0 = tx * (8 * kTileBlocksX), y0 = ty * (8 * TBY);
+
+    {   // reference window, signed pixels
+        const int dwords_per_row = P.pitch >> 2;
+        const int total = win_rows * dwords_per_row;
+        for (int i = tid; i < total; i += blockDim.x) {
+            const int ry = i / dwords_per_row, cx = (i - ry * dwords_per_row) * 4;
+            int gy = y0 - R + row_begin + ry;
+            gy = gy < -R ? -R : (gy > P.height + R - 1 ? P.height + R - 1 : gy);
+            const uint8_t *row = P.ref + (long long)gy * P.ref_stride;
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int gx = x0 - R + cx + b;
+                gx = gx < -R ? -R : (gx > P.width + R - 1 ? P.width + R - 1 : gx);
+                v |= (uint32_t)row[gx] << (8 * b);
+            }
+            reinterpret_cast<uint32_t *>(win)[i] = v ^ 0x80808080u;
+        }
+    }
+    if (tid < NBLK) best_lds[tid] = 0xFFFFFFFFu;
+    const HadamardOps H = make_hadamard_ops(lane);
+    __syncthreads();
+
+    uint32_t best[TBY][kTileBlocksX];
+#pragma unroll
+    for (int j = 0; j < TBY; ++j)
+#pragma unroll
+        for (int i = 0; i < kTileBlocksX; ++i) best[j][i] = 0xFFFFFFFFu;
+
+    const int col_in = n & 15, row_in = n >> 4;                        // this lane's column / row inside a 16 x 2 transform
+    const int sh = (col_in & 3) * 8;
+    // after the half exchange lanes 0-31 own rows 2, 3 of the unit, lanes 32-63 rows 0, 1
+    const int lane_row = (half ? 0 : 2) + row_in;
+    const int n_items = (iy_end - iy_begin) * P.n_groups;
+    const int blocks_left_x = P.blocks_x - tx * kTileBlocksX, blocks_left_y = P.blocks_y - ty * TBY;
+    const uint32_t *__restrict__ tile_coef = coef + (size_t)tile * (NBLK * 32);
+    for (int item = wave; item < n_items; item += n_waves) {
+        const int iyl = item / P.n_groups, g = item - iyl * P.n_groups;   // wave-uniform
+        const int r = 4 * U * (iy_begin + iyl);                        // first window row (tile coordinates) of the item's U units
+        uint32_t a[U][16], b[U][16], pid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v4i w0, w1;
+            load_window(win, P.pitch, r - row_begin + 4 * u + row_in + 4 * half, 16 * g + col_in, sh, w0, w1);
+            hadamard_pack(H, w0, w1, a[u]);
+            load_window(win, P.pitch, r - row_begin + 4 * u + 2 + row_in + 4 * half, 16 * g + col_in, sh, w0, w1);
+            hadamard_pack(H, w0, w1, b[u]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(b[u][k], a[u][k], false, false);
+                b[u][k] = (uint32_t)sw[0];
+                a[u][k] = (uint32_t)sw[1];
+            }
+            pid[u] = (uint32_t)((r + 4 * u + lane_row) << 8 | (16 * g + col_in));
+        }
+
+#pragma unroll
+        for (int j = 0; j < TBY; ++j) {
+            const int dy0 = r - 8 * j;                                 // candidate row index of window row r for block row j
+            if (dy0 + 4 * U - 1 < 0 || dy0 >= span || j >= blocks_left_y) continue;   // wave-uniform
+            const bool rows_full = dy0 >= 0 && dy0 + 4 * U - 1 < span;
+#pragma unroll
+            for (int i = 0; i < kTileBlocksX; ++i) {
+                const int lo = 16 * g - 8 * i;                         // dx index of column 0 of the group for block i
+                if (lo + 15 < 0 || lo >= span || i >= blocks_left_x) continue;       // wave-uniform
+                const uint32_t *__restrict__ c = tile_coef + (j * kTileBlocksX + i) * 32;
+                uint32_t s[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) s[u] = 2u;                 // the "+2" of (sum + 2) >> 2
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) s[u] = __builtin_amdgcn_sad_u16(b[u][k], c[k], s[u]);
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) s[u] = __builtin_amdgcn_sad_u16(a[u][k], c[16 + k], s[u]);
+                uint32_t key[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) key[u] = ((s[u] & ~3u) << 14) | pid[u];      // (s >> 2) << 16 | position
+                if (!(rows_full && lo >= 0 && lo + 15 < span)) {       // wave-uniform: the item straddles the block's window edge
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const bool ok = (unsigned)(lo + col_in) < (unsigned)span && (unsigned)(dy0 + 4 * u + lane_row) < (unsigned)span;
+                        key[u] = ok ? key[u] : 0xFFFFFFFFu;
+                    }
+                }
+                if (U == 2) {
+                    best[j][i] = min3u(best[j][i], key[0], key[1]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) best[j][i] = key[u] < best[j][i] ? key[u] : best[j][i];
+                }
+                if (COSTS) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int dxi = lo + col_in, dyi = dy0 + 4 * u + lane_row;
+                        if ((unsigned)dxi < (unsigned)span && (unsigned)dyi < (unsigned)span) {
+                            const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
+                            P.costs[blk * (size_t)(span * span) + (size_t)(dyi * span + dxi)] = s[u] >> 2;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TBY; ++j)
+#pragma unroll
+        for (int i = 0; i < kTileBlocksX; ++i) {
+            uint32_t v = best[j][i];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)v, m);
+                v = o < v ? o : v;
+            }
+            if (lane == 0) atomicMin(&best_lds[j * kTileBlocksX + i], v);
+        }
+    __syncthreads();
+    if (tid < NBLK) {                                                  // merge with the tile's other bands (me_decode_kernel reads the result)
+        const int bi = tid % kTileBlocksX, bj = tid / kTileBlocksX;
+        const int bx = tx * kTileBlocksX + bi, by = ty * TBY + bj;
+        if (bx < P.blocks_x && by < P.blocks_y && best_lds[tid] != 0xFFFFFFFFu) atomicMin(&P.keys[(size_t)by * P.blocks_x + bx], best_lds[tid]);
+    }
+}
+
+// keys -> (mv, cost) records: window position of the winner minus the block's offset inside its tile
+__global__ __launch_bounds__(256) void me_decode_kernel(const uint32_t *__restrict__ keys, x266_me_result_t *__restrict__ best,
+                                                        int blocks_x, int n_blocks, int tby, int range)
+{
+    const int blk = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (blk >= n_blocks) return;
+    const int bx = blk % blocks_x, by = blk / blocks_x;
+    const uint32_t key = keys[blk];
+    x266_me_result_t res;
+    res.mvx = (int16_t)((int)(key & 0xFFu) - 8 * (bx % kTileBlocksX) - range);          // window column -> dx
+    res.mvy = (int16_t)((int)((key >> 8) & 0xFFu) - 8 * (by % tby) - range);            // window row -> dy
+    res.cost = key >> 16;
+    best[blk] = res;
+}
+
+// ============================================================================
+// Variant 4 (default).  Variant 3's machinery with NO idle lanes in the main loop.
+//
+// A block's window is (2R+1)^2 candidates starting at a multiple of 8 in both directions.  Write
+// 2R+1 = 8F + rem (rem odd, 1 for R = 64).  Units are 8 columns x 8 rows of positions (two 8x4
+// transforms + the half exchange), on the 8-pixel grid of the blocks, so for ANY block the aligned part
+// of its window, [8i, 8i+8F) x [8j, 8j+8F), is exactly F x F whole units: a (unit, block) pair is either
+// entirely valid or not needed, and the scoring loop has no per-lane validity, no edge path.  Items pair
+// two vertically adjacent units (one coefficient fetch per 64 v_sad_u16); a block row whose window starts on
+// the odd unit of a pair takes single-unit paths at its first and last unit row instead of idle lanes.
+// The running minima live in LDS, one slot per (block, lane), updated with ds_min_u32 (issued beside the
+// VALU stream, 6 % of the LDS pipe): no registers, so the block-row loop is a real loop and the
+// 64-instruction scoring bodies exist once per block column and path.
+// The remaining rem columns and rem rows of every window ("+1" at R = 64: 257 of 16641 candidates) are
+// scored by narrow units -- 64 positions down one column, or along one row -- with per-lane validity.
+// Instruction count per 4K frame: 1.67e9 (variant 3) -> see profiles/r02_me_variants.txt.
+// ============================================================================
+template <int TBY, bool COSTS>
+__global__ __launch_bounds__(256, 3) void satd_search_kernel_v4(const MeParams P, const uint32_t *__restrict__ coef)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NBLK = kTileBlocksX * TBY;
+    const int R = P.range, span = 2 * R + 1;
+    const int F = span >> 3, rem = span - 8 * F;                        // window = 8F aligned + rem (odd) more
+    const int n_ucols = kTileBlocksX - 1 + F;                          // main unit columns
+    const int n_item_rows = (TBY - 1 + F + 1) >> 1;                    // main items: pairs of unit rows
+    const int n_rows = 8 * (TBY - 1) + span, n_cols = 8 * (kTileBlocksX - 1) + span;   // candidate positions of the tile
+    const int main_rows = 16 * n_item_rows;
+    const int win_rows = (main_rows > n_rows ? main_rows : n_rows) + 7;
+    uint32_t *slots = reinterpret_cast<uint32_t *>(smem);             // running minima: [block][lane], shared by the workgroup's waves
+    unsigned char *win = smem + NBLK * 256;
+
+    const int tid = threadIdx.x, lane = tid & 63, n_waves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, half = lane >> 5;
+    const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
+    const int x0 = tx * (8 * kTileBlocksX), y0 = ty * (8 * TBY);
+
+    {   // reference window, signed pixels
+        const int dwords_per_row = P.pitch >> 2;
+        const int total = win_rows * dwords_per_row;
+        for (int i = tid; i < total; i += blockDim.x) {
+            const int ry = i / dwords_per_row, cx = (i - ry * dwords_per_row) * 4;
+            int gy = y0 - R + ry;
+            gy = gy < -R ? -R : (gy > P.height + R - 1 ? P.height + R - 1 : gy);
+            const uint8_t *row = P.ref + (long long)gy * P.ref_stride;
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int gx = x0 - R + cx + b;
+                gx = gx < -R ? -R : (gx > P.width + R - 1 ? P.width + R - 1 : gx);
+                v |= (uint32_t)row[gx] << (8 * b);
+            }
+            reinterpret_cast<uint32_t *>(win)[i] = v ^ 0x80808080u;
+        }
+    }
+    for (int i = tid; i < NBLK * 64; i += blockDim.x) slots[i] = 0xFFFFFFFFu;
+    const HadamardOps H = make_hadamard_ops(lane);
+    __syncthreads();
+    uint32_t *my_slot = slots + lane;
+
+    int blocks_left_x = P.blocks_x - tx * kTileBlocksX, blocks_left_y = P.blocks_y - ty * TBY;
+    blocks_left_x = blocks_left_x > kTileBlocksX ? kTileBlocksX : blocks_left_x;
+    blocks_left_y = blocks_left_y > TBY ? TBY : blocks_left_y;
+    const uint32_t *__restrict__ tile_coef = coef + (size_t)blockIdx.x * (NBLK * 32);
+
+    // ---- item list: main (pairs of 8x8 units), then narrow columns, then narrow rows ---------------------
+    const int n_main = F > 0 ? n_item_rows * n_ucols : 0;
+    const int n_chunk_r = (n_rows + 63) >> 6, n_chunk_c = (n_cols + 63) >> 6;
+    const int n_ncol = kTileBlocksX * rem * n_chunk_r;                  // (block column, extra column, 64-row chunk)
+    const int n_nrow = F > 0 ? TBY * rem * n_chunk_c : 0;               // (block row, extra row, 64-column chunk); F = 0: the columns cover it all
+    const int n_items = n_main + n_ncol + n_nrow;
+
+    for (int item = wave; item < n_items; item += n_waves) {
+        if (item < n_main) {
+            // ================= main item: units (2m, ux) and (2m+1, ux) ====================================
+            const int m = item / n_ucols, ux = item - m * n_ucols;     // wave-uniform
+            const int col_in = n & 7, row_in = n >> 3;                 // 8 columns x 4 rows per transform
+            const int sh = (col_in & 3) * 8;
+            const int lane_row = (half ? 0 : 4) + row_in;              // after the exchange lanes 0-31 own rows 4..7 of the unit
+            uint32_t a[2][16], b[2][16], pid[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 8 * (2 * m + u);
+                v4i w0, w1;
+                load_window(win, P.pitch, r + row_in + 4 * half, 8 * ux + col_in, sh, w0, w1);
+                hadamard_pack(H, w0, w1, a[u]);
+                load_window(win, P.pitch, r + 4 + row_in + 4 * half, 8 * ux + col_in, sh, w0, w1);
+                hadamard_pack(H, w0, w1, b[u]);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(b[u][k], a[u][k], false, false);
+                    b[u][k] = (uint32_t)sw[0];
+                    a[u][k] = (uint32_t)sw[1];
+                }
+                pid[u] = (uint32_t)((r + lane_row) << 8 | (8 * ux + col_in));
+            }
+#pragma unroll 1
+            for (int j = 0; j < blocks_left_y; ++j) {
+                const bool va = (unsigned)(2 * m - j) < (unsigned)F, vb = (unsigned)(2 * m + 1 - j) < (unsigned)F;   // unit rows inside block row j's window
+                if (!va && !vb) continue;
+                const uint32_t *__restrict__ crow = tile_coef + j * (kTileBlocksX * 32);
+                if (va && vb) {
+#pragma unroll
+                    for (int i = 0; i < kTileBlocksX; ++i) {
+                        if ((unsigned)(ux - i) >= (unsigned)F || i >= blocks_left_x) continue;          // wave-uniform
+                        const uint32_t *__restrict__ c = crow + i * 32;
+                        uint32_t s0 = 2u, s1 = 2u;                     // the "+2" of (sum + 2) >> 2
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            s0 = __builtin_amdgcn_sad_u16(b[0][k], c[k], s0);
+                            s1 = __builtin_amdgcn_sad_u16(b[1][k], c[k], s1);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            s0 = __builtin_amdgcn_sad_u16(a[0][k], c[16 + k], s0);
+                            s1 = __builtin_amdgcn_sad_u16(a[1][k], c[16 + k], s1);
+                        }
+                        const uint32_t k0 = ((s0 & ~3u) << 14) | pid[0], k1 = ((s1 & ~3u) << 14) | pid[1];   // (s >> 2) << 16 | position
+                        atomicMin(my_slot + (j * kTileBlocksX + i) * 64, k0);           // ds_min_u32, no return value
+                        atomicMin(my_slot + (j * kTileBlocksX + i) * 64, k1);
+                        if (COSTS) {
+                            const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
+                            uint32_t *cm = P.costs + blk * (size_t)(span * span) + (size_t)(8 * ux + col_in - 8 * i);
+                            cm[(size_t)(16 * m + lane_row - 8 * j) * span] = s0 >> 2;
+                            cm[(size_t)(16 * m + 8 + lane_row - 8 * j) * span] = s1 >> 2;
+                        }
+                    }
+                } else {
+                    const int u = va ? 0 : 1;                          // only one unit row of the pair is inside the window
+#pragma unroll
+                    for (int i = 0; i < kTileBlocksX; ++i) {
+                        if ((unsigned)(ux - i) >= (unsigned)F || i >= blocks_left_x) continue;
+                        const uint32_t *__restrict__ c = crow + i * 32;
+                        uint32_t s0 = 2u;
+                        if (u == 0) {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) s0 = __builtin_amdgcn_sad_u16(b[0][k], c[k], s0);
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) s0 = __builtin_amdgcn_sad_u16(a[0][k], c[16 + k], s0);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) s0 = __builtin_amdgcn_sad_u16(b[1][k], c[k], s0);
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) s0 = __builtin_amdgcn_sad_u16(a[1][k], c[16 + k], s0);
+                        }
+                        const uint32_t k0 = ((s0 & ~3u) << 14) | (u == 0 ? pid[0] : pid[1]);
+                        atomicMin(my_slot + (j * kTileBlocksX + i) * 64, k0);
+                        if (COSTS) {
+                            const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
+                            P.costs[blk * (size_t)(span * span) + (size_t)(16 * m + 8 * u + lane_row - 8 * j) * span + (size_t)(8 * ux + col_in - 8 * i)] = s0 >> 2;
+                        }
+                    }
+                }
+            }
+        } else {
+            // ================= narrow item: 64 positions down one column or along one row =====================
+            int it = item - n_main;
+            const bool is_col = it < n_ncol;
+            int bi, bj, prow, pcol;                                    // the block column / row served; this lane's position
+            const int q = (half ? 0 : 32) + n;                         // after the exchange lanes 0-31 own positions 32..63 of the unit
+            if (is_col) {
+                const int chunk = it % n_chunk_r, rest = it / n_chunk_r;
+                const int c = rest % rem;
+                bi = rest / rem; bj = -1;
+                pcol = 8 * bi + 8 * F + c;
+                prow = 64 * chunk + q;
+            } else {
+                it -= n_ncol;
+                const int chunk = it % n_chunk_c, rest = it / n_chunk_c;
+                const int rr = rest % rem;
+                bj = rest / rem; bi = -1;
+                prow = 8 * bj + 8 * F + rr;
+                pcol = 64 * chunk + q;
+            }
+            // position of the lane BEFORE the exchange (transform 1: positions 0..31, transform 2: 32..63), clamped for the loads
+            uint32_t a[16], b[16];
+            {
+                int r1 = is_col ? prow - q + n : prow, c1 = is_col ? pcol : pcol - q + n;
+                int r2 = is_col ? r1 + 32 : r1, c2 = is_col ? c1 : c1 + 32;
+                r1 = r1 > n_rows - 1 ? n_rows - 1 : r1; r2 = r2 > n_rows - 1 ? n_rows - 1 : r2;
+                c1 = c1 > n_cols - 1 ? n_cols - 1 : c1; c2 = c2 > n_cols - 1 ? n_cols - 1 : c2;
+                v4i w0, w1;
+                load_window(win, P.pitch, r1 + 4 * half, c1, (c1 & 3) * 8, w0, w1);
+                hadamard_pack(H, w0, w1, a);
+                load_window(win, P.pitch, r2 + 4 * half, c2, (c2 & 3) * 8, w0, w1);
+                hadamard_pack(H, w0, w1, b);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(b[k], a[k], false, false);
+                    b[k] = (uint32_t)sw[0];
+                    a[k] = (uint32_t)sw[1];
+                }
+            }
+            const uint32_t pid = (uint32_t)(prow << 8 | pcol);
+            const int j_lo = is_col ? 0 : bj, j_hi = is_col ? blocks_left_y : (bj < blocks_left_y ? bj + 1 : bj);
+            const int i_lo = is_col ? bi : 0, i_hi = is_col ? (bi < blocks_left_x ? bi + 1 : bi) : blocks_left_x;
+            const int unit_r0 = __builtin_amdgcn_readfirstlane(is_col ? prow - q : prow);
+            const int unit_c0 = __builtin_amdgcn_readfirstlane(is_col ? pcol : pcol - q);
+#pragma unroll 1
+            for (int j = j_lo; j < j_hi; ++j) {
+                if (is_col && (unit_r0 + 63 < 8 * j || unit_r0 >= 8 * j + span)) continue;            // no row of the unit in the window
+#pragma unroll 1
+                for (int i = i_lo; i < i_hi; ++i) {
+                    if (!is_col && (unit_c0 + 63 < 8 * i || unit_c0 >= 8 * i + span)) continue;
+                    const uint32_t *__restrict__ c = tile_coef + (j * kTileBlocksX + i) * 32;
+                    uint32_t s0 = 2u;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) s0 = __builtin_amdgcn_sad_u16(b[k], c[k], s0);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) s0 = __builtin_amdgcn_sad_u16(a[k], c[16 + k], s0);
+                    const int dyi = prow - 8 * j, dxi = pcol - 8 * i;
+                    const bool ok = (unsigned)dyi < (unsigned)span && (unsigned)dxi < (unsigned)span;
+                    const uint32_t key = ((s0 & ~3u) << 14) | pid;
+                    if (ok) atomicMin(my_slot + (j * kTileBlocksX + i) * 64, key);
+                    if (COSTS && ok) {
+                        const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
+                        P.costs[blk * (size_t)(span * span) + (size_t)dyi * span + (size_t)dxi] = s0 >> 2;
+                    }
+                }
+            }
+        }
+    }
+
+    __syncthreads();
+    for (int blk = wave; blk < NBLK; blk += n_waves) {                 // minimum over the 64 lane slots of a block
+        uint32_t v = slots[blk * 64 + lane];
+#pragma unroll
+        for (int mm = 32; mm >= 1; mm >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)v, mm);
+            v = o < v ? o : v;
+        }
+        const int bi = blk % kTileBlocksX, bj = blk / kTileBlocksX;
+        const int bx = tx * kTileBlocksX + bi, by = ty * TBY + bj;
+        if (lane == 0 && bx < P.blocks_x && by < P.blocks_y) {
+            x266_me_result_t res;
+            res.mvx = (int16_t)((int)(v & 0xFFu) - 8 * bi - R);            // window column -> dx
+            res.mvy = (int16_t)((int)((v >> 8) & 0xFFu) - 8 * bj - R);     // window row -> dy
+            res.cost = v >> 16;
+            P.best[(size_t)by * P.blocks_x + bx] = res;
+        }
+    }
+}
+
+// ============================================================================
 // Full search with the cheaper metric: cost = sum |cur - ref| over the 8x8 block, i.e.
 // sad() of riscv/programs/benchmarks/sad/sad.c:28-39 at n = 8, same harness (raster order, first
 // minimum wins) as the SATD search above.
@@ -578,9 +1015,11 @@ __global__ __launch_bounds__(256) void sad_search_kernel(const MeParams P)
 
 hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
                               int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
-                              int tile_rows, int variant, int row_pairs, uint32_t *d_coef_scratch, hipStream_t stream)
+                              int tile_rows, int variant, int row_pairs, uint32_t *d_coef_scratch, int cu_count, int wg_threads,
+                              int me_splits, hipStream_t stream)
 {
     MeParams P;
+    P.keys = nullptr; P.splits = 1;
     P.cur = d_cur; P.ref = d_ref; P.cur_stride = cur_stride; P.ref_stride = ref_stride;
     P.width = width; P.height = height; P.range = range;
     P.blocks_x = width / 8; P.blocks_y = height / 8;
@@ -593,18 +1032,63 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
     P.pitch = 32 * P.n_groups + 12;
     P.best = d_best; P.costs = d_costs;
     dim3 grid((unsigned)(P.tiles_x * tiles_y)), block(256);
-    if (variant == 2) {
+    if (variant == 2 || variant == 3 || variant == 4) {
         const int n_blocks = P.blocks_x * P.blocks_y;
         const int groups = (n_blocks + 31) / 32;
+        uint32_t *d_keys = variant == 3 ? d_coef_scratch + (size_t)P.tiles_x * tiles_y * kTileBlocksX * tby * 32 : nullptr;   // behind the table
         hipLaunchKernelGGL(me_coef_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, stream, d_cur, cur_stride,
-                           P.blocks_x, n_blocks, P.tiles_x, tby, d_coef_scratch);
+                           P.blocks_x, n_blocks, P.tiles_x, tby, d_coef_scratch, d_keys);
         {
             const hipError_t e0 = hipGetLastError();
             if (e0 != hipSuccess) return e0;
         }
         const int U = row_pairs == 1 ? 1 : (row_pairs == 3 ? 3 : 2);
-        const size_t lds = 128 + (size_t)(P.n_rows + 7 + 2 * U) * P.pitch;   // the last strip may be partly empty
         const uint32_t *cf = d_coef_scratch;
+        if (variant == 4) {
+            const int F = span >> 3;
+            const int n_ucols = kTileBlocksX - 1 + F;
+            const int n_item_rows = (tby - 1 + F + 1) >> 1;
+            const int main_rows = 16 * n_item_rows;
+            P.pitch = 8 * n_ucols + 20;                                  // last position column + 7 pixels + dword alignment
+            const size_t lds4 = (size_t)kTileBlocksX * tby * 256 + (size_t)((main_rows > P.n_rows ? main_rows : P.n_rows) + 7) * P.pitch;
+            dim3 block4((unsigned)(wg_threads ? wg_threads : 256));
+#define X266_ME4(T) do { if (d_costs) hipLaunchKernelGGL((satd_search_kernel_v4<T, true>), grid, block4, lds4, stream, P, cf); \
+                         else         hipLaunchKernelGGL((satd_search_kernel_v4<T, false>), grid, block4, lds4, stream, P, cf); } while (0)
+            if (tby == 4) X266_ME4(4); else if (tby == 1) X266_ME4(1); else X266_ME4(2);
+#undef X266_ME4
+            return hipGetLastError();
+        }
+        if (variant == 3) {
+            const int U3 = U == 1 ? 1 : 2;
+            P.n_groups = (8 * (kTileBlocksX - 1) + span + 15) / 16;      // 16-column groups
+            P.pitch = 16 * P.n_groups + 12;
+            const int n_items_y = ((P.n_rows + 3) / 4 + U3 - 1) / U3;
+            // Workgroups per tile ("me_splits" bands of candidate rows, merged with atomicMin): finer dispatch granularity.
+            const long long tiles = (long long)P.tiles_x * tiles_y;
+            (void)cu_count;
+            int splits = 1;
+            if (me_splits > 0) splits = me_splits;            // measured: no gain on MI355X (profiles/r02_me_variants.txt); kept for A/B
+            if (splits > n_items_y) splits = n_items_y;
+            P.splits = splits;
+            P.keys = d_keys;
+            const int band_items = (n_items_y + splits - 1) / splits;
+            const size_t lds3 = 128 + (size_t)(4 * U3 * band_items + 7) * P.pitch;
+            grid = dim3((unsigned)(tiles * splits));
+            dim3 block3((unsigned)(wg_threads ? wg_threads : 256));
+#define X266_ME3(T, UU) do { if (d_costs) hipLaunchKernelGGL((satd_search_kernel_v3<T, UU, true>), grid, block3, lds3, stream, P, cf); \
+                             else         hipLaunchKernelGGL((satd_search_kernel_v3<T, UU, false>), grid, block3, lds3, stream, P, cf); } while (0)
+            if (tby == 4)      { if (U3 == 1) X266_ME3(4, 1); else X266_ME3(4, 2); }
+            else if (tby == 1) { if (U3 == 1) X266_ME3(1, 1); else X266_ME3(1, 2); }
+            else               { if (U3 == 1) X266_ME3(2, 1); else X266_ME3(2, 2); }
+#undef X266_ME3
+            {
+                const hipError_t e1 = hipGetLastError();
+                if (e1 != hipSuccess) return e1;
+            }
+            hipLaunchKernelGGL(me_decode_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, stream, d_keys, d_best, P.blocks_x, n_blocks, tby, range);
+            return hipGetLastError();
+        }
+        const size_t lds = 128 + (size_t)(P.n_rows + 7 + 2 * U) * P.pitch;   // the last strip may be partly empty
 #define X266_ME(T, UU) do { if (d_costs) hipLaunchKernelGGL((satd_search_kernel_v2<T, UU, true>), grid, block, lds, stream, P, cf); \
                             else         hipLaunchKernelGGL((satd_search_kernel_v2<T, UU, false>), grid, block, lds, stream, P, cf); } while (0)
         if (tby == 4)      { if (U == 1) X266_ME(4, 1); else if (U == 2) X266_ME(4, 2); else X266_ME(4, 3); }

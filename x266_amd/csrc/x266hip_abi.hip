@@ -44,7 +44,9 @@ struct x266hip_ctx {
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
     int me_tile_rows = 4;                           // block rows per ME tile (1, 2 or 4)
     int me_row_pairs = 2;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
-    int me_variant = 2;                             // 1 = LDS coefficients, 2 = scalar coefficients (me_kernels.hip)
+    int me_variant = 4;                             // 1 = LDS coefficients, 2 = scalar coefficients, 3 = scalar coefficients, 16x4 units, position keys (me_kernels.hip)
+    int me_wg_threads = 0;                          // variant 3: workgroup size (0 = 256)
+    int me_splits = 0;                              // variant 3: workgroups per tile (0 = chosen so that the last round of workgroups is full)
     // variant 2 scratch (128 B per 8x8 block of the current frame), ONE PER STREAM: searches enqueued on
     // different streams never share it, and a buffer that a recorded graph may reference is never freed
     // before the context is (outgrown buffers are retired, not released)
@@ -303,7 +305,9 @@ static const OptionDesc kOptions[] = {
     {"dct32_inv_lds_pad_bytes", &x266hip_ctx::lds_pad_inv, 0, 160 * 1024, 1},
     {"satd_lds_pad_bytes", &x266hip_ctx::lds_pad_satd, 0, 160 * 1024, 1},
     {"me_tile_rows", &x266hip_ctx::me_tile_rows, 1, 4, 1},
-    {"me_variant", &x266hip_ctx::me_variant, 1, 2, 1},
+    {"me_variant", &x266hip_ctx::me_variant, 1, 4, 1},
+    {"me_wg_threads", &x266hip_ctx::me_wg_threads, 0, 256, 64},
+    {"me_splits", &x266hip_ctx::me_splits, 0, 8, 1},
     {"me_row_pairs", &x266hip_ctx::me_row_pairs, 1, 3, 1},
     {"diag_passthrough", &x266hip_ctx::passthrough, 0, 1, 1},
     {"diag_tr32_simple", &x266hip_ctx::tr32_simple, 0, 1, 1},
@@ -583,9 +587,10 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
     if (((uintptr_t)d_best & 7u) || ((uintptr_t)d_costs & 3u)) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: unaligned output");
     X_DEV(ctx);
     // tile-major table: whole search tiles (8 x up to 4 blocks), partial edge tiles padded (tile heights 1, 2, 4, 8 all fit)
-    const size_t need = (size_t)((width / 8 + 7) / 8) * 8 * (size_t)((height / 8 + 7) / 8) * 8 * 128;
+    const size_t need = (size_t)((width / 8 + 7) / 8) * 8 * (size_t)((height / 8 + 7) / 8) * 8 * 128      // coefficient table
+                        + (size_t)(width / 8) * (size_t)(height / 8) * 4;                                     // variant 3: one key per block
     uint32_t *d_me_coef = nullptr;
-    if (ctx->me_variant == 2) {
+    if (ctx->me_variant >= 2) {
         x266hip_ctx::MeScratch *slot = nullptr;
         for (x266hip_ctx::MeScratch &m : ctx->me_scratch)
             if (m.stream == (hipStream_t)stream) slot = &m;
@@ -604,7 +609,8 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
     }
     (void)hipGetLastError();
     hipError_t e = launch_satd_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
-                                      d_best, d_costs, ctx->me_tile_rows, ctx->me_variant, ctx->me_row_pairs, d_me_coef, (hipStream_t)stream);
+                                      d_best, d_costs, ctx->me_tile_rows, ctx->me_variant, ctx->me_row_pairs, d_me_coef, ctx->prop.multiProcessorCount,
+                                      ctx->me_wg_threads, ctx->me_splits, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "search launch", e);
     return X266HIP_OK;
 }
