@@ -30,7 +30,7 @@ def timed(fn, reps=20):
 
 ref = None
 if what in ("satd", "all"):
-    for var, tr, rp, wg, sp in ((2, 4, 2, 0, 0), (3, 4, 2, 0, 1), (4, 4, 2, 0, 0), (4, 2, 2, 0, 0), (4, 4, 2, 192, 0), (4, 4, 2, 0, 0)):
+    for var, tr, rp, wg, sp in ((3, 4, 2, 0, 1), (4, 4, 2, 0, 0), (4, 4, 2, 512, 0), (4, 4, 2, 384, 0), (4, 8, 2, 384, 0), (4, 8, 2, 512, 0), (4, 8, 2, 256, 0), (4, 4, 2, 0, 0)):
         cd.set_option("me_tile_rows", tr); cd.set_option("me_variant", var); cd.set_option("me_row_pairs", rp); cd.set_option("me_wg_threads", wg); cd.set_option("me_splits", sp)
         fn = lambda: cd.satd_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr())
         med, mn = timed(fn)

@@ -639,8 +639,8 @@ __global__ __launch_bounds__(256) void me_decode_kernel(const uint32_t *__restri
 // scored by narrow units -- 64 positions down one column, or along one row -- with per-lane validity.
 // Instruction count per 4K frame: 1.67e9 (variant 3) -> see profiles/r02_me_variants.txt.
 // ============================================================================
-template <int TBY, bool COSTS>
-__global__ __launch_bounds__(256, 3) void satd_search_kernel_v4(const MeParams P, const uint32_t *__restrict__ coef)
+template <int TBY, bool COSTS, int WG, int WPS>
+__global__ __launch_bounds__(WG, WPS) void satd_search_kernel_v4(const MeParams P, const uint32_t *__restrict__ coef)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NBLK = kTileBlocksX * TBY;
@@ -1024,7 +1024,7 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
     P.width = width; P.height = height; P.range = range;
     P.blocks_x = width / 8; P.blocks_y = height / 8;
     P.tiles_x = (P.blocks_x + kTileBlocksX - 1) / kTileBlocksX;
-    const int tby = tile_rows == 4 ? 4 : (tile_rows == 1 ? 1 : 2);
+    const int tby = (tile_rows == 8 && variant == 4) ? 8 : (tile_rows >= 4 ? 4 : (tile_rows == 1 ? 1 : 2));
     const int tiles_y = (P.blocks_y + tby - 1) / tby;
     const int span = 2 * range + 1;
     P.n_groups = (8 * (kTileBlocksX - 1) + span + 31) / 32;
@@ -1051,10 +1051,14 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
             const int main_rows = 16 * n_item_rows;
             P.pitch = 8 * n_ucols + 20;                                  // last position column + 7 pixels + dword alignment
             const size_t lds4 = (size_t)kTileBlocksX * tby * 256 + (size_t)((main_rows > P.n_rows ? main_rows : P.n_rows) + 7) * P.pitch;
-            dim3 block4((unsigned)(wg_threads ? wg_threads : 256));
-#define X266_ME4(T) do { if (d_costs) hipLaunchKernelGGL((satd_search_kernel_v4<T, true>), grid, block4, lds4, stream, P, cf); \
-                         else         hipLaunchKernelGGL((satd_search_kernel_v4<T, false>), grid, block4, lds4, stream, P, cf); } while (0)
-            if (tby == 4) X266_ME4(4); else if (tby == 1) X266_ME4(1); else X266_ME4(2);
+            const int wg4 = wg_threads ? wg_threads : 512;                // 8-wave workgroups, 4 waves per SIMD (profiles/r02_me_variants.txt)
+            dim3 block4((unsigned)wg4);
+#define X266_ME4W(T, WG, WPS) do { if (d_costs) hipLaunchKernelGGL((satd_search_kernel_v4<T, true, WG, WPS>), grid, block4, lds4, stream, P, cf); \
+                                   else         hipLaunchKernelGGL((satd_search_kernel_v4<T, false, WG, WPS>), grid, block4, lds4, stream, P, cf); } while (0)
+#define X266_ME4(T) do { if (wg4 == 512) X266_ME4W(T, 512, 4); else if (wg4 == 384) X266_ME4W(T, 384, 3); else X266_ME4W(T, 256, 3); } while (0)
+            if (wg4 != 256 && wg4 != 384 && wg4 != 512) return hipErrorInvalidValue;
+            if (tby == 8) X266_ME4(8); else if (tby == 4) X266_ME4(4); else if (tby == 1) X266_ME4(1); else X266_ME4(2);
+#undef X266_ME4W
 #undef X266_ME4
             return hipGetLastError();
         }
@@ -1117,7 +1121,7 @@ hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const u
     P.width = width; P.height = height; P.range = range;
     P.blocks_x = width / 8; P.blocks_y = height / 8;
     P.tiles_x = (P.blocks_x + kTileBlocksX - 1) / kTileBlocksX;
-    const int tby = tile_rows == 4 ? 4 : (tile_rows == 1 ? 1 : 2);
+    const int tby = tile_rows >= 4 ? 4 : (tile_rows == 1 ? 1 : 2);
     const int tiles_y = (P.blocks_y + tby - 1) / tby;
     const int span = 2 * range + 1;
     P.n_groups = (8 * (kTileBlocksX - 1) + span + 63) / 64;           // 64-column groups (lane = column)

@@ -42,10 +42,10 @@ struct x266hip_ctx {
     int wg_threads = 256;
     int satd_wg_threads = 128;                      // SATD batch (staged): two-wave workgroups, 2 groups per wave (profiles/r01_satd_staged_nt.txt)
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
-    int me_tile_rows = 4;                           // block rows per ME tile (1, 2 or 4)
+    int me_tile_rows = 8;                           // block rows per ME tile (1, 2, 4; 8 for variant 4 -- other variants and the SAD search use min(this, 4))
     int me_row_pairs = 2;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
     int me_variant = 4;                             // 1 = LDS coefficients, 2 = scalar coefficients, 3 = scalar coefficients, 16x4 units, position keys (me_kernels.hip)
-    int me_wg_threads = 0;                          // variant 3: workgroup size (0 = 256)
+    int me_wg_threads = 0;                          // variants 3, 4: workgroup size (0 = 256 for variant 3, 512 for variant 4: two 8-wave workgroups per CU)
     int me_splits = 0;                              // variant 3: workgroups per tile (0 = chosen so that the last round of workgroups is full)
     // variant 2 scratch (128 B per 8x8 block of the current frame), ONE PER STREAM: searches enqueued on
     // different streams never share it, and a buffer that a recorded graph may reference is never freed
@@ -304,9 +304,9 @@ static const OptionDesc kOptions[] = {
     {"dct32_lds_pad_bytes", &x266hip_ctx::lds_pad_dct, 0, 160 * 1024, 1},
     {"dct32_inv_lds_pad_bytes", &x266hip_ctx::lds_pad_inv, 0, 160 * 1024, 1},
     {"satd_lds_pad_bytes", &x266hip_ctx::lds_pad_satd, 0, 160 * 1024, 1},
-    {"me_tile_rows", &x266hip_ctx::me_tile_rows, 1, 4, 1},
+    {"me_tile_rows", &x266hip_ctx::me_tile_rows, 1, 8, 1},
     {"me_variant", &x266hip_ctx::me_variant, 1, 4, 1},
-    {"me_wg_threads", &x266hip_ctx::me_wg_threads, 0, 256, 64},
+    {"me_wg_threads", &x266hip_ctx::me_wg_threads, 0, 512, 64},
     {"me_splits", &x266hip_ctx::me_splits, 0, 8, 1},
     {"me_row_pairs", &x266hip_ctx::me_row_pairs, 1, 3, 1},
     {"diag_passthrough", &x266hip_ctx::passthrough, 0, 1, 1},
