@@ -321,52 +321,91 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
 // once: tile t carries its class in tile_class[t] (type * 4 + log2N - 2) and sits at sample offset tile_offsets[t]
 // (NULL: t * 1024), the wave fetches that class's operand images (L1/L2-resident, 7 x 3.5 KiB) and runs the same
 // staged pipeline.  Consecutive tiles are consecutive memory, so the access stream is that of a contiguous batch.
-struct TileClassOps {
-    const DctOps *p[16];         // index = type * 4 + log2N - 2, type 0..3; [3] = (DCT-II, 32)
-};
+// The operand images of all sixteen classes come from ONE structure-of-arrays table (TileOpsSoA, x266_tables.hpp):
+// dense 1 KiB runs per class.  A wave walks `tiles_per_wave` consecutive tiles and issues the NEXT tile's class byte
+// and data loads before the current tile's arithmetic, so the class -> images -> compute chain of one tile runs
+// under the memory latency of the next.
+// class byte of tile t through the scalar cache: the aligned dword that holds it (t is wave-uniform, so this is an
+// s_load_dword and the class lands in an SGPR without a vector-memory round trip), for any alignment of the table
+__device__ __forceinline__ int tile_class_of(const uint8_t *__restrict__ tile_class, size_t t)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(tile_class) + t;
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    return (int)((w >> (8 * (unsigned)(a & 3))) & 15u);
+}
+
+__device__ __forceinline__ LaneConsts load_tile_consts(const TileOpsSoA *__restrict__ T, int cls, int lane)
+{
+    LaneConsts k;
+    k.p1 = *reinterpret_cast<const v4i *>(T->p1[cls][lane]);
+    k.p2 = *reinterpret_cast<const v4i *>(T->p2[cls][lane]);
+    k.tr = v4i{0, 0, 0, 0};
+    k.c1 = T->c12[cls][lane][0];
+    k.c2 = T->c12[cls][lane][1];
+    return k;
+}
 
 template <bool INVERSE, bool NT>
 __global__ __launch_bounds__(256) void tr_tiles_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t n_tiles,
                                                        const uint32_t *__restrict__ tile_offsets,
-                                                       const uint8_t *__restrict__ tile_class, const TileClassOps ops)
+                                                       const uint8_t *__restrict__ tile_class, const TileOpsSoA *__restrict__ T,
+                                                       unsigned tiles_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
     unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
     const int lane = threadIdx.x & 63;
-    const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (t >= n_tiles) return;
-    const int cls = __builtin_amdgcn_readfirstlane((int)tile_class[t]) & 15;
-    const size_t base = (tile_offsets ? (size_t)tile_offsets[t] : t * 1024) * 2;
-    const char *src = reinterpret_cast<const char *>(in) + base + lane * 16;
-    const v4i g0 = load16<NT>(src), g1 = load16<NT>(src + 1024);
-    const DctOps *__restrict__ o = ops.p[cls];
-    const LaneConsts k = load_consts(o, lane);
-    *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
-    *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
-    __builtin_amdgcn_wave_barrier();
-    if (INVERSE) {
-        const v16i c2r = load_c2r(o, lane >> 5);
-        switch (cls & 3) {                                              // wave-uniform
-        case 0: inv_tile_in_slot<2>(slot, lane, k, c2r); break;
-        case 1: inv_tile_in_slot<3>(slot, lane, k, c2r); break;
-        case 2: inv_tile_in_slot<4>(slot, lane, k, c2r); break;
-        default: inv_tile_in_slot<5>(slot, lane, k, c2r); break;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    size_t t = wave * tiles_per_wave;
+    const size_t t_end = t + tiles_per_wave < n_tiles ? t + tiles_per_wave : n_tiles;
+    if (t >= t_end) return;
+    // prologue: first tile's class, position and data
+    t = (size_t)__builtin_amdgcn_readfirstlane((int)(t & 0xFFFFFFFFu)) | (t & ~(size_t)0xFFFFFFFFu);   // provably wave-uniform
+    int cls = tile_class_of(tile_class, t);
+    size_t base = (tile_offsets ? (size_t)tile_offsets[t] : t * 1024) * 2;
+    v4i g0 = load16<NT>(reinterpret_cast<const char *>(in) + base + lane * 16);
+    v4i g1 = load16<NT>(reinterpret_cast<const char *>(in) + base + 1024 + lane * 16);
+    for (; t < t_end; ++t) {
+        const LaneConsts k = load_tile_consts(T, cls, lane);
+        v16i c2r;
+        if (INVERSE) {
+            const int *__restrict__ s0 = T->c2r[cls][0], *__restrict__ s1 = T->c2r[cls][1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c2r[r] = (lane >> 5) ? s1[r] : s0[r];
         }
-    } else {
-        switch (cls & 3) {
-        case 0: fwd_tile_in_slot<2>(slot, lane, k); break;
-        case 1: fwd_tile_in_slot<3>(slot, lane, k); break;
-        case 2: fwd_tile_in_slot<4>(slot, lane, k); break;
-        default: fwd_tile_in_slot<5>(slot, lane, k); break;
+        const int cur_cls = cls;
+        const size_t cur_base = base;
+        *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
+        *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
+        if (t + 1 < t_end) {                                            // next tile: loads in flight during this tile's passes
+            cls = tile_class_of(tile_class, t + 1);
+            base = (tile_offsets ? (size_t)tile_offsets[t + 1] : (t + 1) * 1024) * 2;
+            g0 = load16<NT>(reinterpret_cast<const char *>(in) + base + lane * 16);
+            g1 = load16<NT>(reinterpret_cast<const char *>(in) + base + 1024 + lane * 16);
         }
+        __builtin_amdgcn_wave_barrier();
+        if (INVERSE) {
+            switch (cur_cls & 3) {                                          // wave-uniform
+            case 0: inv_tile_in_slot<2>(slot, lane, k, c2r); break;
+            case 1: inv_tile_in_slot<3>(slot, lane, k, c2r); break;
+            case 2: inv_tile_in_slot<4>(slot, lane, k, c2r); break;
+            default: inv_tile_in_slot<5>(slot, lane, k, c2r); break;
+            }
+        } else {
+            switch (cur_cls & 3) {
+            case 0: fwd_tile_in_slot<2>(slot, lane, k); break;
+            case 1: fwd_tile_in_slot<3>(slot, lane, k); break;
+            case 2: fwd_tile_in_slot<4>(slot, lane, k); break;
+            default: fwd_tile_in_slot<5>(slot, lane, k); break;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
+        const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
+        __builtin_amdgcn_wave_barrier();
+        char *dst = reinterpret_cast<char *>(out) + cur_base + lane * 16;
+        store16m<NT ? 2 : 0>(dst, s0);
+        store16m<NT ? 2 : 0>(dst + 1024, s1);
     }
-    __builtin_amdgcn_wave_barrier();
-    const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
-    const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
-    __builtin_amdgcn_wave_barrier();
-    char *dst = reinterpret_cast<char *>(out) + base + lane * 16;
-    store16m<NT ? 2 : 0>(dst, s0);
-    store16m<NT ? 2 : 0>(dst + 1024, s1);
 }
 
 }  // namespace
@@ -436,18 +475,18 @@ hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d
 namespace x266 {
 
 hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles, const uint32_t *d_tile_offsets,
-                                  const uint8_t *d_tile_class, const DctOps *const class_ops[16], const LaunchCfg &cfg, hipStream_t stream)
+                                  const uint8_t *d_tile_class, const TileOpsSoA *d_class_ops, const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
-    TileClassOps ops;
-    for (int i = 0; i < 16; ++i) ops.p[i] = class_ops[i];
+    const unsigned tpw = units_per_wave_for(cfg, n_tiles);
+    const size_t waves = (n_tiles + tpw - 1) / tpw;
     const unsigned tpb = (unsigned)cfg.wg_threads;
-    const size_t wpw = tpb / 64, wgs = (n_tiles + wpw - 1) / wpw;
+    const size_t wpw = tpb / 64, wgs = (waves + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
     dim3 grid((unsigned)wgs), block(tpb);
     const bool nt = !d_tile_offsets && (cfg.nontemporal & 3);           // streaming hints only when the tiles are the whole buffer in order
-#define X266_TT(INV, NTV) hipLaunchKernelGGL((tr_tiles_kernel<INV, NTV>), grid, block, lds, stream, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, ops)
+#define X266_TT(INV, NTV) hipLaunchKernelGGL((tr_tiles_kernel<INV, NTV>), grid, block, lds, stream, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, d_class_ops, tpw)
     if (inverse) { if (nt) X266_TT(true, true); else X266_TT(true, false); }
     else         { if (nt) X266_TT(false, true); else X266_TT(false, false); }
 #undef X266_TT

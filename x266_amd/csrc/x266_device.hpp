@@ -66,6 +66,7 @@ struct LaunchCfg {
 };
 
 struct DctOps;
+struct TileOpsSoA;
 
 // Units (blocks, groups, tiles) one wave loops over: the configured count, reduced on small batches
 // until the launch has at least two full rounds of resident waves (about 40 per CU).
@@ -89,7 +90,7 @@ hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const u
                              int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
                              int tile_rows, hipStream_t stream);
 hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles, const uint32_t *d_tile_offsets,
-                                  const uint8_t *d_tile_class, const DctOps *const class_ops[16], const LaunchCfg &cfg, hipStream_t stream);
+                                  const uint8_t *d_tile_class, const TileOpsSoA *d_class_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_dct32_butterfly(const int16_t *d_in, int16_t *d_out, size_t n_blocks, hipStream_t stream);
 hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,
                                const DctOps *d_fwd_ops, const DctOps *d_inv_lds_ops, const LaunchCfg &cfg, hipStream_t stream);

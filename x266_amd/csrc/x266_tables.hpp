@@ -65,6 +65,16 @@ struct DctOps {
     int32_t    c2r[64][16];   // inverse pass-2 constants, per lane and accumulator reg
 };
 
+// Operand images of ALL sixteen tile classes for the mixed-class tile kernel (xTransformTilesDev), structure of
+// arrays: a wave's fetch of one class is three dense runs (1 KiB + 1 KiB + 512 B = 20 cache lines) instead of the
+// 64-byte-strided records above (128 line touches), and the seven classes of a VVC CTU (17.5 KiB) stay L1-resident.
+struct TileOpsSoA {
+    uint32_t p1[16][64][4];
+    uint32_t p2[16][64][4];
+    int32_t  c12[16][64][2];
+    int32_t  c2r[16][2][16];   // inverse: pass-B constants of lane half 0 / 1
+};
+
 inline uint32_t pack4(const int8_t *b)
 {
     uint32_t w;
@@ -259,6 +269,17 @@ inline void build_inv_ops_general(DctOps &o, const Matrix32 &ma, const Matrix32 
         o.lane[l].pad[0] = o.lane[l].pad[1] = 0;
         for (int r = 0; r < 16; ++r) o.c2r[l][r] = (1 << 11) + 128 * colsum_b[16 * h + r];
     }
+}
+
+inline void tile_soa_set(TileOpsSoA &t, int cls, const DctOps &o)
+{
+    for (int l = 0; l < 64; ++l) {
+        for (int q = 0; q < 4; ++q) { t.p1[cls][l][q] = o.lane[l].p1[q]; t.p2[cls][l][q] = o.lane[l].p2[q]; }
+        t.c12[cls][l][0] = o.lane[l].c1;
+        t.c12[cls][l][1] = o.lane[l].c2;
+    }
+    for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) t.c2r[cls][h][r] = o.c2r[32 * h][r];
 }
 
 // transform type codes of the API: 0 DCT-II both ways, 1 DST-VII both ways, 2 horizontal DST-VII + vertical DCT-II,

@@ -29,6 +29,9 @@ struct x266hip_ctx {
     static constexpr int kTypes = 4;                // DCT-II, DST-VII, and the two mixed horizontal / vertical pairs
     DctOps *d_tr[kTypes][3] = {};                   // [type][log2N - 2], N = 4, 8, 16
     DctOps *d_tr_inv[kTypes][3] = {};
+    TileOpsSoA *d_tile_fwd = nullptr, *d_tile_inv = nullptr;   // all sixteen classes, structure of arrays (xTransformTilesDev)
+    int tile_lds_per_wave = 4096;                   // mixed-class tile kernel: LDS charged per wave (resident-wave cap)
+    int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (next tile's loads issued before this tile's arithmetic)
     // options
     int wgs_per_cu_dct = 8;
     int wgs_per_cu_inv = 5;
@@ -196,11 +199,13 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
         return X266HIP_EDEVICE;
     }
     DctOps *h = new (std::nothrow) DctOps;
-    bool ok = h != nullptr;
+    TileOpsSoA *soa_f = new (std::nothrow) TileOpsSoA(), *soa_i = new (std::nothrow) TileOpsSoA();
+    bool ok = h != nullptr && soa_f != nullptr && soa_i != nullptr;
     if (ok) ok = hipMalloc((void **)&ctx->d_fwd, sizeof(DctOps)) == hipSuccess &&
                  hipMalloc((void **)&ctx->d_inv, sizeof(DctOps)) == hipSuccess;
     if (ok) {
         build_fwd_ops(*h);
+        for (int type = 0; type < x266hip_ctx::kTypes; ++type) tile_soa_set(*soa_f, type * 4 + 3, *h);   // size 32 exists for DCT-II only; the other slots stay valid
         ok = hipMemcpy(ctx->d_fwd, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok) {
@@ -209,6 +214,7 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
     }
     if (ok) {
         build_inv_ops(*h, true);
+        for (int type = 0; type < x266hip_ctx::kTypes; ++type) tile_soa_set(*soa_i, type * 4 + 3, *h);
         ok = hipMalloc((void **)&ctx->d_inv_lds, sizeof(DctOps)) == hipSuccess &&
              hipMemcpy(ctx->d_inv_lds, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
     }
@@ -217,14 +223,22 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
             const int n = 4 << l;
             const Matrix32 mh = make_transform_matrix(transform_htype(type), n), mv = make_transform_matrix(transform_vtype(type), n);
             build_fwd_ops_general(*h, mh, mv, transform_shift1(n), transform_shift2(n));
+            tile_soa_set(*soa_f, type * 4 + l, *h);
             ok = hipMalloc((void **)&ctx->d_tr[type][l], sizeof(DctOps)) == hipSuccess &&
                  hipMemcpy(ctx->d_tr[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
             if (!ok) break;
             build_inv_ops_general(*h, mv, mh);
+            tile_soa_set(*soa_i, type * 4 + l, *h);
             ok = hipMalloc((void **)&ctx->d_tr_inv[type][l], sizeof(DctOps)) == hipSuccess &&
                  hipMemcpy(ctx->d_tr_inv[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
         }
+    if (ok) ok = hipMalloc((void **)&ctx->d_tile_fwd, sizeof(TileOpsSoA)) == hipSuccess &&
+                 hipMalloc((void **)&ctx->d_tile_inv, sizeof(TileOpsSoA)) == hipSuccess &&
+                 hipMemcpy(ctx->d_tile_fwd, soa_f, sizeof(TileOpsSoA), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(ctx->d_tile_inv, soa_i, sizeof(TileOpsSoA), hipMemcpyHostToDevice) == hipSuccess;
     delete h;
+    delete soa_f;
+    delete soa_i;
     if (!ok) {
         xHipCodecFree(ctx);
         return X266HIP_ENOMEM;
@@ -249,6 +263,8 @@ void xHipCodecFree(x266hip_ctx *ctx)
         }
     for (const x266hip_ctx::MeScratch &m : ctx->me_scratch) (void)hipFree(m.p);
     for (void *q : ctx->me_retired) (void)hipFree(q);
+    if (ctx->d_tile_fwd) (void)hipFree(ctx->d_tile_fwd);
+    if (ctx->d_tile_inv) (void)hipFree(ctx->d_tile_inv);
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
     if (ctx->d_inv) (void)hipFree(ctx->d_inv);
     if (ctx->d_inv_lds) (void)hipFree(ctx->d_inv_lds);
@@ -291,6 +307,8 @@ static const OptionDesc kOptions[] = {
     {"dct32_fwdinv_blocks_per_wave", &x266hip_ctx::dct_fwdinv_blocks_per_wave, 1, 4096, 1},
     {"satd_groups_per_wave", &x266hip_ctx::satd_groups_per_wave, 1, 4096, 1},
     {"tr_tiles_per_wave", &x266hip_ctx::tr_tiles_per_wave, 1, 64, 1},
+    {"tile_tiles_per_wave", &x266hip_ctx::tile_tiles_per_wave, 0, 64, 1},
+    {"tile_lds_bytes_per_wave", &x266hip_ctx::tile_lds_per_wave, 2048, 40960, 1},
     {"wg_threads", &x266hip_ctx::wg_threads, 64, 256, 64},
     {"satd_wg_threads", &x266hip_ctx::satd_wg_threads, 64, 256, 64},
     {"dct32_wg_threads", &x266hip_ctx::dct_wg_threads, 64, 256, 64},
@@ -453,15 +471,12 @@ int xTransformTilesDev(x266hip_ctx *ctx, int inverse, const int16_t *d_in, int16
     if (bad_ptrs(d_in, d_out, n_tiles) || (n_tiles && !d_tile_class)) return fail(ctx, X266HIP_EINVAL, "xTransformTilesDev: NULL or unaligned buffer");
     if (n_tiles && ((uintptr_t)d_tile_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformTilesDev: unaligned offset table");
     X_DEV(ctx);
-    const DctOps *ops[16];
-    for (int type = 0; type < x266hip_ctx::kTypes; ++type) {
-        for (int l = 0; l < 3; ++l) ops[type * 4 + l] = inverse ? ctx->d_tr_inv[type][l] : ctx->d_tr[type][l];
-        ops[type * 4 + 3] = inverse ? ctx->d_inv_lds : ctx->d_fwd;     // size 32 exists for DCT-II only; the other slots stay valid
-    }
     LaunchCfg cfg = cfg_for(ctx, inverse ? 1 : 0);
     cfg.wg_threads = inverse ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
-    cfg.lds_bytes_per_wave = 4096;                                      // three dependent fetches per tile (class, images, data): more waves in flight pay here (profiles/r01_tiles_one_launch.txt)
-    hipError_t e = launch_transform_tiles(inverse != 0, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, ops, cfg, (hipStream_t)stream);
+    cfg.lds_bytes_per_wave = ctx->tile_lds_per_wave;                    // dependent fetches per tile (class, images, data): more waves in flight pay here
+    cfg.units_per_wave = ctx->tile_tiles_per_wave ? ctx->tile_tiles_per_wave : (inverse ? 2 : 1);   // measured optimum (profiles/r02_tiles_one_launch.txt)
+    hipError_t e = launch_transform_tiles(inverse != 0, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class,
+                                          inverse ? ctx->d_tile_inv : ctx->d_tile_fwd, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "tile transform launch", e);
     return X266HIP_OK;
 }
