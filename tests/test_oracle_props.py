@@ -200,3 +200,29 @@ def test_transform_set_inverse_definition(oracle):
             r9 = residual_np(400 * n * n, 95 + n).reshape(-1, n * n)
             rt = oracle.transform_inv(ttype, n, oracle.transform_fwd(ttype, n, r9))
             assert np.abs(rt.astype(np.int32) - r9.astype(np.int32)).max() <= 6
+
+
+# ---- full-search harness (BASELINE configs[2]; UNPINNED upstream: order, tie-break, padding are this repo's) --------
+def test_search_harness_is_ten_lines_of_numpy(oracle):
+    """The harness stated independently of orc_satd8x8_search: for every 8x8 block and every displacement in
+    [-R, R]^2, cost = satd8x8(cur - ref) with the pinned per-block function; candidates in raster order (dy ascending,
+    then dx), the FIRST minimum wins; the reference is read at (x + dx, y + dy) of a frame padded by >= R."""
+    from _util import me_frames
+    for (w, h, rng, pad, seed) in ((24, 16, 3, 5, 1), (16, 24, 6, 6, 2), (8, 8, 2, 4, 3)):
+        cur, refp = me_frames(w, h, pad, seed, mv=(1, -1), noise=2)
+        if seed == 3:
+            cur[:] = 7
+            refp[:] = 9                                                  # all candidates tie: (-R, -R) must win
+        mv, cost, costs = oracle.satd_search(cur, refp, pad, rng, want_costs=True)
+        span = 2 * rng + 1
+        for by in range(h // 8):
+            for bx in range(w // 8):
+                blk = cur[8 * by:8 * by + 8, 8 * bx:8 * bx + 8].astype(np.int16)
+                cands = [(dy, dx) for dy in range(-rng, rng + 1) for dx in range(-rng, rng + 1)]          # raster order
+                diffs = np.stack([blk - refp[pad + 8 * by + dy:pad + 8 * by + dy + 8, pad + 8 * bx + dx:pad + 8 * bx + dx + 8].astype(np.int16)
+                                  for dy, dx in cands])
+                c = oracle.satd8x8(diffs.reshape(-1, 64))                # the pinned cost (src_tb/satd.c via test_oracle_vs_ref)
+                first = int(np.argmin(c))                                # np.argmin returns the FIRST minimum
+                b = by * (w // 8) + bx
+                assert np.array_equal(costs[b], c) and costs.shape[1] == span * span
+                assert cost[b] == c[first] and tuple(mv[b]) == (cands[first][1], cands[first][0])
