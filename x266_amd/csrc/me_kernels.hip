@@ -1011,6 +1011,195 @@ __global__ __launch_bounds__(256) void sad_search_kernel(const MeParams P)
     }
 }
 
+// ============================================================================
+// SAD search, variant 2 (default).  The same rotating-accumulator scheme (lane = candidate column, the 8 pixels of
+// a reference row at that column serve the eight candidates whose block contains the row), reorganised so that
+// the scored lanes are all valid and the per-candidate bookkeeping is two instructions:
+//   * one pass = ONE block column x 64 candidate columns starting AT the column's own window, walked over all
+//     window rows for the TBY vertically adjacent blocks of the tile -- they share the fetched row (their current
+//     rows sit in 4 x 16 SGPRs) and, unlike horizontally adjacent blocks, the same aligned columns: a window of
+//     2R+1 = 64 G + rem columns is G passes of 64 valid lanes (variant 1 scored 192 lanes for 129 columns);
+//   * the rem extra columns (the "+1" at R = 64) go to narrow passes with lane = candidate ROW (rem <= 8), or to one
+//     masked pass (rem > 8);
+//   * keys hold the window POSITION, (cost << 16 | row << 8 | column) -- the finished row is the same position for
+//     every block of the column, so it is one v_add per row; per (row, block) a v_lshl_or and a v_min.
+// ============================================================================
+template <int TBY, bool COSTS>
+__global__ __launch_bounds__(256) void sad_search_kernel_v2(const MeParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NBLK = kTileBlocksX * TBY;
+    const int R = P.range, span = 2 * R + 1;
+    const int n_rows = 8 * (TBY - 1) + span;                           // candidate rows of the tile
+    const int win_rows = n_rows + 7;
+    uint32_t *best_lds = reinterpret_cast<uint32_t *>(smem);
+    unsigned char *win = smem + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, n_waves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
+    const int x0 = tx * (8 * kTileBlocksX), y0 = ty * (8 * TBY);
+
+    {   // reference window, raw pixels (edge-clamped like the SATD search)
+        const int dwords_per_row = P.pitch >> 2;
+        const int total = win_rows * dwords_per_row;
+        for (int i = tid; i < total; i += blockDim.x) {
+            const int ry = i / dwords_per_row, cx = (i - ry * dwords_per_row) * 4;
+            int gy = y0 - R + ry;
+            gy = gy < -R ? -R : (gy > P.height + R - 1 ? P.height + R - 1 : gy);
+            const uint8_t *row = P.ref + (long long)gy * P.ref_stride;
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int gx = x0 - R + cx + b;
+                gx = gx < -R ? -R : (gx > P.width + R - 1 ? P.width + R - 1 : gx);
+                v |= (uint32_t)row[gx] << (8 * b);
+            }
+            reinterpret_cast<uint32_t *>(win)[i] = v;
+        }
+    }
+    if (tid < NBLK) best_lds[tid] = 0xFFFFFFFFu;
+    __syncthreads();
+
+    int blocks_left_x = P.blocks_x - tx * kTileBlocksX, blocks_left_y = P.blocks_y - ty * TBY;
+    blocks_left_x = blocks_left_x > kTileBlocksX ? kTileBlocksX : blocks_left_x;
+    blocks_left_y = blocks_left_y > TBY ? TBY : blocks_left_y;
+    const int G = span >> 6, rem = span - 64 * G;                       // full 64-column passes, extra columns
+    const int n_wide = G + (rem > 8 ? 1 : 0);                           // + one masked pass
+    const int n_narrow_cols = rem > 8 ? 0 : rem;
+    const int n_chunks = (n_rows + 63) >> 6;
+    const int n_main = kTileBlocksX * n_wide;
+    const int n_items = n_main + kTileBlocksX * n_narrow_cols * n_chunks;
+
+    for (int item = wave; item < n_items; item += n_waves) {
+        const bool wide = item < n_main;
+        int i, gq = 0, ncol = 0, chunk = 0;
+        if (wide) { i = item / n_wide; gq = item - i * n_wide; }
+        else { const int it = item - n_main; chunk = it % n_chunks; const int rest = it / n_chunks; ncol = rest % n_narrow_cols; i = rest / n_narrow_cols; }
+        if (i >= blocks_left_x) continue;
+        // Current rows of the column's TBY blocks, the same in every lane, held in VGPRs: 4 x 16 scalars next to the
+        // loop state do not fit the SGPR file (98 spills when tried; variant 1 overflows it too), and the v_sad_u8
+        // chain does not care which file its second operand comes from.  `lane0` is a zero the compiler cannot see
+        // through, so these stay vector loads.
+        int lane0;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
+        uint32_t c[TBY][8][2];
+#pragma unroll
+        for (int j = 0; j < TBY; ++j) {
+            const int by = ty * TBY + (j < blocks_left_y ? j : blocks_left_y - 1);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(P.cur + (long long)(by * 8 + p) * P.cur_stride + (tx * kTileBlocksX + i) * 8) + lane0;
+                c[j][p][0] = q[0];
+                c[j][p][1] = q[1];
+            }
+        }
+        uint32_t best[TBY];
+#pragma unroll
+        for (int j = 0; j < TBY; ++j) best[j] = 0xFFFFFFFFu;
+
+        if (wide) {
+            const int col = 8 * i + 64 * gq + lane;                    // window column of this lane's candidates
+            const bool lane_ok = 64 * gq + lane < span;                 // false only in the masked pass
+            const int sh = (col & 3) * 8;
+            const unsigned char *colbase = win + (col & ~3);
+            uint32_t acc[TBY][8];
+#pragma unroll
+            for (int j = 0; j < TBY; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[j][k] = 0;
+            uint32_t pid = (uint32_t)col + ((uint32_t)(-7) << 8);       // position of the candidate finished by row ry: (ry - 7, col)
+            for (int ry8 = 0; ry8 < win_rows; ry8 += 8) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int ry = ry8 + m;
+                    if (ry >= win_rows) break;                           // wave-uniform
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(colbase + ry * P.pitch);
+                    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                    const uint32_t a0 = __builtin_amdgcn_alignbit(d1, d0, sh), a1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+#pragma unroll
+                    for (int j = 0; j < TBY; ++j) {
+                        const int rel = ry - 8 * j;                      // row inside block row j's band
+                        if (rel < 0 || rel >= span + 7 || j >= blocks_left_y) continue;      // wave-uniform
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) {
+                            const int slot = (m - p) & 7;
+                            const uint32_t init = p == 0 ? 0u : acc[j][slot];
+                            acc[j][slot] = __builtin_amdgcn_sad_u8(a1, c[j][p][1], __builtin_amdgcn_sad_u8(a0, c[j][p][0], init));
+                        }
+                        const int dyi = rel - 7;                         // the candidate row that has now seen all 8 block rows
+                        if (dyi >= 0 && dyi < span) {                    // wave-uniform
+                            const uint32_t cost = acc[j][(m + 1) & 7];
+                            uint32_t key = (cost << 16) | pid;
+                            if (!lane_ok) key = 0xFFFFFFFFu;
+                            best[j] = key < best[j] ? key : best[j];
+                            if (COSTS && lane_ok) {
+                                const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
+                                P.costs[blk * (size_t)(span * span) + (size_t)dyi * span + (size_t)(64 * gq + lane)] = cost;
+                            }
+                        }
+                    }
+                    pid += 256u;
+                }
+            }
+        } else {
+            // narrow pass: one extra column, lane = candidate row (window row 64 * chunk + lane)
+            const int col = 8 * i + 64 * G + ncol;
+            const int prow = 64 * chunk + lane;
+            const int lrow = prow < n_rows - 1 ? prow : n_rows - 1;       // clamp the loads, not the position
+            const int sh = (col & 3) * 8;
+            const unsigned char *base = win + lrow * P.pitch + (col & ~3);
+            uint32_t a[8][2];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(base + p * P.pitch);
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                a[p][0] = __builtin_amdgcn_alignbit(d1, d0, sh);
+                a[p][1] = __builtin_amdgcn_alignbit(d2, d1, sh);
+            }
+            const uint32_t pid = (uint32_t)(prow << 8 | col);
+#pragma unroll
+            for (int j = 0; j < TBY; ++j) {
+                if (j >= blocks_left_y || 64 * chunk + 63 < 8 * j || 64 * chunk >= 8 * j + span) continue;   // wave-uniform
+                uint32_t cost = 0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) cost = __builtin_amdgcn_sad_u8(a[p][1], c[j][p][1], __builtin_amdgcn_sad_u8(a[p][0], c[j][p][0], cost));
+                const int dyi = prow - 8 * j;
+                const bool ok = (unsigned)dyi < (unsigned)span;
+                const uint32_t key = ok ? ((cost << 16) | pid) : 0xFFFFFFFFu;
+                best[j] = key < best[j] ? key : best[j];
+                if (COSTS && ok) {
+                    const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
+                    P.costs[blk * (size_t)(span * span) + (size_t)dyi * span + (size_t)(64 * G + ncol)] = cost;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TBY; ++j) {
+            uint32_t v = best[j];
+#pragma unroll
+            for (int mm = 32; mm >= 1; mm >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)v, mm);
+                v = o < v ? o : v;
+            }
+            if (lane == 0 && j < blocks_left_y) atomicMin(&best_lds[j * kTileBlocksX + i], v);
+        }
+    }
+    __syncthreads();
+    if (tid < NBLK) {
+        const int bi = tid % kTileBlocksX, bj = tid / kTileBlocksX;
+        const int bx = tx * kTileBlocksX + bi, by = ty * TBY + bj;
+        if (bx < P.blocks_x && by < P.blocks_y) {
+            const uint32_t key = best_lds[tid];
+            x266_me_result_t res;
+            res.mvx = (int16_t)((int)(key & 0xFFu) - 8 * bi - R);
+            res.mvy = (int16_t)((int)((key >> 8) & 0xFFu) - 8 * bj - R);
+            res.cost = key >> 16;
+            P.best[(size_t)by * P.blocks_x + bx] = res;
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
@@ -1114,9 +1303,10 @@ namespace x266 {
 
 hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
                              int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
-                             int tile_rows, hipStream_t stream)
+                             int tile_rows, int variant, hipStream_t stream)
 {
     MeParams P;
+    P.keys = nullptr; P.splits = 1;
     P.cur = d_cur; P.ref = d_ref; P.cur_stride = cur_stride; P.ref_stride = ref_stride;
     P.width = width; P.height = height; P.range = range;
     P.blocks_x = width / 8; P.blocks_y = height / 8;
@@ -1130,6 +1320,13 @@ hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const u
     P.best = d_best; P.costs = d_costs;
     dim3 grid((unsigned)(P.tiles_x * tiles_y)), block(256);
     const size_t lds = 128 + (size_t)(P.n_rows + 7) * P.pitch;
+    if (variant == 2) {
+#define X266_SADS2(T) do { if (d_costs) hipLaunchKernelGGL((sad_search_kernel_v2<T, true>), grid, block, lds, stream, P); \
+                           else         hipLaunchKernelGGL((sad_search_kernel_v2<T, false>), grid, block, lds, stream, P); } while (0)
+        if (tby == 4) X266_SADS2(4); else if (tby == 1) X266_SADS2(1); else X266_SADS2(2);
+#undef X266_SADS2
+        return hipGetLastError();
+    }
 #define X266_SADS(T) do { if (d_costs) hipLaunchKernelGGL((sad_search_kernel<T, true>), grid, block, lds, stream, P); \
                           else         hipLaunchKernelGGL((sad_search_kernel<T, false>), grid, block, lds, stream, P); } while (0)
     if (tby == 4) X266_SADS(4); else if (tby == 1) X266_SADS(1); else X266_SADS(2);

@@ -88,7 +88,7 @@ hipError_t launch_intra32_costs(const x266_intra_ref_t *d_refs, const uint8_t *d
 hipError_t launch_satd8x8_butterfly(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
                              int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
-                             int tile_rows, hipStream_t stream);
+                             int tile_rows, int variant, hipStream_t stream);
 hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles, const uint32_t *d_tile_offsets,
                                   const uint8_t *d_tile_class, const TileOpsSoA *d_class_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_dct32_butterfly(const int16_t *d_in, int16_t *d_out, size_t n_blocks, hipStream_t stream);

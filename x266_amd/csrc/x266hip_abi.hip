@@ -48,6 +48,7 @@ struct x266hip_ctx {
     int me_tile_rows = 8;                           // block rows per ME tile (1, 2, 4; 8 for variant 4 -- other variants and the SAD search use min(this, 4))
     int me_row_pairs = 2;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
     int me_variant = 4;                             // 1 = LDS coefficients, 2 = scalar coefficients, 3 = scalar coefficients, 16x4 units, position keys (me_kernels.hip)
+    int sad_me_variant = 2;                         // SAD search: 1 = four horizontally adjacent blocks per pass (round 1), 2 = one block column per pass, aligned, position keys
     int me_wg_threads = 0;                          // variants 3, 4: workgroup size (0 = 256 for variant 3, 512 for variant 4: two 8-wave workgroups per CU)
     int me_splits = 0;                              // variant 3: workgroups per tile (0 = chosen so that the last round of workgroups is full)
     // variant 2 scratch (128 B per 8x8 block of the current frame), ONE PER STREAM: searches enqueued on
@@ -324,6 +325,7 @@ static const OptionDesc kOptions[] = {
     {"satd_lds_pad_bytes", &x266hip_ctx::lds_pad_satd, 0, 160 * 1024, 1},
     {"me_tile_rows", &x266hip_ctx::me_tile_rows, 1, 8, 1},
     {"me_variant", &x266hip_ctx::me_variant, 1, 4, 1},
+    {"sad_me_variant", &x266hip_ctx::sad_me_variant, 1, 2, 1},
     {"me_wg_threads", &x266hip_ctx::me_wg_threads, 0, 512, 64},
     {"me_splits", &x266hip_ctx::me_splits, 0, 8, 1},
     {"me_row_pairs", &x266hip_ctx::me_row_pairs, 1, 3, 1},
@@ -643,7 +645,7 @@ int xSad8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride
     if (((uintptr_t)d_best & 7u) || ((uintptr_t)d_costs & 3u)) return fail(ctx, X266HIP_EINVAL, "xSad8x8SearchDev: unaligned output");
     X_DEV(ctx);
     hipError_t e = launch_sad_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
-                                     d_best, d_costs, ctx->me_tile_rows, (hipStream_t)stream);
+                                     d_best, d_costs, ctx->me_tile_rows, ctx->sad_me_variant, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "SAD search launch", e);
     return X266HIP_OK;
 }
