@@ -8,7 +8,9 @@
  * It validates before it times: every frame of the pipelined, sharded run must equal, bit for bit, what
  * one device computes for the same frame with the plain batch calls.
  *
- *   usage: stream8k [n_devices (0 = all visible)] [frames] [width] [height]      exit code 0 on success
+ *   usage: stream8k [n_ranks (0 = all visible devices)] [frames] [width] [height]      exit code 0 on success
+ *          n_ranks > visible devices: ranks share devices round-robin (a test mode: RCCL refuses two ranks on one
+ *          device, so the node uses its peer-copy transport -- the whole schedule still runs, with real transfers)
  *   prints one JSON line: frames/s, devices, transport, bit_exact
  */
 #define _POSIX_C_SOURCE 200809L
@@ -39,13 +41,17 @@ int main(int argc, char **argv)
     const int width = argc > 3 ? atoi(argv[3]) : 7680, height = argc > 4 ? atoi(argv[4]) : 4320;
     x266hip_node *node = NULL;
     x266hip_ctx *hip = NULL;
-    if (n_dev <= 0) n_dev = xHipDeviceCount();
-    if (n_dev <= 0) { fprintf(stderr, "no HIP device (this library has no CPU path)\n"); return 1; }
-    if (xHipNodeInit(&node, NULL, n_dev) != X266HIP_OK) { fprintf(stderr, "xHipNodeInit(%d devices) failed\n", n_dev); return 1; }
+    const int visible = xHipDeviceCount();
+    if (visible <= 0) { fprintf(stderr, "no HIP device (this library has no CPU path)\n"); return 1; }
+    if (n_dev <= 0) n_dev = visible;
+    int devices[64];
+    if (n_dev > 64) n_dev = 64;
+    for (int i = 0; i < n_dev; i++) devices[i] = i % visible;
+    if (xHipNodeInit(&node, devices, n_dev) != X266HIP_OK) { fprintf(stderr, "xHipNodeInit(%d devices) failed\n", n_dev); return 1; }
     hip = xHipNodeCtx(node, 0);                                    /* the root's context: frames live on its device */
     const int rccl = xHipNodeSelfTest(node) == X266HIP_OK;         /* ring send/recv + all-reduce over the node's communicators */
     if (!rccl) fprintf(stderr, "RCCL self-test did not pass (%s): peer-copy transport\n", xHipNodeLastError(node));
-    if (!rccl && n_dev > 1) CHECK(xHipNodeSetOption(node, "transport", 1));
+    if (!rccl && n_dev > 1) CHECK(xHipNodeSetOption(node, "transport", 1));   /* (already the node's fallback) */
 
     const size_t n_dct = (size_t)(width / 32) * (height / 32), n_satd = (size_t)(width / 8) * (height / 8);
     const size_t in_bytes[2] = {n_dct * 2048, n_satd * 128}, out_bytes[2] = {n_dct * 2048, n_satd * 4};
@@ -115,7 +121,7 @@ int main(int argc, char **argv)
     printf("{\"workload\": \"%dx%d frame stream: %zu DCT32 + %zu SATD blocks per frame\", \"devices\": %d, \"transport\": \"%s\", "
            "\"frames\": %d, \"frames_per_s\": %.1f, \"ms_per_frame\": %.4f, \"dct32_blocks_per_s\": %.4e, \"satd8x8_blocks_per_s\": %.4e, "
            "\"bit_exact_vs_single_device\": %s}\n",
-           width, height, n_dct, n_satd, n_dev, n_dev == 1 ? "none (one rank)" : rccl ? "rccl send/recv groups" : "hipMemcpyPeerAsync",
+           width, height, n_dct, n_satd, n_dev, visible, n_dev == 1 ? "none (one rank)" : rccl ? "rccl send/recv groups" : "hipMemcpyPeerAsync",
            frames, frames / dt, dt / frames * 1e3, n_dct * frames / dt, n_satd * frames / dt, exact ? "true" : "false");
     free(got); free(want);
     xNodeStreamFree(st);

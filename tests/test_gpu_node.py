@@ -139,6 +139,11 @@ def test_plain_c_host_stream8k():
     assert r.returncode == 0, r.stdout + r.stderr
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["bit_exact_vs_single_device"] is True and line["frames_per_s"] > 100
+    # three ranks sharing the device (peer-copy transport): every frame still equals the single-device result
+    r = subprocess.run([exe, "3", "20", "1920", "1088"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["ranks"] == 3 and line["bit_exact_vs_single_device"] is True
 
 
 def test_calls_restore_the_callers_device(codec):
@@ -175,3 +180,62 @@ def test_searches_on_two_streams_do_not_share_scratch(codec, oracle):
         assert np.array_equal(raw.view(np.uint32).reshape(-1, 2)[:, 1], cost0)
     for s in streams:
         codec.stream_destroy(s)
+
+
+# ---- several ranks on the one GPU of the test box ----------------------------------------------------------------
+# RCCL refuses two ranks on one device (ncclCommInitAll: invalid usage), and a single-process node then falls back to
+# its hipMemcpyPeerAsync transport (SURVEY 8e's alternative).  That makes a real N-rank node on ONE device: every
+# rank has its own context, streams, events and slot buffers, the root works zero-copy in the caller's buffers, peers'
+# shards and stripes really travel (device-to-device copies instead of ncclSend/ncclRecv) -- the whole schedule and
+# partition of the multi-GPU path except the RCCL calls themselves, which test_rccl_executes_on_this_box covers.
+@pytest.fixture(scope="module", params=[2, 3, 5])
+def multi_node(request):
+    n = Node.single_process([0] * request.param)
+    assert n.world == request.param and n.local_ranks == list(range(request.param))
+    yield n
+    n.close()
+
+
+@pytest.mark.parametrize("w,h,n_frames", [(96, 160, 7), (64, 32, 5), (7680, 4320, 3)])
+def test_multi_rank_frame_stream_is_bit_exact(multi_node, oracle, w, h, n_frames):
+    """Ragged shards (15 DCT blocks over 2, 3, 5 ranks; 2 blocks over 3 and 5 ranks leaves ranks idle), slots reused,
+    two frames in flight; at 7680x4320 every rank transforms its 1/N of the frame and the root's buffers receive the rest."""
+    n_d, n_s = (w // 32) * (h // 32), (w // 8) * (h // 8)
+    st = multi_node.frame_stream(w, h)
+    dev = torch.device("cuda", 0)
+    xin = [(torch.from_numpy(_frame(oracle, n_d * 1024, 0x266, f)).to(dev), torch.from_numpy(_frame(oracle, n_s * 64, 0x267, f)).to(dev))
+           for f in range(n_frames)]
+    out = [(torch.zeros(n_d * 1024, dtype=torch.int16, device=dev), torch.zeros(n_s, dtype=torch.int32, device=dev)) for _ in range(n_frames)]
+    torch.cuda.synchronize()
+    tickets = []
+    for f in range(n_frames):
+        tickets.append(st.push([xin[f][0].data_ptr(), xin[f][1].data_ptr()], [out[f][0].data_ptr(), out[f][1].data_ptr()]))
+        if f >= 2:
+            st.wait(tickets[f - 2])
+            assert np.array_equal(out[f - 2][1].cpu().numpy(), oracle.satd8x8(xin[f - 2][1].cpu().numpy(), threads=32).astype(np.int32)), f - 2
+    st.flush()
+    for f in range(n_frames):
+        assert np.array_equal(out[f][0].cpu().numpy(), oracle.dct32_fwd(xin[f][0].cpu().numpy(), threads=32).ravel()), f
+        assert np.array_equal(out[f][1].cpu().numpy(), oracle.satd8x8(xin[f][1].cpu().numpy(), threads=32).astype(np.int32)), f
+    st.close()
+
+
+def test_multi_rank_batch_and_sharded_search(multi_node, codec, oracle):
+    dev = torch.device("cuda", 0)
+    n = 10007
+    x = oracle.fill_residual(n * 1024, 78)
+    tin, tout = torch.from_numpy(x).to(dev), torch.zeros(n * 1024, dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    multi_node.batch_scatter_gather(OP_DCT32_FWD, tin.data_ptr(), tout.data_ptr(), n, 1000)
+    assert np.array_equal(tout.cpu().numpy(), oracle.dct32_fwd(x, threads=16).ravel())
+    w, h, rng = 200, 136, 24
+    cur, refp = me_frames(w, h, rng, 0x52, mv=(-2, 3))
+    mv0, cost0, _ = codec.satd_search(cur, refp, rng, rng)
+    tc, tr = torch.from_numpy(cur).to(dev), torch.from_numpy(refp).to(dev)
+    nb = (h // 8) * (w // 8)
+    for n_stripes in (0, multi_node.world + 2):             # one stripe per rank; more stripes than ranks (contiguous runs)
+        best = torch.zeros(nb * 2, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        multi_node.satd_search(tc.data_ptr(), tc.stride(0), tr.data_ptr() + rng * tr.stride(0) + rng, tr.stride(0), w, h, rng, n_stripes, best.data_ptr())
+        raw = best.cpu().numpy()
+        assert np.array_equal(raw.view(np.int16).reshape(nb, 4)[:, :2], mv0) and np.array_equal(raw.view(np.uint32).reshape(nb, 2)[:, 1], cost0), n_stripes
