@@ -118,7 +118,7 @@ int main(int argc, char **argv)
         CHECK(xHipMemcpyD2H(hip, want, d_ref[(frames - 1) % IN_RING][l], out_bytes[l]));
         if (memcmp(got, want, out_bytes[l])) { exact = 0; fprintf(stderr, "last timed frame, lane %d differs\n", l); }
     }
-    printf("{\"workload\": \"%dx%d frame stream: %zu DCT32 + %zu SATD blocks per frame\", \"devices\": %d, \"transport\": \"%s\", "
+    printf("{\"workload\": \"%dx%d frame stream: %zu DCT32 + %zu SATD blocks per frame\", \"ranks\": %d, \"visible_devices\": %d, \"transport\": \"%s\", "
            "\"frames\": %d, \"frames_per_s\": %.1f, \"ms_per_frame\": %.4f, \"dct32_blocks_per_s\": %.4e, \"satd8x8_blocks_per_s\": %.4e, "
            "\"bit_exact_vs_single_device\": %s}\n",
            width, height, n_dct, n_satd, n_dev, visible, n_dev == 1 ? "none (one rank)" : rccl ? "rccl send/recv groups" : "hipMemcpyPeerAsync",
