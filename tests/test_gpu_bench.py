@@ -46,3 +46,27 @@ def test_bench_small_run_has_every_leg_and_field():
     assert d["also"]["dct32_fwd_inv_fused"]["same_bytes_as_two_kernels"] is True
     assert d["also"]["satd8x8_me_search"]["planted_mv_found_fraction"] > 0.99
     assert "error" not in d
+
+
+def test_bench_two_ranks_share_the_gpu_and_agree_with_one_rank():
+    """The N > 1 path of bench.py on a one-GPU box (X266_BENCH_SHARE_GPU: ranks share the device, control plane on gloo):
+    every rank transforms its own slice of the one seeded stream, so two ranks x n blocks must give the output checksum
+    of one rank x 2n blocks; the JSON reports n_gpus = 2 and the whole-job rate."""
+    n = 16384
+    one = _run(["--steps", "3", "--warmup", "1", "--dct-blocks", str(2 * n), "--no-also", "--no-cpu-baseline"])
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, X266_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--dct-blocks", str(n), "--no-also", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 only
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["cpu_baseline"] is None
+    assert two["output_checksum_sum_i16"] == one["output_checksum_sum_i16"]
+    assert two["config"]["blocks_per_gpu"] == n
