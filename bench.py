@@ -73,6 +73,8 @@ def parse_args():
     ap.add_argument("--no-also", action="store_true", help="headline leg only")
     ap.add_argument("--stream8k", type=int, default=200, metavar="FRAMES",
                     help="frames of the BASELINE configs[4] leg (7680x4320 stream through the node layer); 0 skips it")
+    ap.add_argument("--node-timeout", type=float, default=240.0,
+                    help="seconds the node-layer legs (RCCL) may take before the JSON line is printed without them")
     ap.add_argument("--no-me", action="store_true", help="skip the motion-search legs")
     ap.add_argument("--no-transform-set", action="store_true", help="skip the transform-set / front-end / intra legs")
     return ap.parse_args()
@@ -600,109 +602,128 @@ def main():
             also["intra32"] = intra
             del refs_t, modes_t, index_t, pred_t, src_t, cost_t, bestm_t
 
-        # ---- the node layer of the C ABI: BASELINE configs[4] and the other end-to-end scatter/gather figures
-        if ctrl == "cuda" and args.stream8k > 0:
-            uid = [Node.unique_id() if rank == 0 else None]
-            if dist is not None:
-                dist.broadcast_object_list(uid, src=0, device=torch.device("cuda", local_rank))
-            node = Node.for_rank(local_rank, rank, world, uid[0])      # xHipNodeInitRank: one process per GPU, also at N = 1
-            node.self_test()                                            # RCCL ring send/recv + all-reduce, checked
-            fw8, fh8 = 7680, 4320
-            nd8, ns8 = (fw8 // 32) * (fh8 // 32), (fw8 // 8) * (fh8 // 8)
-            IN_RING, OUT_RING = 3, 4
-            fin = fout = None
-            if rank == 0:
-                fin = [(torch.empty(nd8 * 1024, dtype=torch.int16, device="cuda"), torch.empty(ns8 * 64, dtype=torch.int16, device="cuda")) for _ in range(IN_RING)]
-                fout = [(torch.zeros(nd8 * 1024, dtype=torch.int16, device="cuda"), torch.zeros(ns8, dtype=torch.int32, device="cuda")) for _ in range(OUT_RING)]
-                for i, (a, b) in enumerate(fin):
-                    codec.fill_residual_dev(a.data_ptr(), a.numel(), DCT_SEED, i * 100000007, stream)
-                    codec.fill_residual_dev(b.data_ptr(), b.numel(), SATD_SEED, i * 100000007, stream)
-            torch.cuda.synchronize()
-            st8 = node.frame_stream(fw8, fh8)
-
-            def push8(f):
-                if rank == 0:
-                    a, b = fin[f % IN_RING]
-                    c, e = fout[f % OUT_RING]
-                    st8.push([a.data_ptr(), b.data_ptr()], [c.data_ptr(), e.data_ptr()])
-                else:
-                    st8.push()
-            F = args.stream8k
-            for f in range(8):
-                push8(f)
-            st8.flush()
-            barrier()
-            t0 = time.perf_counter()
-            for f in range(F):
-                push8(f)
-            st8.flush()
-            barrier()
-            wall8 = max_over_ranks(time.perf_counter() - t0)
-            exact8 = None
-            if rank == 0:                                               # last frame against the plain single-device calls
-                a, b = fin[(F - 1) % IN_RING]
-                c, e = fout[(F - 1) % OUT_RING]
-                c1, e1 = torch.empty_like(c), torch.empty_like(e)
-                codec.dct32_fwd_dev(a.data_ptr(), c1.data_ptr(), nd8, stream)
-                codec.satd8x8_dev(b.data_ptr(), e1.data_ptr(), ns8, stream)
-                torch.cuda.synchronize()
-                exact8 = bool(torch.equal(c, c1) and torch.equal(e, e1))
-            peers = world - 1
-            link_bytes = (nd8 * 2048 + ns8 * 128) / world              # one peer's input shard of a frame, over one link
-            also["stream8k"] = {
-                "frames_per_s": F / wall8, "ms_per_frame": wall8 / F * 1e3, "frames": F,
-                "dct32_blocks_per_s": nd8 * F / wall8, "satd8x8_blocks_per_s": ns8 * F / wall8,
-                "frame": "7680x4320: %d DCT32 blocks (66.4 MB) + %d SATD blocks (66.4 MB)" % (nd8, ns8),
-                "path": "C ABI node layer (xNodeStreamPush / Flush): per step one RCCL group carries frame t's shards root -> peers and "
-                        "frame t-2's coefficients and costs peers -> root on a communication stream while every rank transforms frame t"
-                        if world > 1 else "C ABI node layer, one rank: the root transforms the frame in place, no transfer (RCCL only in the self-test)",
-                "bit_exact_vs_single_device": exact8,
-                "link_bound_frames_per_s": (XGMI_LINK_BYTES_PER_S / link_bytes) if peers else None,
-                "link_bound": "each peer's input shard crosses ONE xGMI link (~153 GB/s per direction): <= 7.5e7 DCT32 blocks/s per peer (SURVEY.md 8e)"}
-            st8.close()
-            # one resident batch, scattered and gathered (SURVEY 8e "end-to-end scatter -> compute -> gather")
-            nsg = min(1 << 18, n_dct)
-            xin = xout = None
-            if rank == 0:
-                xin, xout = x[: nsg * 1024], z[: nsg * 1024]
-            torch.cuda.synchronize()
-            node.batch_scatter_gather(OP_DCT32_FWD, xin.data_ptr() if rank == 0 else 0, xout.data_ptr() if rank == 0 else 0, nsg, 0)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(4):
-                node.batch_scatter_gather(OP_DCT32_FWD, xin.data_ptr() if rank == 0 else 0, xout.data_ptr() if rank == 0 else 0, nsg, 0)
-            barrier()
-            wall_sg = max_over_ranks(time.perf_counter() - t0) / 4
-            also["dct32_scatter_gather"] = {"value": nsg / wall_sg, "unit": "blocks/s", "blocks": nsg,
-                                            "note": "root-resident batch cut into 4096-block chunks, pipelined through the node stream "
-                                                    "(xNodeBatchScatterGather); at N = 1 no transfer"}
-            if not args.no_me:
-                # sharded motion search: stripes + halo from the root, records back (xNodeSatd8x8Search)
-                nstr = max(world, 1)
-                node.satd_search(cur.data_ptr() if rank == 0 else 0, cur.stride(0), origin if rank == 0 else 0, refp.stride(0), 3840, 2160, 64, nstr,
-                                 best.data_ptr() if rank == 0 else 0)
-                ref_best = None
-                if rank == 0:
-                    ref_best = best.clone()
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    node.satd_search(cur.data_ptr() if rank == 0 else 0, cur.stride(0), origin if rank == 0 else 0, refp.stride(0), 3840, 2160, 64, nstr,
-                                     best.data_ptr() if rank == 0 else 0)
-                barrier()
-                wall_ms = max_over_ranks(time.perf_counter() - t0) / 3
-                same = None
-                if rank == 0:
-                    codec.satd_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), 3840, 2160, 64, best.data_ptr(), 0, stream)
-                    torch.cuda.synchronize()
-                    same = bool(torch.equal(best, ref_best))
-                also["satd8x8_me_search_sharded"] = {"ms_per_frame": wall_ms * 1e3, "stripes": nstr, "identical_to_single_device": same,
-                                                     "note": "synchronous call incl. scatter of cur stripes + reference halo and gather of (mv, cost)"}
-            node.close()
+        # ---- the node layer of the C ABI: BASELINE configs[4] and the other end-to-end scatter/gather figures.
+        # These legs are the only ones that talk RCCL from this library; a communication hang must not cost the whole
+        # line, so they run under a watchdog: past --node-timeout seconds rank 0 prints the JSON with what it has
+        # (the legs marked as timed out) and every rank leaves.
         result["also"] = also
-        # BASELINE.json quotes two figures, 32x32 DCT blocks/s and 8x8 SATD blocks/s: the second one, lifted to the top level
         result["secondary"] = {"metric": "satd8x8_blocks_per_s", "value": also["satd8x8"]["value"], "unit": "blocks/s",
                                "roofline_frac": also["satd8x8"]["roofline"]["frac"]}
+        if ctrl == "cuda" and args.stream8k > 0:
+            def node_timed_out():
+                also["node_layer_error"] = "node-layer legs did not finish within %.0f s (RCCL hang?); line printed without them" % args.node_timeout
+                if rank == 0:
+                    result.setdefault("cpu_baseline", None)
+                    result["device"] = codec.device_info()["name"].strip()
+                    os.write(json_fd, (json.dumps(result) + "\n").encode())
+                os._exit(0)
+            watchdog = threading.Timer(args.node_timeout, node_timed_out)
+            watchdog.daemon = True
+            watchdog.start()
+
+            def node_legs():
+                uid = [Node.unique_id() if rank == 0 else None]
+                if dist is not None:
+                    dist.broadcast_object_list(uid, src=0, device=torch.device("cuda", local_rank))
+                node = Node.for_rank(local_rank, rank, world, uid[0])      # xHipNodeInitRank: one process per GPU, also at N = 1
+                node.self_test()                                            # RCCL ring send/recv + all-reduce, checked
+                fw8, fh8 = 7680, 4320
+                nd8, ns8 = (fw8 // 32) * (fh8 // 32), (fw8 // 8) * (fh8 // 8)
+                IN_RING, OUT_RING = 3, 4
+                fin = fout = None
+                if rank == 0:
+                    fin = [(torch.empty(nd8 * 1024, dtype=torch.int16, device="cuda"), torch.empty(ns8 * 64, dtype=torch.int16, device="cuda")) for _ in range(IN_RING)]
+                    fout = [(torch.zeros(nd8 * 1024, dtype=torch.int16, device="cuda"), torch.zeros(ns8, dtype=torch.int32, device="cuda")) for _ in range(OUT_RING)]
+                    for i, (a, b) in enumerate(fin):
+                        codec.fill_residual_dev(a.data_ptr(), a.numel(), DCT_SEED, i * 100000007, stream)
+                        codec.fill_residual_dev(b.data_ptr(), b.numel(), SATD_SEED, i * 100000007, stream)
+                torch.cuda.synchronize()
+                st8 = node.frame_stream(fw8, fh8)
+
+                def push8(f):
+                    if rank == 0:
+                        a, b = fin[f % IN_RING]
+                        c, e = fout[f % OUT_RING]
+                        st8.push([a.data_ptr(), b.data_ptr()], [c.data_ptr(), e.data_ptr()])
+                    else:
+                        st8.push()
+                F = args.stream8k
+                for f in range(8):
+                    push8(f)
+                st8.flush()
+                barrier()
+                t0 = time.perf_counter()
+                for f in range(F):
+                    push8(f)
+                st8.flush()
+                barrier()
+                wall8 = max_over_ranks(time.perf_counter() - t0)
+                exact8 = None
+                if rank == 0:                                               # last frame against the plain single-device calls
+                    a, b = fin[(F - 1) % IN_RING]
+                    c, e = fout[(F - 1) % OUT_RING]
+                    c1, e1 = torch.empty_like(c), torch.empty_like(e)
+                    codec.dct32_fwd_dev(a.data_ptr(), c1.data_ptr(), nd8, stream)
+                    codec.satd8x8_dev(b.data_ptr(), e1.data_ptr(), ns8, stream)
+                    torch.cuda.synchronize()
+                    exact8 = bool(torch.equal(c, c1) and torch.equal(e, e1))
+                peers = world - 1
+                link_bytes = (nd8 * 2048 + ns8 * 128) / world              # one peer's input shard of a frame, over one link
+                also["stream8k"] = {
+                    "frames_per_s": F / wall8, "ms_per_frame": wall8 / F * 1e3, "frames": F,
+                    "dct32_blocks_per_s": nd8 * F / wall8, "satd8x8_blocks_per_s": ns8 * F / wall8,
+                    "frame": "7680x4320: %d DCT32 blocks (66.4 MB) + %d SATD blocks (66.4 MB)" % (nd8, ns8),
+                    "path": "C ABI node layer (xNodeStreamPush / Flush): per step one RCCL group carries frame t's shards root -> peers and "
+                            "frame t-2's coefficients and costs peers -> root on a communication stream while every rank transforms frame t"
+                            if world > 1 else "C ABI node layer, one rank: the root transforms the frame in place, no transfer (RCCL only in the self-test)",
+                    "bit_exact_vs_single_device": exact8,
+                    "link_bound_frames_per_s": (XGMI_LINK_BYTES_PER_S / link_bytes) if peers else None,
+                    "link_bound": "each peer's input shard crosses ONE xGMI link (~153 GB/s per direction): <= 7.5e7 DCT32 blocks/s per peer (SURVEY.md 8e)"}
+                st8.close()
+                # one resident batch, scattered and gathered (SURVEY 8e "end-to-end scatter -> compute -> gather")
+                nsg = min(1 << 18, n_dct)
+                xin = xout = None
+                if rank == 0:
+                    xin, xout = x[: nsg * 1024], z[: nsg * 1024]
+                torch.cuda.synchronize()
+                node.batch_scatter_gather(OP_DCT32_FWD, xin.data_ptr() if rank == 0 else 0, xout.data_ptr() if rank == 0 else 0, nsg, 0)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    node.batch_scatter_gather(OP_DCT32_FWD, xin.data_ptr() if rank == 0 else 0, xout.data_ptr() if rank == 0 else 0, nsg, 0)
+                barrier()
+                wall_sg = max_over_ranks(time.perf_counter() - t0) / 4
+                also["dct32_scatter_gather"] = {"value": nsg / wall_sg, "unit": "blocks/s", "blocks": nsg,
+                                                "note": "root-resident batch cut into 4096-block chunks, pipelined through the node stream "
+                                                        "(xNodeBatchScatterGather); at N = 1 no transfer"}
+                if not args.no_me:
+                    # sharded motion search: stripes + halo from the root, records back (xNodeSatd8x8Search)
+                    nstr = max(world, 1)
+                    node.satd_search(cur.data_ptr() if rank == 0 else 0, cur.stride(0), origin if rank == 0 else 0, refp.stride(0), 3840, 2160, 64, nstr,
+                                     best.data_ptr() if rank == 0 else 0)
+                    ref_best = None
+                    if rank == 0:
+                        ref_best = best.clone()
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        node.satd_search(cur.data_ptr() if rank == 0 else 0, cur.stride(0), origin if rank == 0 else 0, refp.stride(0), 3840, 2160, 64, nstr,
+                                         best.data_ptr() if rank == 0 else 0)
+                    barrier()
+                    wall_ms = max_over_ranks(time.perf_counter() - t0) / 3
+                    same = None
+                    if rank == 0:
+                        codec.satd_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), 3840, 2160, 64, best.data_ptr(), 0, stream)
+                        torch.cuda.synchronize()
+                        same = bool(torch.equal(best, ref_best))
+                    also["satd8x8_me_search_sharded"] = {"ms_per_frame": wall_ms * 1e3, "stripes": nstr, "identical_to_single_device": same,
+                                                         "note": "synchronous call incl. scatter of cur stripes + reference halo and gather of (mv, cost)"}
+                node.close()
+            try:
+                node_legs()
+            except Exception as e:                                      # e.g. RCCL missing: keep the rest of the line
+                also["node_layer_error"] = "%s: %s" % (type(e).__name__, e)
+            watchdog.cancel()
 
     # ---- CPU baseline for the headline leg (rank 0, N = 1 only) ------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
