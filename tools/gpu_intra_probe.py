@@ -23,7 +23,10 @@ def run(modes, idx, label):
         cd.stream_sync(); best = min(best, (time.perf_counter() - t0) / 20)
     print("%-28s: %.3f ms  %.3e predictions/s  %.2f TB/s written" % (label, best * 1e3, n / best, n * 1024 / best / 1e12), flush=True)
 allm = np.tile(np.arange(35), nref); idx = np.repeat(np.arange(nref), 35)
-run(allm, idx, "all 35 modes per border")
+for rounds in (1, 2, 3, 4, 6):
+    cd.set_option("intra_rounds", rounds)
+    run(allm, idx, "all 35 modes, rounds=%d" % rounds)
+cd.set_option("intra_rounds", 4)
 for m, name in ((0, "planar"), (1, "DC"), (26, "vertical 26"), (10, "horizontal 10"), (34, "angular 34"), (2, "angular 2"), (21, "angular 21 (neg, vert)"), (15, "angular 15 (neg, horiz)")):
     run(np.full(n, m), idx, name)
 

@@ -48,6 +48,7 @@ struct x266hip_ctx {
     int me_tile_rows = 8;                           // block rows per ME tile (1, 2, 4; 8 for variant 4 -- other variants and the SAD search use min(this, 4))
     int me_row_pairs = 2;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
     int me_variant = 4;                             // 1 = LDS coefficients, 2 = scalar coefficients, 3 = scalar coefficients, 16x4 units, position keys (me_kernels.hip)
+    int intra_rounds = 4;                           // intra prediction: rounds of seven predictions per wave (next round's reference sets prefetched)
     int sad_me_variant = 2;                         // SAD search: 1 = four horizontally adjacent blocks per pass (round 1), 2 = one block column per pass, aligned, position keys
     int me_wg_threads = 0;                          // variants 3, 4: workgroup size (0 = 256 for variant 3, 512 for variant 4: two 8-wave workgroups per CU)
     int me_splits = 0;                              // variant 3: workgroups per tile (0 = chosen so that the last round of workgroups is full)
@@ -326,6 +327,7 @@ static const OptionDesc kOptions[] = {
     {"me_tile_rows", &x266hip_ctx::me_tile_rows, 1, 8, 1},
     {"me_variant", &x266hip_ctx::me_variant, 1, 4, 1},
     {"sad_me_variant", &x266hip_ctx::sad_me_variant, 1, 2, 1},
+    {"intra_rounds", &x266hip_ctx::intra_rounds, 1, 16, 1},
     {"me_wg_threads", &x266hip_ctx::me_wg_threads, 0, 512, 64},
     {"me_splits", &x266hip_ctx::me_splits, 0, 8, 1},
     {"me_row_pairs", &x266hip_ctx::me_row_pairs, 1, 3, 1},
@@ -405,7 +407,7 @@ int xIntra32PredictDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const u
     if (n && (!d_refs || !d_modes || !d_pred || (((uintptr_t)d_refs | (uintptr_t)d_pred) & 15u) || ((uintptr_t)d_ref_index & 3u)))
         return fail(ctx, X266HIP_EINVAL, "xIntra32PredictDev: NULL or unaligned buffer");
     X_DEV(ctx);
-    hipError_t e = launch_intra32_predict(d_refs, d_modes, d_ref_index, d_pred, n, (hipStream_t)stream);
+    hipError_t e = launch_intra32_predict(d_refs, d_modes, d_ref_index, d_pred, n, ctx->intra_rounds, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "intra launch", e);
     return X266HIP_OK;
 }
