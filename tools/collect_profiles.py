@@ -8,10 +8,10 @@ P = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    hits = sorted(glob.glob(pattern, recursive=True))
+    hits = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
     if not hits:
         raise SystemExit("nothing matches " + pattern)
-    return hits[0]
+    return hits[-1]                      # the newest: gpurun_out/ keeps earlier rounds' directories of the same name
 
 
 def short(n):
