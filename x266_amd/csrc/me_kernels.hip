@@ -1109,6 +1109,7 @@ __global__ __launch_bounds__(256) void sad_search_kernel_v2(const MeParams P)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[j][k] = 0;
             uint32_t pid = (uint32_t)col + ((uint32_t)(-7) << 8);       // position of the candidate finished by row ry: (ry - 7, col)
+            const uint32_t dead = lane_ok ? 0u : 0xFFFFFFFFu;           // masked pass: lanes beyond the window get the all-ones key, once per row
             for (int ry8 = 0; ry8 < win_rows; ry8 += 8) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
@@ -1117,6 +1118,7 @@ __global__ __launch_bounds__(256) void sad_search_kernel_v2(const MeParams P)
                     const uint32_t *q = reinterpret_cast<const uint32_t *>(colbase + ry * P.pitch);
                     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
                     const uint32_t a0 = __builtin_amdgcn_alignbit(d1, d0, sh), a1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+                    const uint32_t pidm = pid | dead;
 #pragma unroll
                     for (int j = 0; j < TBY; ++j) {
                         const int rel = ry - 8 * j;                      // row inside block row j's band
@@ -1130,8 +1132,7 @@ __global__ __launch_bounds__(256) void sad_search_kernel_v2(const MeParams P)
                         const int dyi = rel - 7;                         // the candidate row that has now seen all 8 block rows
                         if (dyi >= 0 && dyi < span) {                    // wave-uniform
                             const uint32_t cost = acc[j][(m + 1) & 7];
-                            uint32_t key = (cost << 16) | pid;
-                            if (!lane_ok) key = 0xFFFFFFFFu;
+                            const uint32_t key = (cost << 16) | pidm;
                             best[j] = key < best[j] ? key : best[j];
                             if (COSTS && lane_ok) {
                                 const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
