@@ -6,7 +6,7 @@
  * boundary (a stream is passed as an opaque `void *` that holds a hipStream_t).
  * Reference paths below are relative to the upstream x266 tree.
  *
- * Three groups of entry points:
+ * Four groups of entry points:
  *
  *  1. The six BDPI symbols the Bluespec testbenches import
  *     (src/mkDct32.bsv:409-411, src/mkSatd.bsv:204-206) and that upstream
@@ -22,8 +22,13 @@
  *     Block layout is the reference's: row-major int16, blocks contiguous
  *     (32x32 = 2048 B per DCT block, 8x8 = 128 B per SATD block).
  *
- *  3. Small host utilities (word packing, device memory helpers) so that a
- *     pure-C host can drive the device-pointer API without HIP headers.
+ *  3. Small host utilities (word packing, device memory, streams, events,
+ *     graphs) so that a pure-C host can drive the device-pointer API without
+ *     HIP headers.
+ *
+ *  4. One node, several GPUs (BASELINE configs[4]): shards of a batch, a
+ *     pipelined frame stream and a striped motion search over RCCL send/recv
+ *     groups.  A node and its streams are driven by one host thread at a time.
  *
  * The library NEVER falls back to a CPU implementation: without a usable
  * gfx950 device every compute entry point fails (negative return; the BDPI
