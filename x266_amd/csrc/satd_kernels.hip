@@ -29,22 +29,20 @@
 namespace x266 {
 namespace {
 
-// sum over 16 accumulators of |(int16)(256*hi + lo)|
-__device__ __forceinline__ uint32_t abs_sum16(const v16i &hi, const v16i &lo, uint32_t sum)
+// sum over 16 accumulators of |(int16)x|, the accumulators holding x + 0x8000 in their low 16 bits (biased, see satd_group)
+__device__ __forceinline__ uint32_t abs_sum16(const v16i &acc, uint32_t sum)
 {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        const uint32_t a = ((uint32_t)hi[2 * m] << 8) + (uint32_t)lo[2 * m];
-        const uint32_t b = ((uint32_t)hi[2 * m + 1] << 8) + (uint32_t)lo[2 * m + 1];
-        // low halves of (a, b) side by side, biased so that unsigned |x - bias| = |int16|
-        const uint32_t pk = bperm(b, a, 0x05040100u) ^ 0x80008000u;
+        // low halves side by side: unsigned |biased - 0x8000| = |int16|, two per v_sad_u16
+        const uint32_t pk = bperm((uint32_t)acc[2 * m + 1], (uint32_t)acc[2 * m], 0x05040100u);
         sum = __builtin_amdgcn_sad_u16(pk, 0x80008000u, sum);
     }
     return sum;
 }
 
 // One 32-block group (held as the lane's 64-byte half of its block) -> 32 costs.
-struct SatdOperands { v4i h00, h01, h10, h11; v16i dcfix; };
+struct SatdOperands { v4i h00, h01, h10, h11; v16i dcfix; int dc0; };
 
 __device__ __forceinline__ SatdOperands make_satd_operands(int lane)
 {
@@ -66,28 +64,40 @@ __device__ __forceinline__ SatdOperands make_satd_operands(int lane)
     o.h01 = v4i{(int)(b0 ^ f4), (int)(b1 ^ f4), (int)(b2 ^ f4), (int)(b3 ^ f4)}; // tile 0, step 1: m bit 4 & step
     o.h10 = v4i{(int)(b0 ^ fh), (int)(b1 ^ fh), (int)(b2 ^ fh), (int)(b3 ^ fh)}; // tile 1, step 0: m bit 5 & s bit 5
     o.h11 = o.h01 ^ v4i{(int)fh, (int)fh, (int)fh, (int)fh};
-    // DC fix for the byte-plane offset: coefficient m = 0 lives in tile 0, reg 0, half 0
-    o.dcfix = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    o.dcfix[0] = half == 0 ? 128 * 64 : 0;
+    // Accumulator start of the HIGH byte plane, i.e. in units of 256: 128 = the int16 bias 0x8000 that lets v_sad_u16
+    // take |.| of the truncated coefficient directly, plus (coefficient m = 0: tile 0, reg 0, half 0) 32 = the byte-plane
+    // offset fix 128 * 64.  Both ride through the "<< 8" between the planes for free.
+    o.dcfix = v16i{128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
+    o.dc0 = half == 0 ? 32 : 0;
     return o;
 }
 
 __device__ __forceinline__ uint32_t satd_group(const SatdOperands &H, const v4i &w0, const v4i &w1, const v4i &w2, const v4i &w3)
 {
-    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     v4i lo0, hi0, lo1, hi1;
     split_planes(w0, w1, lo0, hi0);                     // K-step 0: samples 32*half + 0..15
     split_planes(w2, w3, lo1, hi1);                     // K-step 1: samples 32*half + 16..31
     uint32_t sum = 0;
+    // x = 256 * (H * hi) + H * lo: the planes are chained through ONE accumulator -- high plane, "<< 8" (a plain 2-cycle
+    // shift; the bias and the offset fix were put into the accumulator start at 1/256 scale), low plane on top.
     {   // coefficients 0..31
-        v16i ah = mfma(H.h00, hi0, zero);     ah = mfma(H.h01, hi1, ah);
-        v16i al = mfma(H.h00, lo0, H.dcfix);  al = mfma(H.h01, lo1, al);
-        sum = abs_sum16(ah, al, sum);
+        v16i a = mfma(H.h00, hi0, H.dcfix);
+        a = mfma(H.h01, hi1, a);
+        a[0] += H.dc0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = (int)((uint32_t)a[r] << 8);
+        a = mfma(H.h00, lo0, a);
+        a = mfma(H.h01, lo1, a);
+        sum = abs_sum16(a, sum);
     }
     {   // coefficients 32..63
-        v16i ah = mfma(H.h10, hi0, zero);     ah = mfma(H.h11, hi1, ah);
-        v16i al = mfma(H.h10, lo0, zero);     al = mfma(H.h11, lo1, al);
-        sum = abs_sum16(ah, al, sum);
+        v16i a = mfma(H.h10, hi0, H.dcfix);
+        a = mfma(H.h11, hi1, a);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = (int)((uint32_t)a[r] << 8);
+        a = mfma(H.h10, lo0, a);
+        a = mfma(H.h11, lo1, a);
+        sum = abs_sum16(a, sum);
     }
     // the other half of the coefficient rows sits in lane ^ 32
     sum += (uint32_t)__shfl_xor((int)sum, 32);
