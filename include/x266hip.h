@@ -371,6 +371,10 @@ void     xDct32PackDiffRows(const int16_t *mat, int first_row, unsigned int res[
 /* BDPI packing of 4 vertically adjacent coefficients, column-major walk:
  * idx -> col = idx>>5, row = idx&31 (src_tb/dct32.c:223-246). */
 uint64_t xDct32PackDctWord(const int16_t *dct, int idx);
+/* The N x N matrix the transform-set kernels use for a 1-D transform: type 0 = DCT-II (rows 0, 32/N, ... of g_t32,
+ * first N columns: the taps of src/mkDct32.bsv:132-141), 1 = DST-VII; N in {4, 8, 16} (and 32 for DCT-II).
+ * m[k*N + n], row k = frequency.  Lets a host (and the CPU tests) check the product's own tables. */
+int      xTransformMatrix(int type, int size, int16_t *m);
 const char *xHipVersion(void);
 
 /* ------------------------------------------------------------------------ */

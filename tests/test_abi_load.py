@@ -106,3 +106,26 @@ def test_node_layer_without_a_gpu(lib):
         assert lib.xHipDeviceCount() == 0
         with pytest.raises(x266_amd.X266Error):
             Node.single_process([0])
+
+
+def test_product_transform_matrices_match_the_oracle_and_the_closed_form(lib, oracle):
+    """The tables compiled into the product (x266_tables.hpp) -- not only the oracle's copies -- are the sub-matrices of
+    g_t32 and the DST-VII closed form round(64 sqrt(N) sqrt(4/(2N+1)) sin(pi (2k+1)(n+1)/(2N+1)))."""
+    lib.xTransformMatrix.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    g = oracle.table()
+    for ttype in (0, 1):
+        for n in (4, 8, 16, 32):
+            m = np.zeros((n, n), np.int16)
+            rc = lib.xTransformMatrix(ttype, n, m.ctypes.data)
+            if ttype == 1 and n == 32:
+                assert rc < 0
+                continue
+            assert rc == 0
+            assert np.array_equal(m, oracle.transform_matrix(ttype, n))
+            if ttype == 0:
+                assert np.array_equal(m, g[:: 32 // n, :n])
+            else:
+                k, c = np.arange(n)[:, None], np.arange(n)[None, :]
+                want = np.round(64 * np.sqrt(n) * np.sqrt(4.0 / (2 * n + 1)) * np.sin(np.pi * (2 * k + 1) * (c + 1) / (2 * n + 1)))
+                assert np.array_equal(m, want.astype(np.int16))
+    assert lib.xTransformMatrix(2, 8, None) < 0

@@ -36,6 +36,16 @@ void xDct32PackDiffRows(const int16_t *mat, int first_row, unsigned int res[32])
     }
 }
 
+int xTransformMatrix(int type, int size, int16_t *m)
+{
+    if (!m || (type != 0 && type != 1)) return X266HIP_EINVAL;
+    if (!(size == 4 || size == 8 || size == 16 || (size == 32 && type == 0))) return X266HIP_EINVAL;
+    const x266::Matrix32 t = x266::make_transform_matrix(type, size);       // block-diagonal 32x32: the first block is the matrix
+    for (int k = 0; k < size; ++k)
+        for (int n = 0; n < size; ++n) m[k * size + n] = t.v[k][n];
+    return X266HIP_OK;
+}
+
 uint64_t xDct32PackDctWord(const int16_t *dct, int idx)
 {
     const int col = idx >> 5, row = idx & 31;             // column-major walk, 4 rows per word
