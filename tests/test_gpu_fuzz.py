@@ -120,3 +120,65 @@ def test_motion_search_random(codec, oracle, wb, hb, rng, tile_rows, row_pairs, 
     omv, ocost, ocosts = oracle.satd_search(cur, refp, pad, rng, threads=8, want_costs=True, metric=metric)
     assert np.array_equal(costs, ocosts) and np.array_equal(cost, ocost) and np.array_equal(mv, omv)
     assert np.array_equal(cost2, ocost) and np.array_equal(mv2, omv)
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(bw=st.integers(1, 20), bh=st.integers(1, 20), rng=st.integers(1, 64), seed=st.integers(1, 1 << 20),
+       tile_rows=st.sampled_from([1, 2, 4, 8]), variant=st.sampled_from([3, 4]), wg=st.sampled_from([0, 256, 512]),
+       sad_variant=st.sampled_from([1, 2]))
+def test_motion_search_random_frames_ranges_and_shapes(codec, oracle, bw, bh, rng, seed, tile_rows, variant, wg, sad_variant):
+    """Every window remainder (2R+1 = 8F + rem, rem in {1, 3, 5, 7}, F from 0 to 16), ragged tiles, all tile shapes:
+    winners and costs of the SATD and SAD searches equal the oracle's brute force."""
+    from _util import me_frames
+    w, h = 8 * bw, 8 * bh
+    if bw * bh * (2 * rng + 1) ** 2 > 1_500_000:                      # keep the brute-force oracle within seconds
+        rng = max(1, rng // 4)
+    pad = rng + (seed & 3)
+    cur, refp = me_frames(w, h, pad, seed, mv=(min(rng, 2), -min(rng, 1)), noise=3)
+    saved = {k: codec.get_option(k) for k in ("me_tile_rows", "me_variant", "me_wg_threads", "sad_me_variant")}
+    try:
+        codec.set_option("me_tile_rows", tile_rows)
+        codec.set_option("me_variant", variant)
+        codec.set_option("me_wg_threads", wg if variant == 4 else min(wg, 256))
+        codec.set_option("sad_me_variant", sad_variant)
+        mv, cost, _ = codec.satd_search(cur, refp, pad, rng)
+        smv, scost, _ = codec.satd_search(cur, refp, pad, rng, metric="sad")
+    finally:
+        for k, v in saved.items():
+            codec.set_option(k, v)
+    omv, ocost, _ = oracle.satd_search(cur, refp, pad, rng, threads=8)
+    assert np.array_equal(cost, ocost) and np.array_equal(mv, omv), (w, h, rng, tile_rows, variant, wg)
+    omv, ocost, _ = oracle.satd_search(cur, refp, pad, rng, threads=8, metric="sad")
+    assert np.array_equal(scost, ocost) and np.array_equal(smv, omv), (w, h, rng, tile_rows, sad_variant)
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n_tiles=st.integers(1, 300), seed=st.integers(1, 1 << 20), inverse=st.integers(0, 1), tpw=st.integers(0, 5),
+       tpb=st.sampled_from([64, 128, 256]), kind=st.integers(0, 2))
+def test_mixed_class_tiles_random(codec, oracle, n_tiles, seed, inverse, tpw, tpb, kind):
+    """xTransformTilesDev: random class per tile (all 13 valid classes), random tiles per wave / workgroup size, three data
+    mixes -- equal to the oracle's per-class transforms tile by tile."""
+    rs = np.random.RandomState(seed)
+    valid = [t * 4 + l for t in range(4) for l in range(3)] + [3]       # (type, size 4/8/16) + (DCT-II, 32)
+    cls = np.array([valid[i] for i in rs.randint(0, len(valid), n_tiles)], np.uint8)
+    x = _data(kind, n_tiles, 1024, seed)
+    if inverse and kind != 0:
+        x = (x >> 2).astype(np.int16)                                    # keep coefficients in a sane range (clipping is still exercised by kind 2)
+    saved = {k: codec.get_option(k) for k in ("tile_tiles_per_wave", "dct32_wg_threads", "dct32_inv_wg_threads")}
+    try:
+        codec.set_option("tile_tiles_per_wave", tpw)
+        codec.set_option("dct32_wg_threads", tpb)
+        codec.set_option("dct32_inv_wg_threads", tpb)
+        din, dout, dcls = codec.alloc(n_tiles * 2048), codec.alloc(n_tiles * 2048), codec.alloc(max(n_tiles, 16))
+        din.upload(x)
+        dcls.upload(cls)
+        codec.transform_tiles_dev(inverse, din.ptr, dout.ptr, n_tiles, 0, dcls.ptr)
+        codec.stream_sync()
+        got = dout.download(np.int16, n_tiles * 1024).reshape(n_tiles, 1024)
+    finally:
+        for k, v in saved.items():
+            codec.set_option(k, v)
+    for t in range(n_tiles):
+        ttype, n = int(cls[t]) >> 2, (4, 8, 16, 32)[int(cls[t]) & 3]
+        fn = oracle.transform_inv if inverse else oracle.transform_fwd
+        assert np.array_equal(got[t], fn(ttype, n, x[t].reshape(-1, n * n)).ravel()), (t, ttype, n)
