@@ -8,6 +8,7 @@ host/stream8k.c, which validates any number of devices against the single-device
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -239,3 +240,19 @@ def test_multi_rank_batch_and_sharded_search(multi_node, codec, oracle):
         multi_node.satd_search(tc.data_ptr(), tc.stride(0), tr.data_ptr() + rng * tr.stride(0) + rng, tr.stride(0), w, h, rng, n_stripes, best.data_ptr())
         raw = best.cpu().numpy()
         assert np.array_equal(raw.view(np.int16).reshape(nb, 4)[:, :2], mv0) and np.array_equal(raw.view(np.uint32).reshape(nb, 2)[:, 1], cost0), n_stripes
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_rccl_transport_with_n_ranks_under_the_rccl_model(world):
+    """The node layer's RCCL code path itself -- the ncclGroupStart/End of ncclSend/ncclRecv it builds per step -- with
+    2, 3 and 8 ranks on this one GPU: tests/rccl_model/librccl_model.so (X266HIP_RCCL_LIB) stands in for librccl in a
+    separate process and pairs sends with receives the way RCCL does (k-th send a->b with the k-th receive on b from a,
+    equal sizes, anything unmatched = the hang it would be).  Frame stream, batch scatter-gather, sharded search and the
+    self-test must all equal the single-device results."""
+    model = os.path.join(ROOT, "tests", "rccl_model", "librccl_model.so")
+    assert os.path.exists(model), "tests/rccl_model/librccl_model.so is not built (make -C tests/rccl_model)"
+    env = dict(os.environ, X266HIP_RCCL_LIB=model)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_model", "run_node_under_model.py"), str(world)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ok all" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "falls back" not in r.stderr                                  # the RCCL transport ran, not the peer-copy fallback

@@ -49,8 +49,10 @@ Rccl *rccl()
     static bool tried = false;
     if (tried) return r.handle ? &r : nullptr;
     tried = true;
-    const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    // X266HIP_RCCL_LIB names the library to use instead (another RCCL build; the tests' single-process model)
+    const char *names[] = {std::getenv("X266HIP_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char *n : names) {
+        if (!n || !*n) continue;
         r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (r.handle) break;
     }
