@@ -607,11 +607,11 @@ int stream_step(x266hip_nstream *s, const void *const *d_in, void *const *d_out,
         DeviceScope dev(lr.device);
         if (p.done_recorded[slot]) {
             N_HIP(node, hipEventSynchronize(p.ev_done[slot]));
-            N_HIP(node, hipStreamWaitEvent(lr.comm_stream, p.ev_done[slot], 0));
+            if (W > 1) N_HIP(node, hipStreamWaitEvent(lr.comm_stream, p.ev_done[slot], 0));
         }
         if (lr.rank == root && has_frame) {                           // inputs come from the caller's stream
             N_HIP(node, hipEventRecord(p.ev_producer, (hipStream_t)producer_stream));
-            N_HIP(node, hipStreamWaitEvent(lr.comm_stream, p.ev_producer, 0));
+            if (W > 1) N_HIP(node, hipStreamWaitEvent(lr.comm_stream, p.ev_producer, 0));
             N_HIP(node, hipStreamWaitEvent(lr.compute_stream, p.ev_producer, 0));
         }
     }
@@ -660,8 +660,10 @@ int stream_step(x266hip_nstream *s, const void *const *d_in, void *const *d_out,
         LocalRank &lr = node->local[i];
         x266hip_nstream::PerRank &p = s->per[i];
         DeviceScope dev(lr.device);
-        N_HIP(node, hipEventRecord(p.ev_xfer[slot], lr.comm_stream));
-        p.xfer_recorded[slot] = true;
+        if (W > 1) {                                                    // one rank: nothing travels, the communication stream stays idle
+            N_HIP(node, hipEventRecord(p.ev_xfer[slot], lr.comm_stream));
+            p.xfer_recorded[slot] = true;
+        }
         if (!has_frame) continue;
         if (lr.rank != root) N_HIP(node, hipStreamWaitEvent(lr.compute_stream, p.ev_xfer[slot], 0));   // the root works in place: nothing to wait for
         for (int l = 0; l < s->n_lanes; ++l) {
