@@ -258,8 +258,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libx266hip has no CPU path")
     # Test hook (never set by the driver): X266_BENCH_SHARE_GPU=1 lets several ranks share the visible
     # GPUs with the control-plane collectives on gloo, so that the N > 1 code path -- shard offsets,
-    # max-over-ranks timing, checksum reduction -- can be exercised on a one-GPU box (the node-layer legs
-    # are skipped there: RCCL refuses two ranks on one device).
+    # max-over-ranks timing, checksum reduction -- can be exercised on a one-GPU box.  RCCL refuses two ranks on
+    # one device, so the node-layer legs run there only when X266HIP_RCCL_LIB names the tests' RCCL model.
     share = os.environ.get("X266_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = local_rank % torch.cuda.device_count()
@@ -609,7 +609,7 @@ def main():
         result["also"] = also
         result["secondary"] = {"metric": "satd8x8_blocks_per_s", "value": also["satd8x8"]["value"], "unit": "blocks/s",
                                "roofline_frac": also["satd8x8"]["roofline"]["frac"]}
-        if ctrl == "cuda" and args.stream8k > 0:
+        if (ctrl == "cuda" or os.environ.get("X266HIP_RCCL_LIB")) and args.stream8k > 0:
             def node_timed_out():
                 also["node_layer_error"] = "node-layer legs did not finish within %.0f s (RCCL hang?); line printed without them" % args.node_timeout
                 if rank == 0:
@@ -624,7 +624,7 @@ def main():
             def node_legs():
                 uid = [Node.unique_id() if rank == 0 else None]
                 if dist is not None:
-                    dist.broadcast_object_list(uid, src=0, device=torch.device("cuda", local_rank))
+                    dist.broadcast_object_list(uid, src=0, device=torch.device("cuda", local_rank) if ctrl == "cuda" else None)
                 node = Node.for_rank(local_rank, rank, world, uid[0])      # xHipNodeInitRank: one process per GPU, also at N = 1
                 node.self_test()                                            # RCCL ring send/recv + all-reduce, checked
                 fw8, fh8 = 7680, 4320

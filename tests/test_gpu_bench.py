@@ -70,3 +70,30 @@ def test_bench_two_ranks_share_the_gpu_and_agree_with_one_rank():
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["cpu_baseline"] is None
     assert two["output_checksum_sum_i16"] == one["output_checksum_sum_i16"]
     assert two["config"]["blocks_per_gpu"] == n
+
+
+def test_bench_node_legs_with_two_processes_under_the_rccl_model():
+    """bench.py --gpus 2 with its node-layer legs (stream8k, scatter-gather, sharded search) in two processes on this one GPU:
+    control plane on gloo, the library's RCCL calls served by tests/rccl_model (multi-process mode).  The rates mean
+    nothing here; the legs must complete, match the single-device results, and leave exactly one JSON line."""
+    import socket
+    model = os.path.join(ROOT, "tests", "rccl_model", "librccl_model.so")
+    assert os.path.exists(model)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, X266_BENCH_SHARE_GPU="1", X266HIP_RCCL_LIB=model, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--dct-blocks", "16384", "--satd-blocks", "65536", "--stream8k", "6", "--no-transform-set", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    also = d["also"]
+    assert "node_layer_error" not in also, also.get("node_layer_error")
+    assert also["stream8k"]["bit_exact_vs_single_device"] is True and also["stream8k"]["frames"] == 6
+    assert also["dct32_scatter_gather"]["value"] > 0
+    assert also["satd8x8_me_search_sharded"]["identical_to_single_device"] is True and also["satd8x8_me_search_sharded"]["stripes"] == 2

@@ -256,3 +256,18 @@ def test_rccl_transport_with_n_ranks_under_the_rccl_model(world):
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ok all" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     assert "falls back" not in r.stderr                                  # the RCCL transport ran, not the peer-copy fallback
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_one_process_per_rank_under_the_rccl_model(world):
+    """The node layer as bench.py drives it under torch.distributed.run -- xHipNodeInitRank in `world` PROCESSES, the root
+    pushing frames and the peers pushing nothing -- on this one GPU: the model's multi-process mode (shared-memory
+    rendezvous, host-staged copies) stands in for librccl.  Frame streams up to 7680x4320, batch scatter-gather and the sharded
+    search, all bit-exact against the single-device calls; an unmatched or mis-sized transfer fails instead of hanging."""
+    model = os.path.join(ROOT, "tests", "rccl_model", "librccl_model.so")
+    assert os.path.exists(model), "tests/rccl_model/librccl_model.so is not built (make -C tests/rccl_model)"
+    env = dict(os.environ, X266HIP_RCCL_LIB=model, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_model", "run_ranks_under_model.py"), str(world)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok all" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "ok sharded motion search" in r.stdout and "7680x4320" in r.stdout
