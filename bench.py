@@ -694,7 +694,7 @@ def main():
                 barrier()
                 wall_sg = max_over_ranks(time.perf_counter() - t0) / 4
                 also["dct32_scatter_gather"] = {"value": nsg / wall_sg, "unit": "blocks/s", "blocks": nsg,
-                                                "note": "root-resident batch cut into 4096-block chunks, pipelined through the node stream "
+                                                "note": "root-resident batch cut into chunks (8 MiB of input per rank), pipelined through the node stream "
                                                         "(xNodeBatchScatterGather); at N = 1 no transfer"}
                 if not args.no_me:
                     # sharded motion search: stripes + halo from the root, records back (xNodeSatd8x8Search)

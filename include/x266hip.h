@@ -347,8 +347,8 @@ int  xNodeStreamFlush(x266hip_nstream *s);
  * the step's shard has left (peers).  No communication; EINVAL when fewer than two later steps exist. */
 int  xNodeStreamWait(x266hip_nstream *s, long ticket);
 /* One batch through the same machinery (SURVEY 8e "end-to-end scatter -> compute -> gather"): the batch
- * is cut into chunks of chunk_units (0: 4096 DCT blocks / 65536 SATD blocks), pushed as frames, flushed.
- * Synchronous.  d_in / d_out on the root as above. */
+ * is cut into chunks of chunk_units (0 = default: one launch with one rank, else 8 MiB of input per
+ * rank and chunk but at least four chunks), pushed as frames, flushed.  Synchronous.  d_in / d_out on the root as above. */
 int  xNodeBatchScatterGather(x266hip_node *node, int op, const void *d_in, void *d_out, size_t n_units,
                              size_t chunk_units);
 /* Full-search motion estimation of one frame over the node (xSatd8x8SearchDev semantics and argument

@@ -725,7 +725,13 @@ int xNodeBatchScatterGather(x266hip_node *node, int op, const void *d_in, void *
 {
     if (!node || op < 0 || op > 2) return X266HIP_EINVAL;
     if (n_units == 0) return X266HIP_OK;
-    if (chunk_units == 0) chunk_units = op == 2 ? 65536 : 4096;
+    if (chunk_units == 0) {
+        // one rank: nothing travels, so nothing to pipeline -- one launch.  Otherwise 8 MiB of input per rank and chunk
+        // (about 50 us on an xGMI link, well above a group's launch cost), but at least four chunks to overlap
+        const size_t floor_units = (size_t)(8u << 20) / kInUnit[op];
+        chunk_units = node->world == 1 ? n_units : floor_units * (size_t)node->world;
+        if (node->world > 1 && chunk_units > n_units / 4) chunk_units = n_units / 4 > floor_units ? n_units / 4 : floor_units;
+    }
     if (chunk_units > n_units) chunk_units = n_units;
     x266hip_nstream *s = nullptr;
     int rc = xNodeStreamCreate(node, 1, &op, &chunk_units, &s);
