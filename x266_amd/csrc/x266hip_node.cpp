@@ -19,6 +19,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -43,13 +45,9 @@ struct Rccl {
     std::string why;
 };
 
-Rccl *rccl()
+void load_rccl(Rccl &r)
 {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.handle ? &r : nullptr;
-    tried = true;
-    // X266HIP_RCCL_LIB names the library to use instead (another RCCL build; the tests' single-process model)
+    // X266HIP_RCCL_LIB names the library to use instead (another RCCL build; the tests' RCCL model)
     const char *names[] = {std::getenv("X266HIP_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char *n : names) {
         if (!n || !*n) continue;
@@ -57,8 +55,9 @@ Rccl *rccl()
         if (r.handle) break;
     }
     if (!r.handle) {
-        r.why = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
-        return nullptr;
+        const char *why = dlerror();
+        r.why = std::string("dlopen(librccl.so.1): ") + (why ? why : "not found");
+        return;
     }
     bool ok = true;
 #define X_SYM(field, name) ok = ok && ((r.field = (decltype(r.field))dlsym(r.handle, name)) != nullptr)
@@ -77,9 +76,15 @@ Rccl *rccl()
         r.why = "librccl.so.1 lacks an expected symbol";
         dlclose(r.handle);
         r.handle = nullptr;
-        return nullptr;
     }
-    return &r;
+}
+
+Rccl *rccl()                               // loaded once, whichever thread asks first
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, load_rccl, std::ref(r));
+    return r.handle ? &r : nullptr;
 }
 
 struct DeviceScope {                       // the caller's current device is put back on exit
