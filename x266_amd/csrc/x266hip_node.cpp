@@ -79,11 +79,17 @@ void load_rccl(Rccl &r)
     }
 }
 
-Rccl *rccl()                               // loaded once, whichever thread asks first
+Rccl &rccl_state()                         // loaded once, whichever thread asks first
 {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, load_rccl, std::ref(r));
+    return r;
+}
+
+Rccl *rccl()
+{
+    Rccl &r = rccl_state();
     return r.handle ? &r : nullptr;
 }
 
@@ -355,7 +361,7 @@ int xHipNodeInit(x266hip_node **out, const int *devices, int n_devices)
             node->err = std::string("ncclCommInitAll: ") + R->GetErrorString(r);
         }
     } else {
-        node->err = "RCCL unavailable";
+        node->err = "RCCL unavailable: " + rccl_state().why;
     }
     if (!node->have_rccl) {                 // a single-process node can still move shards with peer copies
         std::fprintf(stderr, "x266hip: node falls back to hipMemcpyPeerAsync transport (%s)\n", node->err.c_str());
@@ -383,7 +389,7 @@ int xHipNodeInitRank(x266hip_node **out, int device, int rank, int world, const 
     *out = nullptr;
     Rccl *R = rccl();
     if (!R) {
-        std::fprintf(stderr, "x266hip: RCCL is required for a process-per-GPU node and could not be loaded\n");
+        std::fprintf(stderr, "x266hip: RCCL is required for a process-per-GPU node and could not be loaded (%s)\n", rccl_state().why.c_str());
         return X266HIP_ECOMM;
     }
     x266hip_node *node = new (std::nothrow) x266hip_node;
