@@ -28,6 +28,8 @@
 // The bound is VALU issue (v_sad_u16), not HBM: the frame pair is ~18 MB.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdint>
 
 #include "x266_device.hpp"
@@ -1110,11 +1112,14 @@ __global__ __launch_bounds__(256) void sad_search_kernel_v2(const MeParams P)
                 for (int k = 0; k < 8; ++k) acc[j][k] = 0;
             uint32_t pid = (uint32_t)col + ((uint32_t)(-7) << 8);       // position of the candidate finished by row ry: (ry - 7, col)
             const uint32_t dead = lane_ok ? 0u : 0xFFFFFFFFu;           // masked pass: lanes beyond the window get the all-ones key, once per row
-            for (int ry8 = 0; ry8 < win_rows; ry8 += 8) {
+            // Eight window rows.  STEADY: every block row of the tile is inside its band and finishes a candidate on every
+            // one of the eight rows (all but the first and last few groups), so the body carries no wave-uniform tests at all.
+            auto rows8 = [&](auto steady_tag, int ry8) {
+                constexpr bool STEADY = decltype(steady_tag)::value;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const int ry = ry8 + m;
-                    if (ry >= win_rows) break;                           // wave-uniform
+                    if (!STEADY && ry >= win_rows) break;                // wave-uniform
                     const uint32_t *q = reinterpret_cast<const uint32_t *>(colbase + ry * P.pitch);
                     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
                     const uint32_t a0 = __builtin_amdgcn_alignbit(d1, d0, sh), a1 = __builtin_amdgcn_alignbit(d2, d1, sh);
@@ -1122,7 +1127,7 @@ __global__ __launch_bounds__(256) void sad_search_kernel_v2(const MeParams P)
 #pragma unroll
                     for (int j = 0; j < TBY; ++j) {
                         const int rel = ry - 8 * j;                      // row inside block row j's band
-                        if (rel < 0 || rel >= span + 7 || j >= blocks_left_y) continue;      // wave-uniform
+                        if (!STEADY && (rel < 0 || rel >= span + 7 || j >= blocks_left_y)) continue;      // wave-uniform
 #pragma unroll
                         for (int p = 0; p < 8; ++p) {
                             const int slot = (m - p) & 7;
@@ -1130,7 +1135,7 @@ __global__ __launch_bounds__(256) void sad_search_kernel_v2(const MeParams P)
                             acc[j][slot] = __builtin_amdgcn_sad_u8(a1, c[j][p][1], __builtin_amdgcn_sad_u8(a0, c[j][p][0], init));
                         }
                         const int dyi = rel - 7;                         // the candidate row that has now seen all 8 block rows
-                        if (dyi >= 0 && dyi < span) {                    // wave-uniform
+                        if (STEADY || (dyi >= 0 && dyi < span)) {        // wave-uniform
                             const uint32_t cost = acc[j][(m + 1) & 7];
                             const uint32_t key = (cost << 16) | pidm;
                             best[j] = key < best[j] ? key : best[j];
@@ -1142,6 +1147,12 @@ __global__ __launch_bounds__(256) void sad_search_kernel_v2(const MeParams P)
                     }
                     pid += 256u;
                 }
+            };
+            const bool full_tile = blocks_left_y == TBY;
+            for (int ry8 = 0; ry8 < win_rows; ry8 += 8) {
+                // steady: min rel = ry8 - 8 (TBY - 1) >= 7 and max rel = ry8 + 7 < span + 7
+                if (full_tile && ry8 >= 8 * TBY && ry8 < span) rows8(std::true_type{}, ry8);
+                else                                           rows8(std::false_type{}, ry8);
             }
         } else {
             // narrow pass: one extra column, lane = candidate row (window row 64 * chunk + lane)
