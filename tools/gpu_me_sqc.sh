@@ -1,6 +1,8 @@
-R=${GRAFT_REPO_ROOT}
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# Scalar data-cache and instruction-cache counters of the motion-search kernels (run through gpurun): one PMC pass over tools/gpu_me_probe.py
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 -L 2>/dev/null | grep -i "SQC_DCACHE\|SQC_TC_\|SQC_ICACHE" | head -30
+
 rocprofv3 --kernel-trace --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_ICACHE_REQ SQC_ICACHE_MISSES --output-format csv -d $R/gpurun_out/me_sqc -- python $R/tools/gpu_me_probe.py satd > /dev/null 2>&1
 cd $R
 python - <<EOF
