@@ -271,3 +271,21 @@ def test_one_process_per_rank_under_the_rccl_model(world):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok all" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
     assert "ok sharded motion search" in r.stdout and "7680x4320" in r.stdout
+
+
+@pytest.mark.parametrize("n_ranks,size", [(1, (7680, 4320)), (3, (1920, 1088)), (4, (7680, 4320))])
+def test_plain_c_host_with_one_process_per_rank(n_ranks, size):
+    """host/stream8k_ranks.c: fork before HIP, rank 0 hands the RCCL id to the others through pipes, xHipNodeInitRank in
+    every process, the same Push / Flush sequence everywhere -- from plain C.  One rank runs on real RCCL; more than one
+    rank on this one GPU needs the RCCL model (multi-process mode)."""
+    exe = os.path.join(ROOT, "host", "stream8k_ranks")
+    assert os.path.exists(exe), "host/stream8k_ranks is not built (make -C host)"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if n_ranks > 1:
+        model = os.path.join(ROOT, "tests", "rccl_model", "librccl_model.so")
+        assert os.path.exists(model)
+        env["X266HIP_RCCL_LIB"] = model
+    r = subprocess.run([exe, str(n_ranks), "12", str(size[0]), str(size[1])], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["processes"] == n_ranks and d["bit_exact_vs_single_device"] is True and d["frames"] == 12
