@@ -371,6 +371,11 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
 ncclResult_t ncclCommDestroy(ncclComm_t comm)
 {
     if (comm && comm->mp) {
+        Mp *mp = comm->mp;
+        for (int dst = 0; dst < mp->nranks; ++dst) {                     // staging files nobody came for (a failed run)
+            MpPair &q = mp->sh->pair[mp->rank][dst];
+            for (uint64_t seq = q.consumed.load(); seq < q.posted.load(); ++seq) unlink(stage_name(mp, mp->rank, dst, seq).c_str());
+        }
         munmap(comm->mp->sh, sizeof(MpShared));
         delete comm->mp;
     }
