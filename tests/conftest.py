@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# Some GPU tests use torch for device memory next to the library.  The torch wheel bundles its own HIP runtime with the
+# same SONAME as ROCm's, and torch only finds the GPU behind its own copy: whichever test
+# runs first, torch's copy has to be the one the process loads.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

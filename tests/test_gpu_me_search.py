@@ -90,3 +90,23 @@ def test_full_frame_4k_sampled(codec, oracle):
         omv, ocost, _ = oracle.satd_search(cs, rs, pad, rng, threads=oracle.hw_threads())
         assert np.array_equal(mv[by * bxn:(by + 1) * bxn], omv)
         assert np.array_equal(cost[by * bxn:(by + 1) * bxn], ocost)
+
+
+@pytest.mark.parametrize("w,h,rng", [(640, 360, 64), (1280, 136, 64), (3840, 136, 64), (3840, 544, 64), (200, 72, 20), (1920, 1080, 64)])
+def test_automatic_tile_height_changes_nothing_but_the_time(codec, w, h, rng):
+    """"me_tile_rows" = 0 (the default) picks 8-, 4- or 2-row tiles from the frame size; whatever it picks, mv, cost and
+    the SAD search's winners equal those of explicitly chosen tile heights (each checked against the oracle above)."""
+    assert codec.get_option("me_tile_rows") == 0                     # the default is the automatic choice
+    h -= h % 8
+    cur, refp = me_frames(w, h, rng, 31 + w, mv=(3, -2), noise=3)
+    got = codec.satd_search(cur, refp, rng, rng)
+    got_sad = codec.satd_search(cur, refp, rng, rng, metric="sad")
+    try:
+        for tr in (8, 4, 2):
+            codec.set_option("me_tile_rows", tr)
+            mv, cost, _ = codec.satd_search(cur, refp, rng, rng)
+            assert np.array_equal(mv, got[0]) and np.array_equal(cost, got[1]), tr
+            mv, cost, _ = codec.satd_search(cur, refp, rng, rng, metric="sad")
+            assert np.array_equal(mv, got_sad[0]) and np.array_equal(cost, got_sad[1]), tr
+    finally:
+        codec.set_option("me_tile_rows", 0)

@@ -38,10 +38,10 @@ if what in ("satd", "all"):
         if ref is None: ref = res
         print("satd variant=%d tile_rows=%d units=%d wg=%3d splits=%d: median %.3f ms (min %.3f)  %.3e SATD/s  frac_of_floor %.3f  same_result=%s"
               % (var, tr, rp, wg, sp, med, mn, ncand / med * 1e3, 1.7554 / med, bool(torch.equal(res, ref))), flush=True)
-    cd.set_option("me_tile_rows", 8); cd.set_option("me_variant", 4); cd.set_option("me_row_pairs", 2); cd.set_option("me_wg_threads", 0); cd.set_option("me_splits", 0)
+    cd.set_option("me_tile_rows", 0); cd.set_option("me_variant", 4); cd.set_option("me_row_pairs", 2); cd.set_option("me_wg_threads", 0); cd.set_option("me_splits", 0)
 if what in ("sad", "all"):
     for var, tr in ((1, 4), (2, 4), (2, 2)):
         cd.set_option("me_tile_rows", tr); cd.set_option("sad_me_variant", var)
         med, mn = timed(lambda: cd.sad_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr()))
         print("SAD search variant=%d tile_rows=%d: median %.3f ms (min %.3f)  %.3e SAD/s  frac_of_floor %.3f" % (var, tr, med, mn, ncand / med * 1e3, 0.8777 / med), flush=True)
-    cd.set_option("me_tile_rows", 8); cd.set_option("sad_me_variant", 2)
+    cd.set_option("me_tile_rows", 0); cd.set_option("sad_me_variant", 2)

@@ -1225,6 +1225,22 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
     P.width = width; P.height = height; P.range = range;
     P.blocks_x = width / 8; P.blocks_y = height / 8;
     P.tiles_x = (P.blocks_x + kTileBlocksX - 1) / kTileBlocksX;
+    if (tile_rows <= 0 && variant == 4) {
+        // Tile height by frame size.  Measured (profiles/r02_me_sizes.txt, R = 64, 256 CUs): a launch of T tiles takes about
+        // L + (ceil(T / CUs) - 1) * S with (L, S) = (0.40, 0.30) ms for 8-row tiles, (0.23, 0.167) for 4 and (0.146, 0.098) for 2
+        // -- a lone tile costs L whatever the chip could do next to it, and tall tiles halve the position transforms per
+        // block.  4K frames want 8 rows, a 544-row stripe 4, a 360p frame 2; only the ratios matter, they hold for any range.
+        const int cus = cu_count > 0 ? cu_count : 256;
+        const float L[3] = {4.0f, 2.3f, 1.46f}, S[3] = {3.0f, 1.67f, 0.98f};
+        const int cand[3] = {8, 4, 2};
+        float best_t = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const long long tiles = (long long)P.tiles_x * ((P.blocks_y + cand[c] - 1) / cand[c]);
+            const float t = L[c] + (float)((tiles + cus - 1) / cus - 1) * S[c];
+            if (c == 0 || t < best_t) { best_t = t; tile_rows = cand[c]; }
+        }
+    }
+    if (tile_rows <= 0) tile_rows = 4;                               // the earlier variants: their measured best
     const int tby = (tile_rows == 8 && variant == 4) ? 8 : (tile_rows >= 4 ? 4 : (tile_rows == 1 ? 1 : 2));
     const int tiles_y = (P.blocks_y + tby - 1) / tby;
     const int span = 2 * range + 1;
@@ -1323,7 +1339,7 @@ hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const u
     P.width = width; P.height = height; P.range = range;
     P.blocks_x = width / 8; P.blocks_y = height / 8;
     P.tiles_x = (P.blocks_x + kTileBlocksX - 1) / kTileBlocksX;
-    const int tby = tile_rows >= 4 ? 4 : (tile_rows == 1 ? 1 : 2);
+    const int tby = tile_rows >= 4 ? 4 : (tile_rows == 1 ? 1 : 2);   // 0 (automatic) = 2: as fast as 4 on a 4K frame, finer-grained on small ones
     const int tiles_y = (P.blocks_y + tby - 1) / tby;
     const int span = 2 * range + 1;
     P.n_groups = (8 * (kTileBlocksX - 1) + span + 63) / 64;           // 64-column groups (lane = column)

@@ -45,7 +45,7 @@ struct x266hip_ctx {
     int wg_threads = 256;
     int satd_wg_threads = 128;                      // SATD batch (staged): two-wave workgroups, 2 groups per wave (profiles/r01_satd_staged_nt.txt)
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
-    int me_tile_rows = 8;                           // block rows per ME tile (1, 2, 4; 8 for variant 4 -- other variants and the SAD search use min(this, 4))
+    int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (variant 4: 8, 4 or 2; SAD search: 2), else 1, 2, 4, 8 (8: variant 4 only)
     int me_row_pairs = 2;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
     int me_variant = 4;                             // 1 = LDS coefficients, 2 = scalar coefficients, 3 = scalar coefficients, 16x4 units, position keys (me_kernels.hip)
     int intra_rounds = 4;                           // intra prediction: rounds of seven predictions per wave (next round's reference sets prefetched)
@@ -324,7 +324,7 @@ static const OptionDesc kOptions[] = {
     {"dct32_lds_pad_bytes", &x266hip_ctx::lds_pad_dct, 0, 160 * 1024, 1},
     {"dct32_inv_lds_pad_bytes", &x266hip_ctx::lds_pad_inv, 0, 160 * 1024, 1},
     {"satd_lds_pad_bytes", &x266hip_ctx::lds_pad_satd, 0, 160 * 1024, 1},
-    {"me_tile_rows", &x266hip_ctx::me_tile_rows, 1, 8, 1},
+    {"me_tile_rows", &x266hip_ctx::me_tile_rows, 0, 8, 1},
     {"me_variant", &x266hip_ctx::me_variant, 1, 4, 1},
     {"sad_me_variant", &x266hip_ctx::sad_me_variant, 1, 2, 1},
     {"intra_rounds", &x266hip_ctx::intra_rounds, 1, 16, 1},
