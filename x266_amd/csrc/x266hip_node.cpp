@@ -110,6 +110,7 @@ struct LocalRank {
     x266hip_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     hipStream_t comm_stream = nullptr, compute_stream = nullptr;
+    hipStream_t compute_stream_odd = nullptr;  // frames of odd steps: consecutive frames share nothing, so their kernels may overlap
     std::vector<DevBuf> me_bufs;           // motion-search stripe buffers (cur, ref, best per owned stripe)
     DevBuf selftest;
 };
@@ -205,6 +206,7 @@ int open_rank(x266hip_node *node, LocalRank &lr)
     DeviceScope dev(lr.device);
     N_HIP(node, hipStreamCreateWithFlags(&lr.comm_stream, hipStreamNonBlocking));
     N_HIP(node, hipStreamCreateWithFlags(&lr.compute_stream, hipStreamNonBlocking));
+    N_HIP(node, hipStreamCreateWithFlags(&lr.compute_stream_odd, hipStreamNonBlocking));
     return X266HIP_OK;
 }
 
@@ -215,13 +217,13 @@ LocalRank *root_rank(x266hip_node *node)
     return nullptr;
 }
 
-int launch(x266hip_node *node, LocalRank &lr, int op, const void *in, void *out, size_t n)
+int launch(x266hip_node *node, LocalRank &lr, int op, const void *in, void *out, size_t n, hipStream_t stream)
 {
     if (n == 0) return X266HIP_OK;
     switch (op) {
-    case 0: N_X(node, lr, xDct32FwdBatchDev(lr.ctx, (const int16_t *)in, (int16_t *)out, n, lr.compute_stream)); break;
-    case 1: N_X(node, lr, xDct32InvBatchDev(lr.ctx, (const int16_t *)in, (int16_t *)out, n, lr.compute_stream)); break;
-    default: N_X(node, lr, xSatd8x8BatchDev(lr.ctx, (const int16_t *)in, (uint32_t *)out, n, lr.compute_stream)); break;
+    case 0: N_X(node, lr, xDct32FwdBatchDev(lr.ctx, (const int16_t *)in, (int16_t *)out, n, stream)); break;
+    case 1: N_X(node, lr, xDct32InvBatchDev(lr.ctx, (const int16_t *)in, (int16_t *)out, n, stream)); break;
+    default: N_X(node, lr, xSatd8x8BatchDev(lr.ctx, (const int16_t *)in, (uint32_t *)out, n, stream)); break;
     }
     return X266HIP_OK;
 }
@@ -315,12 +317,14 @@ void xHipNodeFree(x266hip_node *node)
         DeviceScope dev(lr.device);
         if (lr.comm_stream) (void)hipStreamSynchronize(lr.comm_stream);
         if (lr.compute_stream) (void)hipStreamSynchronize(lr.compute_stream);
+        if (lr.compute_stream_odd) (void)hipStreamSynchronize(lr.compute_stream_odd);
         if (lr.comm && R) (void)R->CommDestroy(lr.comm);
         for (DevBuf &b : lr.me_bufs)
             if (b.p) (void)hipFree(b.p);
         if (lr.selftest.p) (void)hipFree(lr.selftest.p);
         if (lr.comm_stream) (void)hipStreamDestroy(lr.comm_stream);
         if (lr.compute_stream) (void)hipStreamDestroy(lr.compute_stream);
+        if (lr.compute_stream_odd) (void)hipStreamDestroy(lr.compute_stream_odd);
         if (lr.ctx) xHipCodecFree(lr.ctx);
     }
     delete node;
@@ -516,6 +520,7 @@ void xNodeStreamFree(x266hip_nstream *s)
         DeviceScope dev(lr.device);
         (void)hipStreamSynchronize(lr.comm_stream);
         (void)hipStreamSynchronize(lr.compute_stream);
+        (void)hipStreamSynchronize(lr.compute_stream_odd);
         x266hip_nstream::PerRank &p = s->per[i];
         for (int sl = 0; sl < x266hip_nstream::kSlots; ++sl) {
             for (int l = 0; l < 4; ++l) {
@@ -623,7 +628,7 @@ int stream_step(x266hip_nstream *s, const void *const *d_in, void *const *d_out,
         if (lr.rank == root && has_frame) {                           // inputs come from the caller's stream
             N_HIP(node, hipEventRecord(p.ev_producer, (hipStream_t)producer_stream));
             if (W > 1) N_HIP(node, hipStreamWaitEvent(lr.comm_stream, p.ev_producer, 0));
-            N_HIP(node, hipStreamWaitEvent(lr.compute_stream, p.ev_producer, 0));
+            N_HIP(node, hipStreamWaitEvent(slot ? lr.compute_stream_odd : lr.compute_stream, p.ev_producer, 0));
         }
     }
     if (node->transport == 1 && has_frame && drives_root) {           // peer copies run on the PEERS' streams and read the root's frame
@@ -676,16 +681,17 @@ int stream_step(x266hip_nstream *s, const void *const *d_in, void *const *d_out,
             p.xfer_recorded[slot] = true;
         }
         if (!has_frame) continue;
-        if (lr.rank != root) N_HIP(node, hipStreamWaitEvent(lr.compute_stream, p.ev_xfer[slot], 0));   // the root works in place: nothing to wait for
+        hipStream_t cs = slot ? lr.compute_stream_odd : lr.compute_stream;   // the slot's own stream: frame t-2 (same buffers) is ahead of frame t on it
+        if (lr.rank != root) N_HIP(node, hipStreamWaitEvent(cs, p.ev_xfer[slot], 0));   // the root works in place: nothing to wait for
         for (int l = 0; l < s->n_lanes; ++l) {
             size_t b, e;
             shard(cur.units[l], lr.rank, W, &b, &e);
             const void *in = lr.rank == root ? (const void *)(cur.d_in[l] + b * kInUnit[s->op[l]]) : p.in[slot][l];
             void *out = lr.rank == root ? (void *)(cur.d_out[l] + b * kOutUnit[s->op[l]]) : p.out[slot][l];
-            rc = launch(node, lr, s->op[l], in, out, e - b);
+            rc = launch(node, lr, s->op[l], in, out, e - b, cs);
             if (rc) return rc;
         }
-        N_HIP(node, hipEventRecord(p.ev_done[slot], lr.compute_stream));
+        N_HIP(node, hipEventRecord(p.ev_done[slot], cs));
         p.done_recorded[slot] = true;
     }
     s->n_steps = t + 1;
@@ -715,6 +721,7 @@ int xNodeStreamFlush(x266hip_nstream *s)
         DeviceScope dev(lr.device);
         N_HIP(s->node, hipStreamSynchronize(lr.comm_stream));
         N_HIP(s->node, hipStreamSynchronize(lr.compute_stream));
+        N_HIP(s->node, hipStreamSynchronize(lr.compute_stream_odd));
     }
     return X266HIP_OK;
 }
