@@ -339,7 +339,9 @@ void xNodeStreamFree(x266hip_nstream *s);
  * (NULL: the stream's max_units) must be the same on every rank.  producer_stream: the root-device
  * stream the inputs were produced on (ordering by event; NULL = the default stream).
  * Inputs of a step may be overwritten, and its ticket waited for, once two later steps have been issued
- * (Push or Flush).  *ticket (may be NULL) receives t. */
+ * (Push or Flush); until then its buffers belong to the stream -- the kernels of consecutive frames run on
+ * two alternating streams and may overlap, so frames t and t+1 must not share buffers.  *ticket (may be NULL)
+ * receives t. */
 int  xNodeStreamPush(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units,
                      void *producer_stream, long *ticket);
 /* Issues the two draining steps and blocks until every pushed frame's results are in place. */
