@@ -242,6 +242,37 @@ def test_multi_rank_batch_and_sharded_search(multi_node, codec, oracle):
         assert np.array_equal(raw.view(np.int16).reshape(nb, 4)[:, :2], mv0) and np.array_equal(raw.view(np.uint32).reshape(nb, 2)[:, 1], cost0), n_stripes
 
 
+def test_multi_rank_stream_with_ragged_unit_counts(multi_node, oracle):
+    """Unit counts that change from frame to frame -- zero, one, fewer than ranks, not divisible -- through the pipelined
+    stream with 2, 3 and 5 ranks: every shard boundary and every skipped (empty) transfer must agree on both ends."""
+    dev = torch.device("cuda", 0)
+    caps = [37, 1003, 37]
+    st = multi_node.stream([OP_DCT32_INV, OP_SATD8X8, OP_DCT32_FWD], caps)
+    z = torch.from_numpy(oracle.fill_residual(caps[0] * 1024, 15)).to(dev)
+    d = torch.from_numpy(oracle.fill_residual(caps[1] * 64, 16)).to(dev)
+    zh, dh = z.cpu().numpy(), d.cpu().numpy()
+    rs = np.random.RandomState(multi_node.world)
+    plans = [[37, 1003, 37], [0, 0, 0], [1, 1, 1], [multi_node.world - 1, multi_node.world + 1, 0], [0, 7, 36]]
+    plans += [[int(rs.randint(0, c + 1)) for c in caps] for _ in range(7)]
+    outs = []
+    for units in plans:                                              # all frames in flight back to back, distinct output buffers
+        o = (torch.zeros(caps[0] * 1024, dtype=torch.int16, device=dev), torch.zeros(caps[1], dtype=torch.int32, device=dev),
+             torch.zeros(caps[2] * 1024, dtype=torch.int16, device=dev))
+        outs.append(o)
+        torch.cuda.synchronize()
+        st.push([z.data_ptr(), d.data_ptr(), z.data_ptr()], [t.data_ptr() for t in o], units)
+    st.flush()
+    for units, (o0, o1, o2) in zip(plans, outs):
+        a, b, c = units
+        assert np.array_equal(o0.cpu().numpy()[: a * 1024], oracle.dct32_inv(zh[: a * 1024]).ravel()), units
+        assert not o0.cpu().numpy()[a * 1024:].any(), units           # nothing written past the frame's units
+        assert np.array_equal(o1.cpu().numpy()[:b], oracle.satd8x8(dh[: b * 64]).astype(np.int32)), units
+        assert not o1.cpu().numpy()[b:].any(), units
+        assert np.array_equal(o2.cpu().numpy()[: c * 1024], oracle.dct32_fwd(zh[: c * 1024]).ravel()), units
+        assert not o2.cpu().numpy()[c * 1024:].any(), units
+    st.close()
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_rccl_transport_with_n_ranks_under_the_rccl_model(world):
     """The node layer's RCCL code path itself -- the ncclGroupStart/End of ncclSend/ncclRecv it builds per step -- with
