@@ -38,6 +38,25 @@ for (w, h, n_frames) in ((96, 160, 6), (64, 32, 4), (1920, 1088, 3)):
     st.close()
     print("ok frame stream %dx%d, %d frames, %d ranks" % (w, h, n_frames, world))
 
+# unit counts that change from frame to frame (zero, one, fewer than ranks): empty transfers are skipped on both ends
+from x266_amd.node import OP_DCT32_INV
+caps = [19, 301]
+st = node.stream([OP_DCT32_INV, OP_SATD8X8], caps)
+zin = rs.randint(-255, 256, caps[0] * 1024).astype(np.int16)
+din = rs.randint(-255, 256, caps[1] * 64).astype(np.int16)
+dz, dd = dev(zin), dev(din)
+plans = [[19, 301], [0, 0], [1, 1], [world - 1, world + 1], [0, 5], [7, 0], [18, 300]]
+outs = [(codec.alloc(caps[0] * 2048), codec.alloc(caps[1] * 4)) for _ in plans]
+for units, (o0, o1) in zip(plans, outs):
+    st.push([dz.ptr, dd.ptr], [o0.ptr, o1.ptr], units)
+st.flush()
+for units, (o0, o1) in zip(plans, outs):
+    a, b = units
+    assert np.array_equal(o0.download(np.int16, caps[0] * 1024)[: a * 1024], codec.dct32_inv(zin[: a * 1024]).ravel()), units
+    assert np.array_equal(o1.download(np.uint32, caps[1])[:b], codec.satd8x8(din[: b * 64])), units
+st.close()
+print("ok ragged unit counts")
+
 n = 5003
 x = rs.randint(-255, 256, n * 1024).astype(np.int16)
 di, do = dev(x), codec.alloc(n * 2048)

@@ -58,6 +58,30 @@ def child(world, rank, id_file):
         st.close()
         del bufs
 
+    # unit counts that change from frame to frame: every process passes the same counts, only the root has buffers
+    from x266_amd.node import OP_DCT32_INV, OP_SATD8X8
+    caps = [19, 301]
+    st = node.stream([OP_DCT32_INV, OP_SATD8X8], caps)
+    zin = rs.randint(-255, 256, caps[0] * 1024).astype(np.int16)
+    din = rs.randint(-255, 256, caps[1] * 64).astype(np.int16)
+    plans = [[19, 301], [0, 0], [1, 1], [world - 1, world + 1], [0, 5], [7, 0], [18, 300]]
+    if root:
+        dz, dd = dev(zin), dev(din)
+        outs = [(codec.alloc(caps[0] * 2048), codec.alloc(caps[1] * 4)) for _ in plans]
+    for k, units in enumerate(plans):
+        if root:
+            st.push([dz.ptr, dd.ptr], [outs[k][0].ptr, outs[k][1].ptr], units)
+        else:
+            st.push(None, None, units)
+    st.flush()
+    if root:
+        for units, (o0, o1) in zip(plans, outs):
+            a, b = units
+            assert np.array_equal(o0.download(np.int16, caps[0] * 1024)[: a * 1024], codec.dct32_inv(zin[: a * 1024]).ravel()), units
+            assert np.array_equal(o1.download(np.uint32, caps[1])[:b], codec.satd8x8(din[: b * 64])), units
+        print("ok ragged unit counts", flush=True)
+    st.close()
+
     n = 5003
     x = rs.randint(-255, 256, n * 1024).astype(np.int16)
     if root:
