@@ -743,6 +743,10 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
+        if result.get("also", {}).get("node_layer_error"):           # peers may be stuck in a collective this rank left: no orderly shutdown
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
