@@ -31,6 +31,8 @@ struct x266hip_ctx {
     DctOps *d_tr_inv[kTypes][3] = {};
     TileOpsSoA *d_tile_fwd = nullptr, *d_tile_inv = nullptr;   // all sixteen classes, structure of arrays (xTransformTilesDev)
     int tile_lds_per_wave = 4096;                   // mixed-class tile kernel: LDS charged per wave (resident-wave cap)
+    int tile_variant = 0;                           // mixed-class tile kernel: 1 = persistent workgroups with the class images in LDS (A/B)
+    int tile_wgs_per_cu = 2;                        // ... its workgroups per CU
     int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (next tile's loads issued before this tile's arithmetic)
     // options
     int wgs_per_cu_dct = 8;
@@ -310,6 +312,8 @@ static const OptionDesc kOptions[] = {
     {"satd_groups_per_wave", &x266hip_ctx::satd_groups_per_wave, 1, 4096, 1},
     {"tr_tiles_per_wave", &x266hip_ctx::tr_tiles_per_wave, 1, 64, 1},
     {"tile_tiles_per_wave", &x266hip_ctx::tile_tiles_per_wave, 0, 64, 1},
+    {"tile_variant", &x266hip_ctx::tile_variant, 0, 1, 1},
+    {"tile_wgs_per_cu", &x266hip_ctx::tile_wgs_per_cu, 1, 8, 1},
     {"tile_lds_bytes_per_wave", &x266hip_ctx::tile_lds_per_wave, 2048, 40960, 1},
     {"wg_threads", &x266hip_ctx::wg_threads, 64, 256, 64},
     {"satd_wg_threads", &x266hip_ctx::satd_wg_threads, 64, 256, 64},
@@ -479,6 +483,8 @@ int xTransformTilesDev(x266hip_ctx *ctx, int inverse, const int16_t *d_in, int16
     cfg.wg_threads = inverse ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
     cfg.lds_bytes_per_wave = ctx->tile_lds_per_wave;                    // dependent fetches per tile (class, images, data): more waves in flight pay here
     cfg.units_per_wave = ctx->tile_tiles_per_wave ? ctx->tile_tiles_per_wave : (inverse ? 2 : 1);   // measured optimum (profiles/r02_tiles_one_launch.txt)
+    cfg.variant = ctx->tile_variant;
+    cfg.wgs_per_cu = ctx->tile_wgs_per_cu;
     hipError_t e = launch_transform_tiles(inverse != 0, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class,
                                           inverse ? ctx->d_tile_inv : ctx->d_tile_fwd, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "tile transform launch", e);
