@@ -83,6 +83,8 @@ int  xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap,
  *   "dct32_lds_bytes_per_wave", ... LDS charged per wave = cap on resident waves per CU
  *   "adaptive_per_wave"      shrink the per-wave run on small batches (default 1)
  *   "dct32_variant" / "satd_variant" 1 = persistent grid-stride launch of the direct kernels
+ *   "tile_variant"           xTransformTilesDev: 1 = persistent workgroups with every class's operand images in LDS
+ *                            (slower than the default streaming launch; kept for comparison)
  *   "me_variant", "me_tile_rows", "me_row_pairs"   motion-search kernel shape ("me_tile_rows" 0, the default:
  *                            tile height chosen from the frame size and the CU count) */
 int  xHipSetOption(x266hip_ctx *ctx, const char *key, int value);
