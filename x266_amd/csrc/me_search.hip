@@ -1,0 +1,493 @@
+// me_search.hip -- full-search 8x8 SATD motion estimation for gfx950 (BASELINE configs[2]:
+// 3840x2160 luma, 8x8 blocks, window +-64 => 2.157e9 SATDs / frame), round-3 kernel.
+//
+// Per-candidate cost is pinned by the reference: satd8x8(cur - ref) with satd8x8 =
+// src_tb/satd.c:31-118 (9-bit differences, as the testbench feeds them, src/mkSatd.bsv:229).
+// The search harness around it -- candidate order, tie-break, padding -- has no upstream
+// counterpart and is defined in include/x266hip.h (raster order dy-major, first minimum wins).
+//
+// Algorithm.  The Hadamard transform is linear and a 9-bit difference cannot
+// wrap int16, so satd(cur - ref) = (sum_m |Hc[m] - Hr[m]| + 2) >> 2 with Hc = H64*cur, Hr = H64*ref,
+// exactly.  The search runs in the transform domain: Hr is formed once per candidate POSITION and
+// scored against every block whose window contains the position with v_sad_u16 (two |a-b| per
+// instruction) against the block's coefficients held in SGPRs.  Bound: VALU issue of v_sad_u16.
+//
+// What round 3 changed against the round-2 kernel (profiles/r03_me_variants.txt):
+//   * ONE LANE = ONE POSITION straight out of the matrix core.  The A operand of
+//     v_mfma_i32_32x32x32_i8 is the 16x16 Hadamard matrix over (row parity, column) of the window,
+//     zero outside the lane half that will receive the output row, so the K-slots a lane feeds
+//     (16 of its own window's pixels per K-step) only ever meet the output rows the same lane
+//     receives: four K-steps x four sign patterns (+A / -A per pixel-row pair) give the lane all 64
+//     coefficients of its own window.  No half-wave exchange (16 v_permlane32_swap per 64 positions),
+//     no v_perm packing (32) and no bias xor (32): two coefficient sets share one accumulator --
+//     high set, << 16 (+ bias), low set on top -- and the int16 bias 0x8000 of the high field comes
+//     from a constant MFMA.  16 v_alignbit + 32 v_lshl_add per 64 positions are all the VALU the
+//     transform still costs.
+//   * the coefficient rows of the blocks stream through TWO HALF-ROW SGPR sets: the half needed next
+//     is requested right after the first v_sad_u16 of the current half, so every scalar load has 31
+//     v_sad_u16 of its own wave to land in and the only wait sees exactly one load in flight
+//     (s_waitcnt lgkmcnt(0) is all SMEM offers); the two ds_min_u32 of a block are issued one phase
+//     late for the same reason.  32 SGPRs of operands instead of 64: no spills.
+//   * the block loop is one run-time loop over the item's valid blocks (no per-column unrolling).
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include <cstdint>
+
+#include "x266_device.hpp"
+#include "x266_mfma_blocks.hpp"
+
+namespace x266 {
+namespace {
+
+constexpr int kTileBlocksX = 8;           // blocks per tile row (64 pixels)
+// LDS bytes per window row, the same for every range (R <= 64: 23 unit columns x 8 + 7 pixels + dword slack): a compile-time
+// pitch turns the 24 row addresses of a position's window into immediate offsets.  51 dwords: odd, so the four rows a
+// half-wave reads land in different banks.
+constexpr int kPitch = 204;
+
+typedef uint32_t u16v __attribute__((ext_vector_type(16)));
+
+struct MeParams {
+    const uint8_t *cur;
+    const uint8_t *ref;           // pixel (0,0); valid for x,y in [-range, dim + range)
+    long long cur_stride, ref_stride;
+    int width, height, range;
+    int blocks_x, blocks_y;       // width / 8, height / 8
+    int tiles_x;
+    x266_me_result_t *best;
+    uint32_t *costs;              // optional [block][(2R+1)^2]
+};
+
+// ---- lane = position Hadamard transform on the matrix core ------------------------------------------
+// Output row m of the MFMA lands in lane half (m >> 2) & 1, register r = (m & 3) | (m >> 3) << 2.
+// A[m][k], k = 16 h + t: (-1)^popcount(r & t) for h == that half, else 0; t = 8 (y & 1) + x indexes the
+// 16 pixels of one K-step (window rows 2s, 2s+1).  `neg` = -A.  `kc`: 32 slots x 32 x 32 = 0x8000.
+struct LaneOps { v4i pos, neg, kc; };
+
+__device__ __forceinline__ LaneOps make_lane_ops(int lane)
+{
+    const uint32_t NEG = 0xFEFEFEFEu;
+    const uint32_t m = (uint32_t)lane & 31u, h = (uint32_t)lane >> 5;
+    const uint32_t r = (m & 3u) | ((m >> 3) << 2);
+    const bool active = ((m >> 2) & 1u) == h;
+    const uint32_t inner = (r & 1) ? ((r & 2) ? 0x01FFFF01u : 0xFF01FF01u) : ((r & 2) ? 0xFFFF0101u : 0x01010101u);
+    const uint32_t f0 = (r & 4) ? NEG : 0u, f1 = (r & 8) ? NEG : 0u;
+    const uint32_t on = active ? 0xFFFFFFFFu : 0u;
+    LaneOps o;
+    o.pos = v4i{(int)(inner & on), (int)((inner ^ f0) & on), (int)((inner ^ f1) & on), (int)((inner ^ f0 ^ f1) & on)};
+    o.neg = v4i{(int)((inner ^ NEG) & on), (int)((inner ^ f0 ^ NEG) & on), (int)((inner ^ f1 ^ NEG) & on), (int)((inner ^ f0 ^ f1 ^ NEG) & on)};
+    o.kc = v4i{0x20202020, 0x20202020, 0x20202020, 0x20202020};
+    return o;
+}
+
+// px[s] = window rows 2s, 2s+1 of this lane's 8x8 window (signed pixels, 16 bytes).  out[k], out[16+k]:
+// biased uint16 pairs {coefficient 16 + k | coefficient k}, {48 + k | 32 + k} (natural H64 order
+// c = 16 q + r over pixel index 8 y + x; the order is irrelevant under sum |.| as long as the block
+// table uses the same one, and it does: me_coef_kernel calls this function too).
+__device__ __forceinline__ void hadamard_lane(const LaneOps &O, const v4i (&px)[4], uint32_t (&out)[32])
+{
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // high fields: q = 1 (signs + - + -) and q = 3 (+ - - +) share the bias and their first two K-steps
+    v16i t = mfma(O.kc, O.kc, zero);
+    t = mfma(O.pos, px[0], t); t = mfma(O.neg, px[1], t);
+    v16i a = mfma(O.pos, px[2], t); a = mfma(O.neg, px[3], a);
+    v16i b = mfma(O.neg, px[2], t); b = mfma(O.pos, px[3], b);
+    // << 16 (a full-rate v_lshlrev_b32; the low field's bias is one more constant MFMA), then q = 0 (+ + + +) and q = 2 (+ + - -)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = (int)((uint32_t)a[k] << 16);
+    a = mfma(O.kc, O.kc, a);
+    a = mfma(O.pos, px[0], a); a = mfma(O.pos, px[1], a); a = mfma(O.pos, px[2], a); a = mfma(O.pos, px[3], a);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) b[k] = (int)((uint32_t)b[k] << 16);
+    b = mfma(O.kc, O.kc, b);
+    b = mfma(O.pos, px[0], b); b = mfma(O.pos, px[1], b); b = mfma(O.neg, px[2], b); b = mfma(O.neg, px[3], b);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { out[k] = (uint32_t)a[k]; out[16 + k] = (uint32_t)b[k]; }
+}
+
+// 8x8 bytes at (row, col) of the LDS window -> the four K-step operands: three aligned dwords per row and a funnel shift.
+// (gfx950 does serve unaligned ds_read_b64 -- tools/lds_unaligned_test.hip -- which would save the 16 v_alignbit_b32, but at a
+// fraction of the aligned rate: 2.34 -> 2.49 ms per 4K frame, profiles/r03_me_variants.txt.)  The row offsets are immediates (kPitch).
+__device__ __forceinline__ void load_window8(const unsigned char *lds0, int win_offset, int row, int col, v4i (&px)[4])
+{
+    const int sh = (col & 3) * 8;
+    int off = win_offset + row * kPitch + (col & ~3);
+    asm volatile("" : "+v"(off));         // keep the window's LDS offset in the register: y * kPitch then fits the DS offset fields
+    const unsigned char *base = lds0 + off;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(base + y * kPitch);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        px[y >> 1][2 * (y & 1)]     = (int)__builtin_amdgcn_alignbit(d1, d0, sh);
+        px[y >> 1][2 * (y & 1) + 1] = (int)__builtin_amdgcn_alignbit(d2, d1, sh);
+    }
+}
+
+// Pre-pass: Hc of every 8x8 block of the current frame, 32 dwords per block in hadamard_lane's order.
+// Blocks are stored TILE-MAJOR (search tile, then block row, then block column inside the tile): the
+// search kernel addresses all blocks of its tile from one scalar base.
+__global__ __launch_bounds__(256) void me_coef_kernel(const uint8_t *__restrict__ cur, long long cur_stride,
+                                                      int blocks_x, int n_blocks, int tiles_x, int tby,
+                                                      uint32_t *__restrict__ coef)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (wave * 64 >= n_blocks) return;
+    int blk = wave * 64 + lane;
+    const bool live = blk < n_blocks;
+    if (!live) blk = n_blocks - 1;
+    const int bx = blk % blocks_x, by = blk / blocks_x;
+    const uint8_t *src = cur + (long long)(by * 8) * cur_stride + bx * 8;
+    v4i px[4];
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        const uint8_t *q = src + (long long)y * cur_stride;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { lo |= (uint32_t)q[b] << (8 * b); hi |= (uint32_t)q[4 + b] << (8 * b); }
+        px[y >> 1][2 * (y & 1)]     = (int)(lo ^ 0x80808080u);
+        px[y >> 1][2 * (y & 1) + 1] = (int)(hi ^ 0x80808080u);
+    }
+    const LaneOps O = make_lane_ops(lane);
+    uint32_t p[32];
+    hadamard_lane(O, px, p);
+    if (live) {
+        const size_t slot = ((size_t)(by / tby) * tiles_x + bx / kTileBlocksX) * (size_t)(kTileBlocksX * tby)
+                            + (size_t)(by % tby) * kTileBlocksX + bx % kTileBlocksX;
+        v4i *dst = reinterpret_cast<v4i *>(coef + slot * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = v4i{(int)p[4 * k], (int)p[4 * k + 1], (int)p[4 * k + 2], (int)p[4 * k + 3]};
+    }
+}
+
+// x / d for 0 <= x < 64, d in {1, 2, 3} (the chunk counts of the narrow items) without a divider sequence
+__device__ __forceinline__ int div_small(int x, int d) { return d == 1 ? x : (d == 2 ? x >> 1 : (x * 21846) >> 16); }
+
+__device__ __forceinline__ uint32_t sad16(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u16(a, b, c); }
+#define X266_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Scores NU (1 or 2) units against the blocks (j, i), j in [j_lo, j_hi], i in [i_lo, i_hi] of the tile
+// (both ranges non-empty, wave-uniform).  pa / pb: the units' 32 coefficient dwords per lane; pid_a / pid_b
+// their window positions (row << 8 | column); row_a / row_b the units' first candidate row (cost map only).
+// MASKED (narrow units, NU = 1): a lane's position counts for block (j, i) only if it lies inside that block's window.
+template <int NU, bool COSTS, bool MASKED = false>
+__device__ __forceinline__ void score_blocks(const uint32_t (&pa)[32], const uint32_t (&pb)[32], uint32_t pid_a, uint32_t pid_b,
+                                             int j_lo, int j_hi, int i_lo, int i_hi,
+                                             const uint32_t *__restrict__ tile_coef, unsigned long long *my_slot,
+                                             const MeParams &P, int span, int tile_bx, int tile_by, int prow_a, int prow_b, int pcol)
+{
+    int i = i_lo, j = j_lo;
+    const uint32_t *cp = tile_coef + (j * kTileBlocksX + i) * 32;
+    u16v LO = *reinterpret_cast<const u16v *>(cp);
+    // keys are 64 bits, {cost : window position}: one v_lshrrev_b32 per candidate, the position half is the unit's own register
+    // (a register pair per unit whose low half, the position, is written once: only the high half changes per block)
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+    u2v key_a = {pid_a, 0xFFFFFFFFu}, key_b = {pid_b, 0xFFFFFFFFu};    // the previous block's keys, not yet in LDS
+    unsigned long long *slot = my_slot + (j * kTileBlocksX + i) * 64;
+    for (;;) {
+        uint32_t s0 = sad16(pa[0], LO[0], 2u), s1 = 2u;               // the "+2" of (sum + 2) >> 2
+        if (NU == 2) s1 = sad16(pb[0], LO[0], 2u);
+        X266_FENCE();
+        const u16v HI = *reinterpret_cast<const u16v *>(cp + 16);     // second half of this block's row: 31 v_sad_u16 to land in
+        atomicMin(slot, __builtin_bit_cast(unsigned long long, key_a));   // ds_min_u64, no return value
+        if (NU == 2) atomicMin(slot, __builtin_bit_cast(unsigned long long, key_b));
+        X266_FENCE();
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            s0 = sad16(pa[k], LO[k], s0);
+            if (NU == 2) s1 = sad16(pb[k], LO[k], s1);
+        }
+        slot = my_slot + (j * kTileBlocksX + i) * 64;
+        const int bj = j, bi = i;
+        const bool last = (i == i_hi) && (j == j_hi);
+        if (i == i_hi) { i = i_lo; ++j; } else ++i;
+        const uint32_t *cn = last ? cp : tile_coef + (j * kTileBlocksX + i) * 32;
+        X266_FENCE();
+        s0 = sad16(pa[16], HI[0], s0);
+        if (NU == 2) s1 = sad16(pb[16], HI[0], s1);
+        X266_FENCE();
+        LO = *reinterpret_cast<const u16v *>(cn);                      // first half of the next block's row
+        X266_FENCE();
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            s0 = sad16(pa[16 + k], HI[k], s0);
+            if (NU == 2) s1 = sad16(pb[16 + k], HI[k], s1);
+        }
+        key_a.y = s0 >> 2;
+        if (NU == 2) key_b.y = s1 >> 2;
+        bool ok = true;
+        if (MASKED) {
+            ok = (unsigned)(prow_a - 8 * bj) < (unsigned)span && (unsigned)(pcol - 8 * bi) < (unsigned)span;
+            key_a.y = ok ? key_a.y : 0xFFFFFFFFu;
+        }
+        if (COSTS && ok) {
+            const size_t blk = (size_t)(tile_by + bj) * P.blocks_x + (tile_bx + bi);
+            uint32_t *cm = P.costs + blk * (size_t)(span * span) + (size_t)(pcol - 8 * bi);
+            cm[(size_t)(prow_a - 8 * bj) * span] = s0 >> 2;
+            if (NU == 2) cm[(size_t)(prow_b - 8 * bj) * span] = s1 >> 2;
+        }
+        if (last) break;
+        cp = cn;
+    }
+    atomicMin(slot, __builtin_bit_cast(unsigned long long, key_a));
+    if (NU == 2) atomicMin(slot, __builtin_bit_cast(unsigned long long, key_b));
+}
+
+// A block's window is (2R+1)^2 candidates starting at a multiple of 8 in both directions.  Write
+// 2R+1 = 8F + rem (rem odd, 1 for R = 64).  Units are 8 columns x 8 rows of positions on the 8-pixel grid
+// of the blocks, one position per lane, so for ANY block the aligned part of its window,
+// [8i, 8i+8F) x [8j, 8j+8F), is exactly F x F whole units: a (unit, block) pair is either entirely valid
+// or not needed, and the scoring loop has no per-lane validity, no edge path.  Items pair two vertically
+// adjacent units (one coefficient fetch per 64 v_sad_u16); the block row whose window starts on the odd unit
+// of a pair, and the one whose window ends on the even unit, are scored with that unit alone.
+// The running minima live in LDS, one slot per (block, lane), updated with ds_min_u32 (issued beside the
+// VALU stream): no registers, so the block loop is a real loop.
+// The remaining rem columns and rem rows of every window ("+1" at R = 64: 257 of 16641 candidates) are
+// scored by narrow units -- 64 positions down one column, or along one row -- with per-lane validity.
+template <int TBY, bool COSTS, int WG, int WPS>
+__global__ __launch_bounds__(WG, WPS) void satd_search_kernel(const MeParams P, const uint32_t *__restrict__ coef)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NBLK = kTileBlocksX * TBY;
+    const int R = P.range, span = 2 * R + 1;
+    const int F = span >> 3, rem = span - 8 * F;                        // window = 8F aligned + rem (odd) more
+    const int n_ucols = kTileBlocksX - 1 + F;                          // main unit columns
+    const int n_item_rows = (TBY - 1 + F + 1) >> 1;                    // main items: pairs of unit rows
+    const int n_rows = 8 * (TBY - 1) + span, n_cols = 8 * (kTileBlocksX - 1) + span;   // candidate positions of the tile
+    const int main_rows = 16 * n_item_rows;
+    const int win_rows = (main_rows > n_rows ? main_rows : n_rows) + 7;
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);   // running minima: [block][lane], shared by the workgroup's waves
+    unsigned char *win = smem + NBLK * 512;
+
+    const int tid = threadIdx.x, lane = tid & 63, n_waves = WG >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
+    const int x0 = tx * (8 * kTileBlocksX), y0 = ty * (8 * TBY);
+
+#ifdef X266_ME_TIMING
+    unsigned long long *tstamp = (!COSTS && P.costs) ? reinterpret_cast<unsigned long long *>(P.costs) + (size_t)blockIdx.x * 12 : nullptr;
+    if (tstamp && tid == 0) tstamp[0] = __builtin_readcyclecounter();
+#endif
+    {   // reference window, signed pixels: a wave takes whole rows (one dword per lane), eight rows in flight
+        typedef uint32_t u32_any_align __attribute__((aligned(1)));
+        const int dwords_per_row = (8 * n_ucols + 20) >> 2;                // what this range reads of a row (51 at R = 64)
+        const int gx0 = x0 - R + 4 * lane;                               // >= -R: only the right and bottom edges clamp
+        const bool inside = gx0 + 3 <= P.width + R - 1;
+        const int last_x = P.width + R - 1, last_y = P.height + R - 1;
+        for (int ry0 = wave; ry0 < win_rows; ry0 += 8 * n_waves) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ry = ry0 + u * n_waves;
+                int gy = y0 - R + (ry < win_rows ? ry : win_rows - 1);
+                gy = gy > last_y ? last_y : gy;
+                const uint8_t *row = P.ref + (long long)gy * P.ref_stride;
+                if (inside) v[u] = *reinterpret_cast<const u32_any_align *>(row + gx0);
+                else {
+                    v[u] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { const int gx = gx0 + b > last_x ? last_x : gx0 + b; v[u] |= (uint32_t)row[gx] << (8 * b); }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ry = ry0 + u * n_waves;
+                if (ry < win_rows && lane < dwords_per_row) reinterpret_cast<uint32_t *>(win + ry * kPitch)[lane] = v[u] ^ 0x80808080u;
+            }
+        }
+    }
+    for (int i = tid; i < NBLK * 64; i += WG) slots[i] = ~0ull;
+    uint32_t *next_item = reinterpret_cast<uint32_t *>(win + win_rows * kPitch);   // items are handed out dynamically: the waves of a
+    if (tid == 0) *next_item = (uint32_t)n_waves;                                    // SIMD do not advance at the same rate (issue priority by age)
+    __syncthreads();
+#ifdef X266_ME_TIMING
+    if (tstamp && tid == 0) tstamp[1] = __builtin_readcyclecounter();
+#endif
+    unsigned long long *my_slot = slots + lane;
+
+    int blocks_left_x = P.blocks_x - tx * kTileBlocksX, blocks_left_y = P.blocks_y - ty * TBY;
+    blocks_left_x = blocks_left_x > kTileBlocksX ? kTileBlocksX : blocks_left_x;
+    blocks_left_y = blocks_left_y > TBY ? TBY : blocks_left_y;
+    const uint32_t *__restrict__ tile_coef = coef + (size_t)blockIdx.x * (NBLK * 32);
+
+    // ---- item list: main (pairs of 8x8 units), then narrow columns, then narrow rows ---------------------
+    const int n_main = F > 0 ? n_item_rows * n_ucols : 0;
+    const int n_chunk_r = (n_rows + 63) >> 6, n_chunk_c = (n_cols + 63) >> 6;
+    const int n_ncol = kTileBlocksX * rem * n_chunk_r;                  // (block column, extra column, 64-row chunk)
+    const int n_nrow = F > 0 ? TBY * rem * n_chunk_c : 0;               // (block row, extra row, 64-column chunk); F = 0: the columns cover it all
+    const int n_items = n_main + n_ncol + n_nrow;
+    const int py = lane >> 3, pxx = lane & 7;                           // this lane's position inside a main unit
+
+    int fetched = 0;
+    for (int item = wave; item < n_items; item = __builtin_amdgcn_readfirstlane(fetched)) {
+        fetched = lane == 0 ? (int)atomicAdd(next_item, 1u) : 0;           // ds_add_rtn_u32, issued now, consumed after the item's work
+        // The matrix-core operands are rebuilt per item (a dozen 2-cycle instructions) from a lane id the compiler cannot see
+        // through: kept across the scoring loops they are what gets spilled.
+        int opaque_lane = lane;
+        asm volatile("" : "+v"(opaque_lane));
+        const LaneOps O = make_lane_ops(opaque_lane);
+        if (item < n_main) {
+            // ================= main item: units (2m, ux) and (2m+1, ux) ====================================
+            const int m = item / n_ucols, ux = item - m * n_ucols;     // wave-uniform
+            int i_lo = ux - F + 1, i_hi = ux;
+            i_lo = i_lo < 0 ? 0 : i_lo;
+            i_hi = i_hi > blocks_left_x - 1 ? blocks_left_x - 1 : i_hi;
+            if (i_lo > i_hi) continue;
+            // block rows: pairs for j in [2m+2-F, 2m]; unit 2m alone for j = 2m+1-F; unit 2m+1 alone for j = 2m+1
+            int jp_lo = 2 * m + 2 - F, jp_hi = 2 * m;
+            jp_lo = jp_lo < 0 ? 0 : jp_lo;
+            jp_hi = jp_hi > blocks_left_y - 1 ? blocks_left_y - 1 : jp_hi;
+            const int j_a = 2 * m + 1 - F, j_b = 2 * m + 1;
+            const bool only_a = j_a >= 0 && j_a < blocks_left_y, only_b = j_b < blocks_left_y;
+            const bool pairs = jp_lo <= jp_hi;
+            if (!pairs && !only_a && !only_b) continue;
+            const int col = 8 * ux + pxx;
+            const int row_a = 16 * m + py, row_b = row_a + 8;
+            const uint32_t pid_a = (uint32_t)(row_a << 8 | col), pid_b = (uint32_t)(row_b << 8 | col);
+            v4i px[4];
+            uint32_t pa[32];
+            load_window8(smem, NBLK * 512, row_a, col, px);
+            hadamard_lane(O, px, pa);
+            if (!pairs && !only_b) {                                   // the tile's last unit row: nothing pairs with it
+                score_blocks<1, COSTS>(pa, pa, pid_a, pid_a, j_a, j_a, i_lo, i_hi, tile_coef, my_slot, P, span, tx * kTileBlocksX, ty * TBY, row_a, row_a, col);
+                continue;
+            }
+            uint32_t pb[32];
+            load_window8(smem, NBLK * 512, row_b, col, px);
+            hadamard_lane(O, px, pb);
+            if (pairs)  score_blocks<2, COSTS>(pa, pb, pid_a, pid_b, jp_lo, jp_hi, i_lo, i_hi, tile_coef, my_slot, P, span, tx * kTileBlocksX, ty * TBY, row_a, row_b, col);
+            if (only_a) score_blocks<1, COSTS>(pa, pa, pid_a, pid_a, j_a, j_a, i_lo, i_hi, tile_coef, my_slot, P, span, tx * kTileBlocksX, ty * TBY, row_a, row_a, col);
+            if (only_b) score_blocks<1, COSTS>(pb, pb, pid_b, pid_b, j_b, j_b, i_lo, i_hi, tile_coef, my_slot, P, span, tx * kTileBlocksX, ty * TBY, row_b, row_b, col);
+        } else {
+            // ================= narrow item: 64 positions down one column or along one row =====================
+            // item order inside each kind: extra column / row, then 64-position chunk, then block column / row (fastest),
+            // so that the only divisor is the chunk count, 1..3
+            int it = item - n_main;
+            const bool is_col = it < n_ncol;
+            int bi, bj, prow, pcol;                                    // the block column / row served; this lane's position
+            if (is_col) {
+                bi = it & (kTileBlocksX - 1); bj = -1;
+                const int rest = it >> 3;
+                const int c = div_small(rest, n_chunk_r), chunk = rest - c * n_chunk_r;
+                pcol = 8 * bi + 8 * F + c;
+                prow = 64 * chunk + lane;
+            } else {
+                it -= n_ncol;
+                bj = it & (TBY - 1); bi = -1;
+                const int rest = it / TBY;
+                const int rr = div_small(rest, n_chunk_c), chunk = rest - rr * n_chunk_c;
+                prow = 8 * bj + 8 * F + rr;
+                pcol = 64 * chunk + lane;
+            }
+            uint32_t pa[32];
+            {
+                const int r1 = prow > n_rows - 1 ? n_rows - 1 : prow, c1 = pcol > n_cols - 1 ? n_cols - 1 : pcol;   // clamped for the loads
+                v4i px[4];
+                load_window8(smem, NBLK * 512, r1, c1, px);
+                hadamard_lane(O, px, pa);
+            }
+            const uint32_t pid = (uint32_t)(prow << 8 | pcol);
+            // the blocks whose window the unit's 64 positions can touch (wave-uniform); the per-lane test is in score_blocks
+            int j_lo, j_hi, i_lo, i_hi;
+            if (is_col) {
+                const int unit_r0 = prow - lane;                           // rows unit_r0 .. +63 against windows [8j, 8j + span)
+                j_lo = (unit_r0 - span + 8) >> 3; j_hi = (unit_r0 + 63) >> 3;
+                i_lo = i_hi = bi;
+            } else {
+                const int unit_c0 = pcol - lane;
+                i_lo = (unit_c0 - span + 8) >> 3; i_hi = (unit_c0 + 63) >> 3;
+                j_lo = j_hi = bj;
+            }
+            j_lo = __builtin_amdgcn_readfirstlane(j_lo < 0 ? 0 : j_lo); i_lo = __builtin_amdgcn_readfirstlane(i_lo < 0 ? 0 : i_lo);
+            j_hi = __builtin_amdgcn_readfirstlane(j_hi > blocks_left_y - 1 ? blocks_left_y - 1 : j_hi);
+            i_hi = __builtin_amdgcn_readfirstlane(i_hi > blocks_left_x - 1 ? blocks_left_x - 1 : i_hi);
+            if (j_lo > j_hi || i_lo > i_hi) continue;
+            score_blocks<1, COSTS, true>(pa, pa, pid, pid, j_lo, j_hi, i_lo, i_hi, tile_coef, my_slot, P, span, tx * kTileBlocksX, ty * TBY, prow, prow, pcol);
+        }
+    }
+
+#ifdef X266_ME_TIMING
+    if (tstamp && lane == 0) tstamp[2 + wave] = __builtin_readcyclecounter();
+#endif
+    __syncthreads();
+    for (int blk = wave; blk < NBLK; blk += n_waves) {                 // minimum over the 64 lane slots of a block
+        unsigned long long v = slots[blk * 64 + lane];
+#pragma unroll
+        for (int mm = 32; mm >= 1; mm >>= 1) {
+            const unsigned long long o = (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)v, mm)
+                                         | ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mm) << 32);
+            v = o < v ? o : v;
+        }
+        const int bi = blk % kTileBlocksX, bj = blk / kTileBlocksX;
+        const int bx = tx * kTileBlocksX + bi, by = ty * TBY + bj;
+        if (lane == 0 && bx < P.blocks_x && by < P.blocks_y) {
+            x266_me_result_t res;
+            res.mvx = (int16_t)((int)(v & 0xFFu) - 8 * bi - R);            // window column -> dx
+            res.mvy = (int16_t)((int)((v >> 8) & 0xFFu) - 8 * bj - R);     // window row -> dy
+            res.cost = (uint32_t)(v >> 32);
+            P.best[(size_t)by * P.blocks_x + bx] = res;
+        }
+    }
+#ifdef X266_ME_TIMING
+    if (tstamp && tid == 0) { tstamp[10] = __builtin_readcyclecounter(); tstamp[11] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) /* XCC_ID */ | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) /* HW_ID */; }
+#endif
+}
+
+}  // namespace
+
+hipError_t launch_satd_search5(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
+                               int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
+                               int tile_rows, uint32_t *d_coef_scratch, int cu_count, hipStream_t stream)
+{
+    MeParams P;
+    P.cur = d_cur; P.ref = d_ref; P.cur_stride = cur_stride; P.ref_stride = ref_stride;
+    P.width = width; P.height = height; P.range = range;
+    P.blocks_x = width / 8; P.blocks_y = height / 8;
+    P.tiles_x = (P.blocks_x + kTileBlocksX - 1) / kTileBlocksX;
+    if (tile_rows <= 0) {
+        // Tile height by frame size.  Measured (profiles/r02_me_sizes.txt, R = 64, 256 CUs): a launch of T tiles takes about
+        // L + (ceil(T / CUs) - 1) * S with (L, S) = (0.40, 0.30) ms for 8-row tiles, (0.23, 0.167) for 4 and (0.146, 0.098) for 2
+        // -- a lone tile costs L whatever the chip could do next to it, and tall tiles halve the position transforms per
+        // block.  4K frames want 8 rows, a 544-row stripe 4, a 360p frame 2; only the ratios matter, they hold for any range.
+        const int cus = cu_count > 0 ? cu_count : 256;
+        const float L[3] = {4.0f, 2.3f, 1.46f}, S[3] = {3.0f, 1.67f, 0.98f};
+        const int cand[3] = {8, 4, 2};
+        float best_t = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const long long tiles = (long long)P.tiles_x * ((P.blocks_y + cand[c] - 1) / cand[c]);
+            const float t = L[c] + (float)((tiles + cus - 1) / cus - 1) * S[c];
+            if (c == 0 || t < best_t) { best_t = t; tile_rows = cand[c]; }
+        }
+    }
+    const int tby = tile_rows >= 8 ? 8 : (tile_rows >= 4 ? 4 : (tile_rows == 1 ? 1 : 2));
+    const int tiles_y = (P.blocks_y + tby - 1) / tby;
+    const int span = 2 * range + 1;
+    const int n_rows = 8 * (tby - 1) + span;
+    P.best = d_best; P.costs = d_costs;
+    const int n_blocks = P.blocks_x * P.blocks_y;
+    hipLaunchKernelGGL(me_coef_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, stream, d_cur, cur_stride,
+                       P.blocks_x, n_blocks, P.tiles_x, tby, d_coef_scratch);
+    {
+        const hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
+    }
+    const int F = span >> 3;
+    const int n_item_rows = (tby - 1 + F + 1) >> 1;
+    const int main_rows = 16 * n_item_rows;
+    const size_t lds = (size_t)kTileBlocksX * tby * 512 + (size_t)((main_rows > n_rows ? main_rows : n_rows) + 7) * kPitch + 16;   // minima, window, item counter
+    const dim3 grid((unsigned)(P.tiles_x * tiles_y)), block(512);        // 8-wave workgroups, two per CU: 4 waves per SIMD
+    const uint32_t *cf = d_coef_scratch;
+#ifdef X266_ME_TIMING
+#define X266_ME5(T) hipLaunchKernelGGL((satd_search_kernel<T, false, 512, 4>), grid, block, lds, stream, P, cf)
+#else
+#define X266_ME5(T) do { if (d_costs) hipLaunchKernelGGL((satd_search_kernel<T, true, 512, 4>), grid, block, lds, stream, P, cf); \
+                         else         hipLaunchKernelGGL((satd_search_kernel<T, false, 512, 4>), grid, block, lds, stream, P, cf); } while (0)
+#endif
+    if (tby == 8) X266_ME5(8); else if (tby == 4) X266_ME5(4); else if (tby == 1) X266_ME5(1); else X266_ME5(2);
+#undef X266_ME5
+    return hipGetLastError();
+}
+
+}  // namespace x266

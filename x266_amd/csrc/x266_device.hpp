@@ -110,6 +110,9 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
                               int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
                               int tile_rows, int variant, int row_pairs, uint32_t *d_coef_scratch, int cu_count, int wg_threads,
                               int me_splits, hipStream_t stream);
+hipError_t launch_satd_search5(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
+                               int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
+                               int tile_rows, uint32_t *d_coef_scratch, int cu_count, hipStream_t stream);
 hipError_t launch_sad(int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out, size_t n_blocks, hipStream_t stream);
 hipError_t launch_tile_convert(bool pack, x266_ref_block_t *d_tiles, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
                                long long strd_y, long long strd_c, int width, int height, hipStream_t stream);

@@ -49,7 +49,7 @@ struct x266hip_ctx {
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
     int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (variant 4: 8, 4 or 2; SAD search: 2), else 1, 2, 4, 8 (8: variant 4 only)
     int me_row_pairs = 2;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
-    int me_variant = 4;                             // 1 = LDS coefficients, 2 = scalar coefficients, 3 = scalar coefficients, 16x4 units, position keys (me_kernels.hip)
+    int me_variant = 5;                             // 1 = LDS coefficients, 2 = scalar coefficients, 3 = scalar coefficients, 16x4 units, position keys (me_kernels.hip)
     int intra_rounds = 4;                           // intra prediction: rounds of seven predictions per wave (next round's reference sets prefetched)
     int sad_me_variant = 2;                         // SAD search: 1 = four horizontally adjacent blocks per pass (round 1), 2 = one block column per pass, aligned, position keys
     int me_wg_threads = 0;                          // variants 3, 4: workgroup size (0 = 256 for variant 3, 512 for variant 4: two 8-wave workgroups per CU)
@@ -329,7 +329,7 @@ static const OptionDesc kOptions[] = {
     {"dct32_inv_lds_pad_bytes", &x266hip_ctx::lds_pad_inv, 0, 160 * 1024, 1},
     {"satd_lds_pad_bytes", &x266hip_ctx::lds_pad_satd, 0, 160 * 1024, 1},
     {"me_tile_rows", &x266hip_ctx::me_tile_rows, 0, 8, 1},
-    {"me_variant", &x266hip_ctx::me_variant, 1, 4, 1},
+    {"me_variant", &x266hip_ctx::me_variant, 1, 5, 1},
     {"sad_me_variant", &x266hip_ctx::sad_me_variant, 1, 2, 1},
     {"intra_rounds", &x266hip_ctx::intra_rounds, 1, 16, 1},
     {"me_wg_threads", &x266hip_ctx::me_wg_threads, 0, 512, 64},
@@ -633,7 +633,10 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
         d_me_coef = slot->p;
     }
     (void)hipGetLastError();
-    hipError_t e = launch_satd_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
+    hipError_t e = ctx->me_variant == 5
+        ? launch_satd_search5(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
+                              d_best, d_costs, ctx->me_tile_rows, d_me_coef, ctx->prop.multiProcessorCount, (hipStream_t)stream)
+        : launch_satd_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
                                       d_best, d_costs, ctx->me_tile_rows, ctx->me_variant, ctx->me_row_pairs, d_me_coef, ctx->prop.multiProcessorCount,
                                       ctx->me_wg_threads, ctx->me_splits, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "search launch", e);
