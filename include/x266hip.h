@@ -82,11 +82,10 @@ int  xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap,
  *   "dct32_wg_threads", "dct32_inv_wg_threads", "satd_wg_threads" (64..256)
  *   "dct32_lds_bytes_per_wave", ... LDS charged per wave = cap on resident waves per CU
  *   "adaptive_per_wave"      shrink the per-wave run on small batches (default 1)
- *   "dct32_variant" / "satd_variant" 1 = persistent grid-stride launch of the direct kernels
- *   "tile_variant"           xTransformTilesDev: 1 = persistent workgroups with every class's operand images in LDS
- *                            (slower than the default streaming launch; kept for comparison)
- *   "me_variant", "me_tile_rows", "me_row_pairs"   motion-search kernel shape ("me_tile_rows" 0, the default:
- *                            tile height chosen from the frame size and the CU count) */
+ *   "dct32_variant" / "satd_variant" 2 = the reference's butterfly on the vector ALU instead of the matrix core
+ *                            (the one comparison variant per kernel family north_star asks for; 0 = default)
+ *   "me_tile_rows"           motion-search tile height in block rows (0, the default: chosen from the frame size
+ *                            and the CU count) */
 int  xHipSetOption(x266hip_ctx *ctx, const char *key, int value);
 int  xHipGetOption(const x266hip_ctx *ctx, const char *key, int *value);
 
@@ -166,6 +165,11 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
 /* The same search with the cheaper metric: cost = sum |cur - ref| over the 8x8 block,
  * i.e. sad() of riscv/programs/benchmarks/sad/sad.c:28-39 at n = 8; same candidate order and
  * tie-break.  d_cur must be 4-byte aligned with cur_stride a multiple of 4. */
+/* Allocates xSatd8x8SearchDev's scratch (128 bytes per 8x8 block of the frame) for searches of frames up to
+ * width x height enqueued on `stream`, so that no launch path allocates: for stream captures and real-time loops.
+ * The library keeps one buffer per stream, for at most 8 streams (the least recently used one is released after
+ * its last search has finished); buffers handed out under a capture live as long as the context. */
+int xHipMeScratchReserve(x266hip_ctx *ctx, void *stream, int width, int height);
 int xSad8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride, const uint8_t *d_ref,
                      intptr_t ref_stride, int width, int height, int range, x266_me_result_t *d_best,
                      uint32_t *d_costs, void *stream);
@@ -256,8 +260,8 @@ int xHipStreamDestroy(x266hip_ctx *ctx, void *stream);
  * xHipGraphBegin and xHipGraphEnd -- any of the ...Dev calls above, in any number -- is recorded
  * instead of run, and xHipGraphLaunch replays the whole sequence with one submission.  The recorded
  * calls keep their pointer and size arguments, so a graph is replayed over the same buffers with new
- * contents.  Run the sequence once before capturing it: calls that size internal scratch on first use
- * (xSatd8x8SearchDev) must not do so inside a capture. */
+ * contents.  xSatd8x8SearchDev sizes an internal scratch buffer per (stream, frame size) on first use, which is
+ * illegal inside a capture: call xHipMeScratchReserve (below) or run one search on that stream beforehand. */
 typedef struct x266hip_graph x266hip_graph;
 int xHipGraphBegin(x266hip_ctx *ctx, void *stream);
 int xHipGraphEnd(x266hip_ctx *ctx, void *stream, x266hip_graph **graph);

@@ -26,8 +26,8 @@ OPTIONS = {
     "dct32_lds_stage": st.integers(0, 1),
     "satd_lds_stage": st.integers(0, 1),
     "tr_lds_stage": st.integers(0, 1),
-    "dct32_variant": st.integers(0, 2),
-    "satd_variant": st.integers(0, 2),
+    "dct32_variant": st.sampled_from([0, 2]),
+    "satd_variant": st.sampled_from([0, 2]),
     "dct32_blocks_per_wave": st.integers(1, 9),
     "dct32_inv_blocks_per_wave": st.integers(1, 9),
     "dct32_fwdinv_blocks_per_wave": st.integers(1, 9),
@@ -112,17 +112,15 @@ def test_intra_random(codec, oracle, n, seed):
 
 
 @fuzz(30)
-@given(wb=st.integers(1, 14), hb=st.integers(1, 9), rng=st.integers(1, 24), tile_rows=st.sampled_from([1, 2, 4]),
-       row_pairs=st.integers(1, 3), variant=st.integers(1, 2), metric=st.sampled_from(["satd", "sad"]), seed=st.integers(1, 1 << 20))
-def test_motion_search_random(codec, oracle, wb, hb, rng, tile_rows, row_pairs, variant, metric, seed):
+@given(wb=st.integers(1, 14), hb=st.integers(1, 9), rng=st.integers(1, 24), tile_rows=st.sampled_from([0, 1, 2, 4, 8]),
+       metric=st.sampled_from(["satd", "sad"]), seed=st.integers(1, 1 << 20))
+def test_motion_search_random(codec, oracle, wb, hb, rng, tile_rows, metric, seed):
     from _util import me_frames
     w, h, pad = 8 * wb, 8 * hb, rng + (seed % 4)
     cur, refp = me_frames(w, h, pad, seed, mv=(min(rng, seed % 5), -min(rng, seed % 3)))
-    saved = {k: codec.get_option(k) for k in ("me_tile_rows", "me_variant", "me_row_pairs")}
+    saved = {k: codec.get_option(k) for k in ("me_tile_rows",)}
     try:
         codec.set_option("me_tile_rows", tile_rows)
-        codec.set_option("me_variant", variant)
-        codec.set_option("me_row_pairs", row_pairs)
         mv, cost, costs = codec.satd_search(cur, refp, pad, rng, want_costs=True, metric=metric)
         mv2, cost2, _ = codec.satd_search(cur, refp, pad, rng, metric=metric)
     finally:
@@ -135,9 +133,8 @@ def test_motion_search_random(codec, oracle, wb, hb, rng, tile_rows, row_pairs, 
 
 @fuzz(30)
 @given(bw=st.integers(1, 20), bh=st.integers(1, 20), rng=st.integers(1, 64), seed=st.integers(1, 1 << 20),
-       tile_rows=st.sampled_from([1, 2, 4, 8]), variant=st.sampled_from([3, 4]), wg=st.sampled_from([0, 256, 512]),
-       sad_variant=st.sampled_from([1, 2]))
-def test_motion_search_random_frames_ranges_and_shapes(codec, oracle, bw, bh, rng, seed, tile_rows, variant, wg, sad_variant):
+       tile_rows=st.sampled_from([1, 2, 4, 8]))
+def test_motion_search_random_frames_ranges_and_shapes(codec, oracle, bw, bh, rng, seed, tile_rows):
     """Every window remainder (2R+1 = 8F + rem, rem in {1, 3, 5, 7}, F from 0 to 16), ragged tiles, all tile shapes:
     winners and costs of the SATD and SAD searches equal the oracle's brute force."""
     from _util import me_frames
@@ -146,21 +143,18 @@ def test_motion_search_random_frames_ranges_and_shapes(codec, oracle, bw, bh, rn
         rng = max(1, rng // 4)
     pad = rng + (seed & 3)
     cur, refp = me_frames(w, h, pad, seed, mv=(min(rng, 2), -min(rng, 1)), noise=3)
-    saved = {k: codec.get_option(k) for k in ("me_tile_rows", "me_variant", "me_wg_threads", "sad_me_variant")}
+    saved = {k: codec.get_option(k) for k in ("me_tile_rows",)}
     try:
         codec.set_option("me_tile_rows", tile_rows)
-        codec.set_option("me_variant", variant)
-        codec.set_option("me_wg_threads", wg if variant == 4 else min(wg, 256))
-        codec.set_option("sad_me_variant", sad_variant)
         mv, cost, _ = codec.satd_search(cur, refp, pad, rng)
         smv, scost, _ = codec.satd_search(cur, refp, pad, rng, metric="sad")
     finally:
         for k, v in saved.items():
             codec.set_option(k, v)
     omv, ocost, _ = oracle.satd_search(cur, refp, pad, rng, threads=8)
-    assert np.array_equal(cost, ocost) and np.array_equal(mv, omv), (w, h, rng, tile_rows, variant, wg)
+    assert np.array_equal(cost, ocost) and np.array_equal(mv, omv), (w, h, rng, tile_rows)
     omv, ocost, _ = oracle.satd_search(cur, refp, pad, rng, threads=8, metric="sad")
-    assert np.array_equal(scost, ocost) and np.array_equal(smv, omv), (w, h, rng, tile_rows, sad_variant)
+    assert np.array_equal(scost, ocost) and np.array_equal(smv, omv), (w, h, rng, tile_rows)
 
 
 @fuzz(25)

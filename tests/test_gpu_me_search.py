@@ -10,19 +10,15 @@ from _util import me_frames, splitmix64
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant,row_pairs", [(1, 1), (2, 1), (2, 2), (2, 3), (3, 1), (3, 2), (4, 2), (5, 2)])
 @pytest.mark.parametrize("w,h,rng,tile_rows", [
     (64, 16, 4, 2), (64, 48, 8, 1), (64, 48, 8, 2), (64, 48, 8, 4), (136, 72, 16, 2), (136, 72, 16, 4),
-    (72, 40, 1, 2), (200, 24, 33, 2), (8, 8, 5, 2), (128, 64, 64, 2), (24, 136, 64, 4), (136, 72, 16, 8), (72, 136, 64, 8), (64, 64, 3, 8)])
-def test_every_candidate_cost_and_winner(codec, oracle, w, h, rng, tile_rows, variant, row_pairs):
-    if tile_rows == 8 and variant < 4:
-        pytest.skip("8-row tiles exist for variant 4 only")
+    (72, 40, 1, 2), (200, 24, 33, 2), (8, 8, 5, 2), (128, 64, 64, 2), (24, 136, 64, 4), (136, 72, 16, 8), (72, 136, 64, 8), (64, 64, 3, 8),
+    (64, 48, 8, 8), (200, 24, 33, 1), (24, 136, 64, 1), (264, 200, 12, 4), (72, 72, 2, 4), (80, 80, 7, 2), (96, 40, 31, 8)])
+def test_every_candidate_cost_and_winner(codec, oracle, w, h, rng, tile_rows):
     pad = rng + 3
     cur, refp = me_frames(w, h, pad, 100 + w + h + rng, mv=(min(rng, 3), -min(rng, 2)))
-    saved = {k: codec.get_option(k) for k in ("me_tile_rows", "me_variant", "me_row_pairs")}
+    saved = {k: codec.get_option(k) for k in ("me_tile_rows",)}
     codec.set_option("me_tile_rows", tile_rows)
-    codec.set_option("me_variant", variant)
-    codec.set_option("me_row_pairs", row_pairs)
     try:
         mv, cost, costs = codec.satd_search(cur, refp, pad, rng, want_costs=True)
         mv2, cost2, _ = codec.satd_search(cur, refp, pad, rng)          # the search-only kernel (no cost map)

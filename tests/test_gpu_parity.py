@@ -199,22 +199,20 @@ def test_argument_errors(codec):
     assert L.xSatd8x8Batch(codec.ctx, None, None, 3) < 0
     assert L.xHipSetOption(codec.ctx, b"no_such_option", 1) < 0
     for key, bad in ((b"dct32_wg_threads", 96), (b"dct32_wg_threads", 512), (b"dct32_blocks_per_wave", 0), (b"nontemporal", 16),
-                     (b"dct32_lds_bytes_per_wave", 1024), (b"me_variant", 0)):
+                     (b"dct32_lds_bytes_per_wave", 1024), (b"me_tile_rows", 9)):
         assert L.xHipSetOption(codec.ctx, key, bad) < 0, key                     # out of range: rejected, value unchanged
     assert codec.get_option("dct32_wg_threads") == 64
     assert b"" != L.xHipLastError(codec.ctx)
 
 
-@pytest.mark.parametrize("variant,nt,tpb,per_wave,wgs,stage", [
-    (0, 0, 64, 1, 8, 0), (0, 4, 256, 3, 8, 0), (0, 3, 128, 16, 8, 0), (0, 11, 192, 7, 8, 0),
-    (0, 0, 64, 1, 8, 1), (0, 3, 256, 3, 8, 1), (0, 1, 128, 16, 8, 1), (0, 2, 192, 7, 8, 1), (0, 11, 64, 5, 8, 1), (0, 0, 256, 2, 8, 1),
-    (1, 0, 256, 1, 1, 0), (1, 7, 64, 1, 3, 0), (1, 3, 256, 1, 8, 1)])
-def test_launch_geometry_options_do_not_change_results(codec, oracle, variant, nt, tpb, per_wave, wgs, stage):
+@pytest.mark.parametrize("nt,tpb,per_wave,stage", [
+    (0, 64, 1, 0), (4, 256, 3, 0), (3, 128, 16, 0), (11, 192, 7, 0), (7, 64, 1, 0),
+    (0, 64, 1, 1), (3, 256, 3, 1), (1, 128, 16, 1), (2, 192, 7, 1), (11, 64, 5, 1), (0, 256, 2, 1)])
+def test_launch_geometry_options_do_not_change_results(codec, oracle, nt, tpb, per_wave, stage):
     x = residual_np(3001 * 1024, 0x266).reshape(-1, 1024)
     d = x.reshape(-1, 64)[:100003]
-    keys = ("adaptive_per_wave", "nontemporal", "wg_threads", "satd_wg_threads", "dct32_wg_threads", "dct32_inv_wg_threads", "dct32_lds_stage", "satd_lds_stage", "dct32_variant", "satd_variant", "dct32_blocks_per_wave",
-            "dct32_inv_blocks_per_wave", "satd_groups_per_wave", "dct32_wgs_per_cu", "dct32_inv_wgs_per_cu",
-            "satd_wgs_per_cu")
+    keys = ("adaptive_per_wave", "nontemporal", "wg_threads", "satd_wg_threads", "dct32_wg_threads", "dct32_inv_wg_threads", "dct32_lds_stage", "satd_lds_stage", "dct32_blocks_per_wave",
+            "dct32_inv_blocks_per_wave", "satd_groups_per_wave")
     saved = {k: codec.get_option(k) for k in keys}
     try:
         codec.set_option("nontemporal", nt)
@@ -223,12 +221,8 @@ def test_launch_geometry_options_do_not_change_results(codec, oracle, variant, n
             codec.set_option(k, tpb)
         codec.set_option("dct32_lds_stage", stage)
         codec.set_option("satd_lds_stage", stage)
-        for k in ("dct32_variant", "satd_variant"):
-            codec.set_option(k, variant)
         for k in ("dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "satd_groups_per_wave"):
             codec.set_option(k, per_wave)
-        for k in ("dct32_wgs_per_cu", "dct32_inv_wgs_per_cu", "satd_wgs_per_cu"):
-            codec.set_option(k, wgs)
         z = oracle.dct32_fwd(x, threads=8)
         assert np.array_equal(codec.dct32_fwd(x), z)
         assert np.array_equal(codec.dct32_inv(z), oracle.dct32_inv(z, threads=8))

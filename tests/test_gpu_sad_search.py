@@ -14,23 +14,19 @@ def codec():
     return x266_amd.Codec(0)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("w,h,rng,tile_rows", [
     (64, 16, 4, 2), (64, 48, 8, 1), (64, 48, 8, 2), (64, 48, 8, 4), (136, 72, 16, 2), (136, 72, 16, 4),
     (72, 40, 1, 2), (200, 24, 33, 2), (8, 8, 5, 2), (128, 64, 64, 2), (24, 136, 64, 4), (40, 40, 31, 4), (72, 72, 36, 4), (64, 64, 3, 2)])
-def test_every_candidate_cost_and_winner(codec, oracle, w, h, rng, tile_rows, variant):
+def test_every_candidate_cost_and_winner(codec, oracle, w, h, rng, tile_rows):
     pad = rng + 3
     cur, refp = me_frames(w, h, pad, 300 + w + h + rng, mv=(min(rng, 3), -min(rng, 2)))
     saved = codec.get_option("me_tile_rows")
-    saved_v = codec.get_option("sad_me_variant")
     codec.set_option("me_tile_rows", tile_rows)
-    codec.set_option("sad_me_variant", variant)
     try:
         mv, cost, costs = codec.satd_search(cur, refp, pad, rng, want_costs=True, metric="sad")
         mv2, cost2, _ = codec.satd_search(cur, refp, pad, rng, metric="sad")       # the search-only instantiation
     finally:
         codec.set_option("me_tile_rows", saved)
-        codec.set_option("sad_me_variant", saved_v)
     omv, ocost, ocosts = oracle.satd_search(cur, refp, pad, rng, threads=8, want_costs=True, metric="sad")
     assert np.array_equal(costs, ocosts)
     assert np.array_equal(cost, ocost) and np.array_equal(mv, omv)

@@ -148,20 +148,10 @@ def test_mixed_per_ctu_forward_32_by_offsets(codec, oracle):
     assert np.array_equal(dout.download(np.int16, x.size).reshape(64, 1024), oracle.dct32_fwd(x))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("n_tiles,with_offsets", [(1, False), (7, False), (403, False), (403, True), (4096, False), (20011, False)])
-def test_mixed_tiles_one_launch(codec, oracle, n_tiles, with_offsets, variant):
+def test_mixed_tiles_one_launch(codec, oracle, n_tiles, with_offsets):
     """xTransformTilesDev: every tile its own (type, size) class, one launch forward and one inverse, equal to the
-    oracle's per-class transforms of the tile's blocks.  variant 1 = the persistent kernel with the class images in LDS
-    (kept for the A/B of profiles/r02_tiles_one_launch.txt)."""
-    codec.set_option("tile_variant", variant)
-    try:
-        _mixed_tiles_one_launch(codec, oracle, n_tiles, with_offsets)
-    finally:
-        codec.set_option("tile_variant", 0)
-
-
-def _mixed_tiles_one_launch(codec, oracle, n_tiles, with_offsets):
+    oracle's per-class transforms of the tile's blocks."""
     rng = np.random.default_rng(n_tiles + 17 * with_offsets)
     cls_list = CLASSES + MIXED
     pick = rng.integers(0, len(cls_list), n_tiles)

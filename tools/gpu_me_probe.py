@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer probe: full-search timing at 4K (GPU box), HIP events per launch.
-usage: gpu_me_probe.py [satd|sad|all]"""
+"""Developer probe: full-search timing at 4K (GPU box), HIP events per launch, per tile height.
+usage: gpu_me_probe.py [satd|sad|all]   -- every configuration's result is compared with the first one's"""
 import os, sys, statistics
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,18 +30,22 @@ def timed(fn, reps=20):
 
 ref = None
 if what in ("satd", "all"):
-    for var, tr, rp, wg, sp in ((3, 4, 2, 0, 1), (4, 4, 2, 0, 0), (4, 4, 2, 512, 0), (4, 4, 2, 384, 0), (4, 8, 2, 384, 0), (4, 8, 2, 512, 0), (4, 8, 2, 256, 0), (4, 4, 2, 0, 0)):
-        cd.set_option("me_tile_rows", tr); cd.set_option("me_variant", var); cd.set_option("me_row_pairs", rp); cd.set_option("me_wg_threads", wg); cd.set_option("me_splits", sp)
+    for tr in (8, 4, 2, 0):
+        cd.set_option("me_tile_rows", tr)
         fn = lambda: cd.satd_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr())
         med, mn = timed(fn)
         res = best.clone()
         if ref is None: ref = res
-        print("satd variant=%d tile_rows=%d units=%d wg=%3d splits=%d: median %.3f ms (min %.3f)  %.3e SATD/s  frac_of_floor %.3f  same_result=%s"
-              % (var, tr, rp, wg, sp, med, mn, ncand / med * 1e3, 1.7554 / med, bool(torch.equal(res, ref))), flush=True)
-    cd.set_option("me_tile_rows", 0); cd.set_option("me_variant", 4); cd.set_option("me_row_pairs", 2); cd.set_option("me_wg_threads", 0); cd.set_option("me_splits", 0)
+        print("satd tile_rows=%d: median %.3f ms (min %.3f)  %.3e SATD/s  frac_of_floor %.3f  same_result=%s"
+              % (tr, med, mn, ncand / med * 1e3, 1.7554 / med, bool(torch.equal(res, ref))), flush=True)
+    cd.set_option("me_tile_rows", 0)
 if what in ("sad", "all"):
-    for var, tr in ((1, 4), (2, 4), (2, 2)):
-        cd.set_option("me_tile_rows", tr); cd.set_option("sad_me_variant", var)
+    ref = None
+    for tr in (4, 2, 1, 0):
+        cd.set_option("me_tile_rows", tr)
         med, mn = timed(lambda: cd.sad_search_dev(dc.data_ptr(), cur.strides[0], org, refp.strides[0], w, h, rng, best.data_ptr()))
-        print("SAD search variant=%d tile_rows=%d: median %.3f ms (min %.3f)  %.3e SAD/s  frac_of_floor %.3f" % (var, tr, med, mn, ncand / med * 1e3, 0.8777 / med), flush=True)
-    cd.set_option("me_tile_rows", 0); cd.set_option("sad_me_variant", 2)
+        res = best.clone()
+        if ref is None: ref = res
+        print("SAD search tile_rows=%d: median %.3f ms (min %.3f)  %.3e SAD/s  frac_of_floor %.3f  same_result=%s"
+              % (tr, med, mn, ncand / med * 1e3, 0.8777 / med, bool(torch.equal(res, ref))), flush=True)
+    cd.set_option("me_tile_rows", 0)

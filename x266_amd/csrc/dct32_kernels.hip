@@ -33,7 +33,7 @@
 //
 // Kernels in this file: dct32_lds_kernel (default: LDS-staged line-dense traffic, forward / inverse),
 // dct32_fwdinv_lds_kernel (coefficients + reconstruction in one pass), dct32_from_tiles_kernel
-// (residual formation fused in), dct32_kernel (direct fragment loads, streaming or persistent: A/B only).
+// (residual formation fused in), dct32_kernel (direct fragment loads: A/B only).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -66,14 +66,10 @@ __device__ __forceinline__ void inv_block(const v4i &w0, const v4i &w1, const La
 }
 
 // ---- kernel ----------------------------------------------------------------
-// Each wave transforms `count` blocks: start, start + stride, ...  Two launch
-// shapes use it:
-//   streaming  : stride 1, count = blocks_per_wave, one wave per chunk, a grid
-//                as large as the batch.  The hardware dispatcher then walks the
-//                batch in address order, which is what HBM likes best (a plain
-//                one-element-per-thread copy is ~15 % faster on this chip than
-//                any persistent grid-stride copy).
-//   persistent : stride = number of waves, resident grid, grid-stride.
+// Each wave transforms blocks_per_wave consecutive blocks, one wave per chunk, a grid as large as
+// the batch: the hardware dispatcher then walks the batch in address order,
+// which is what HBM likes best (a plain one-element-per-thread copy is ~15 % faster on this chip than
+// any persistent grid-stride copy; the persistent launch of rounds 1-2 is gone for that reason).
 // The next block's loads are issued before the current block's arithmetic
 // (two register sets in ping-pong).
 // MODE 0 forward, 1 inverse, 2 pass-through (diagnostic only: same loads, stores and loop,
@@ -86,16 +82,9 @@ __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ 
 {
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    size_t b, stride, end;
-    if (blocks_per_wave) {                    // streaming: contiguous chunk
-        b = wave * blocks_per_wave;
-        stride = 1;
-        end = b + blocks_per_wave < n_blocks ? b + blocks_per_wave : n_blocks;
-    } else {                                  // persistent: grid-stride
-        b = wave;
-        stride = ((size_t)gridDim.x * blockDim.x) >> 6;
-        end = n_blocks;
-    }
+    size_t b = wave * blocks_per_wave;
+    const size_t stride = 1;
+    const size_t end = b + blocks_per_wave < n_blocks ? b + blocks_per_wave : n_blocks;
     if (b >= end) return;
 
     const size_t lane_off = (size_t)(lane & 31) * 64 + (size_t)(lane >> 5) * 32;   // bytes
@@ -392,21 +381,13 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
     if (n_blocks == 0) return hipSuccess;
     const unsigned tpb = cfg.wg_threads;                       // 64 .. 256, multiple of 64
     const size_t waves_per_wg = tpb / 64;
-    unsigned bpw = 0;
-    size_t wgs;
-    if (cfg.variant == 0) {                                    // streaming launch
-        bpw = units_per_wave_for(cfg, n_blocks);
-        const size_t waves = (n_blocks + bpw - 1) / bpw;
-        wgs = (waves + waves_per_wg - 1) / waves_per_wg;
-    } else {                                                   // persistent launch
-        wgs = (n_blocks + waves_per_wg - 1) / waves_per_wg;
-        const size_t cap = (size_t)cfg.cu_count * (size_t)cfg.wgs_per_cu;
-        if (wgs > cap) wgs = cap;
-    }
+    const unsigned bpw = units_per_wave_for(cfg, n_blocks);
+    const size_t waves = (n_blocks + bpw - 1) / bpw;
+    const size_t wgs = (waves + waves_per_wg - 1) / waves_per_wg;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs), block(tpb);
     const int mode = cfg.passthrough ? 2 : (inverse ? 1 : 0);
-    if (cfg.lds_stage && cfg.variant == 0) {                   // line-dense global traffic through a private LDS slot
+    if (cfg.lds_stage) {                                       // line-dense global traffic through a private LDS slot
         const size_t per_wave = cfg.lds_bytes_per_wave < 2048 ? 2048 : (size_t)cfg.lds_bytes_per_wave;
         const size_t lds = waves_per_wg * per_wave + (size_t)cfg.lds_pad_bytes;
         if (mode == 0 && (cfg.nontemporal & 11) == 11) hipLaunchKernelGGL((dct32_lds_kernel<0, 11>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);

@@ -435,9 +435,224 @@ __global__ __launch_bounds__(WG, WPS) void satd_search_kernel(const MeParams P, 
 #endif
 }
 
+
+// ============================================================================
+// The same search with the cheaper metric: cost = sum |cur - ref| over the 8x8 block, i.e.
+// sad() of riscv/programs/benchmarks/sad/sad.c:28-39 at n = 8.  No transform, so the structure is its own:
+// lane = candidate column; the 8 pixels of a reference row at that column (two dwords, aligned once with
+// v_alignbit) belong to the eight candidates whose block contains the row, one per block row p = 0..7 -- eight
+// rotating accumulators per block, the slot that has just received p = 7 is a finished candidate.
+//   * one pass = ONE block column x 64 candidate columns starting AT the column's own window, walked over all
+//     window rows for the TBY vertically adjacent blocks of the tile (they share the fetched row and the aligned
+//     columns): a window of 2R+1 = 64 G + rem columns is G passes of 64 valid lanes;
+//   * the rem extra columns (the "+1" at R = 64) go to narrow passes with lane = candidate ROW (rem <= 8), or to
+//     one masked pass (rem > 8);
+//   * round 3: the accumulators ARE the keys.  v_sad_hi_u8 adds its sum at bit 16, so a chain started from the
+//     candidate's window position (row << 8 | column) ends as (cost << 16 | position): per (row, block) the
+//     bookkeeping is one v_min_u32 (round 2: v_lshl_or + v_min after 16 v_sad_u8).  Passes are handed to the
+//     waves dynamically (they are few and uneven).
+// ============================================================================
+__device__ __forceinline__ uint32_t sadhi8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_hi_u8(a, b, c); }
+
+template <int TBY, bool COSTS>
+__global__ __launch_bounds__(256) void sad_search_kernel(const MeParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NBLK = kTileBlocksX * TBY;
+    constexpr uint32_t DEAD = 0xC0000000u;                             // above every (cost << 16 | position), no carry out when a cost is added
+    const int R = P.range, span = 2 * R + 1;
+    const int n_rows = 8 * (TBY - 1) + span;                           // candidate rows of the tile
+    const int win_rows = n_rows + 7;
+    uint32_t *best_lds = reinterpret_cast<uint32_t *>(smem);           // [NBLK <= 32] minima, then the pass counter: 256-byte header
+    uint32_t *next_item = best_lds + NBLK;
+    unsigned char *win = smem + 256;
+
+    const int tid = threadIdx.x, lane = tid & 63, n_waves = 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
+    const int x0 = tx * (8 * kTileBlocksX), y0 = ty * (8 * TBY);
+
+    {   // reference window, raw pixels (edge-clamped like the SATD search): whole rows per wave, eight in flight
+        typedef uint32_t u32_any_align __attribute__((aligned(1)));
+        const int dwords_per_row = (8 * (kTileBlocksX - 1) + span + 7 + 3 + 3) >> 2;
+        const int gx0 = x0 - R + 4 * lane;
+        const bool inside = gx0 + 3 <= P.width + R - 1;
+        const int last_x = P.width + R - 1, last_y = P.height + R - 1;
+        for (int ry0 = wave; ry0 < win_rows; ry0 += 8 * n_waves) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ry = ry0 + u * n_waves;
+                int gy = y0 - R + (ry < win_rows ? ry : win_rows - 1);
+                gy = gy > last_y ? last_y : gy;
+                const uint8_t *row = P.ref + (long long)gy * P.ref_stride;
+                if (inside) v[u] = *reinterpret_cast<const u32_any_align *>(row + gx0);
+                else {
+                    v[u] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { const int gx = gx0 + b > last_x ? last_x : gx0 + b; v[u] |= (uint32_t)row[gx] << (8 * b); }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ry = ry0 + u * n_waves;
+                if (ry < win_rows && lane < dwords_per_row) reinterpret_cast<uint32_t *>(win + ry * kPitch)[lane] = v[u];
+            }
+        }
+    }
+    if (tid < NBLK) best_lds[tid] = 0xFFFFFFFFu;
+    if (tid == 0) *next_item = (uint32_t)n_waves;
+    __syncthreads();
+
+    int blocks_left_x = P.blocks_x - tx * kTileBlocksX, blocks_left_y = P.blocks_y - ty * TBY;
+    blocks_left_x = blocks_left_x > kTileBlocksX ? kTileBlocksX : blocks_left_x;
+    blocks_left_y = blocks_left_y > TBY ? TBY : blocks_left_y;
+    const int G = span >> 6, rem = span - 64 * G;                       // full 64-column passes, extra columns
+    const int n_wide = G + (rem > 8 ? 1 : 0);                           // + one masked pass
+    const int n_narrow_cols = rem > 8 ? 0 : rem;
+    const int n_chunks = (n_rows + 63) >> 6;
+    const int n_main = kTileBlocksX * n_wide;
+    const int n_items = n_main + kTileBlocksX * n_narrow_cols * n_chunks;
+
+    int fetched = 0;
+    for (int item = wave; item < n_items; item = __builtin_amdgcn_readfirstlane(fetched)) {
+        fetched = lane == 0 ? (int)atomicAdd(next_item, 1u) : 0;
+        const bool wide = item < n_main;
+        int i, gq = 0, ncol = 0, chunk = 0;
+        if (wide) { i = item & (kTileBlocksX - 1); gq = item >> 3; }            // block column fastest: the heavy passes come first
+        else { const int it = item - n_main; i = it & (kTileBlocksX - 1); const int rest = it >> 3; ncol = rest / n_chunks; chunk = rest - ncol * n_chunks; }
+        if (i >= blocks_left_x) continue;
+        // Current rows of the column's TBY blocks, the same in every lane, held in VGPRs: TBY x 16 scalars next to the
+        // loop state do not fit the SGPR file, and the v_sad chain does not care which file its operand comes from.
+        // `lane0` is a zero the compiler cannot see through, so these stay vector loads.
+        int lane0;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
+        uint32_t c[TBY][8][2];
+#pragma unroll
+        for (int j = 0; j < TBY; ++j) {
+            const int by = ty * TBY + (j < blocks_left_y ? j : blocks_left_y - 1);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(P.cur + (long long)(by * 8 + p) * P.cur_stride + (tx * kTileBlocksX + i) * 8) + lane0;
+                c[j][p][0] = q[0];
+                c[j][p][1] = q[1];
+            }
+        }
+        uint32_t best[TBY];
+#pragma unroll
+        for (int j = 0; j < TBY; ++j) best[j] = 0xFFFFFFFFu;
+
+        if (wide) {
+            const int col = 8 * i + 64 * gq + lane;                    // window column of this lane's candidates
+            const bool lane_ok = 64 * gq + lane < span;                 // false only in the masked pass
+            const int sh = (col & 3) * 8;
+            const unsigned char *colbase = win + (col & ~3);
+            uint32_t acc[TBY][8];
+#pragma unroll
+            for (int j = 0; j < TBY; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[j][k] = 0;
+            uint32_t pid = (uint32_t)col | (lane_ok ? 0u : DEAD);       // position of the candidate STARTED by row ry: (ry, col)
+            // Eight window rows.  STEADY: every block row of the tile is inside its band and finishes a candidate on every
+            // one of the eight rows (all but the first and last few groups), so the body carries no wave-uniform tests at all.
+            auto rows8 = [&](auto steady_tag, int ry8) {
+                constexpr bool STEADY = decltype(steady_tag)::value;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int ry = ry8 + m;
+                    if (!STEADY && ry >= win_rows) break;                // wave-uniform
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(colbase + ry * kPitch);
+                    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                    const uint32_t a0 = __builtin_amdgcn_alignbit(d1, d0, sh), a1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+#pragma unroll
+                    for (int j = 0; j < TBY; ++j) {
+                        const int rel = ry - 8 * j;                      // row inside block row j's band
+                        if (!STEADY && (rel < 0 || rel >= span + 7 || j >= blocks_left_y)) continue;      // wave-uniform
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) {
+                            const int slot = (m - p) & 7;
+                            const uint32_t init = p == 0 ? pid : acc[j][slot];   // a candidate's chain starts from its position
+                            acc[j][slot] = sadhi8(a1, c[j][p][1], sadhi8(a0, c[j][p][0], init));
+                        }
+                        const int dyi = rel - 7;                         // the candidate row that has now seen all 8 block rows
+                        if (STEADY || (dyi >= 0 && dyi < span)) {        // wave-uniform
+                            const uint32_t key = acc[j][(m + 1) & 7];    // (cost << 16 | row << 8 | column)
+                            best[j] = key < best[j] ? key : best[j];
+                            if (COSTS && lane_ok) {
+                                const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
+                                P.costs[blk * (size_t)(span * span) + (size_t)dyi * span + (size_t)(64 * gq + lane)] = key >> 16;
+                            }
+                        }
+                    }
+                    pid += 256u;
+                }
+            };
+            const bool full_tile = blocks_left_y == TBY;
+            for (int ry8 = 0; ry8 < win_rows; ry8 += 8) {
+                // steady: min rel = ry8 - 8 (TBY - 1) >= 7 and max rel = ry8 + 7 < span + 7
+                if (full_tile && ry8 >= 8 * TBY && ry8 < span) rows8(std::true_type{}, ry8);
+                else                                           rows8(std::false_type{}, ry8);
+            }
+        } else {
+            // narrow pass: one extra column, lane = candidate row (window row 64 * chunk + lane)
+            const int col = 8 * i + 64 * G + ncol;
+            const int prow = 64 * chunk + lane;
+            const int lrow = prow < n_rows - 1 ? prow : n_rows - 1;       // clamp the loads, not the position
+            const int sh = (col & 3) * 8;
+            const unsigned char *base = win + lrow * kPitch + (col & ~3);
+            uint32_t a[8][2];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(base + p * kPitch);
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                a[p][0] = __builtin_amdgcn_alignbit(d1, d0, sh);
+                a[p][1] = __builtin_amdgcn_alignbit(d2, d1, sh);
+            }
+            const uint32_t pid = (uint32_t)(prow << 8 | col);
+#pragma unroll
+            for (int j = 0; j < TBY; ++j) {
+                if (j >= blocks_left_y || 64 * chunk + 63 < 8 * j || 64 * chunk >= 8 * j + span) continue;   // wave-uniform
+                const int dyi = prow - 8 * j;
+                const bool ok = (unsigned)dyi < (unsigned)span;
+                uint32_t key = ok ? pid : (pid | DEAD);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) key = sadhi8(a[p][1], c[j][p][1], sadhi8(a[p][0], c[j][p][0], key));
+                best[j] = key < best[j] ? key : best[j];
+                if (COSTS && ok) {
+                    const size_t blk = (size_t)(ty * TBY + j) * P.blocks_x + (tx * kTileBlocksX + i);
+                    P.costs[blk * (size_t)(span * span) + (size_t)dyi * span + (size_t)(64 * G + ncol)] = key >> 16;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TBY; ++j) {
+            uint32_t v = best[j];
+#pragma unroll
+            for (int mm = 32; mm >= 1; mm >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)v, mm);
+                v = o < v ? o : v;
+            }
+            if (lane == 0 && j < blocks_left_y) atomicMin(&best_lds[j * kTileBlocksX + i], v);
+        }
+    }
+    __syncthreads();
+    if (tid < NBLK) {
+        const int bi = tid % kTileBlocksX, bj = tid / kTileBlocksX;
+        const int bx = tx * kTileBlocksX + bi, by = ty * TBY + bj;
+        if (bx < P.blocks_x && by < P.blocks_y) {
+            const uint32_t key = best_lds[tid];
+            x266_me_result_t res;
+            res.mvx = (int16_t)((int)(key & 0xFFu) - 8 * bi - R);
+            res.mvy = (int16_t)((int)((key >> 8) & 0xFFu) - 8 * bj - R);
+            res.cost = key >> 16;
+            P.best[(size_t)by * P.blocks_x + bx] = res;
+        }
+    }
+}
+
 }  // namespace
 
-hipError_t launch_satd_search5(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
+hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
                                int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
                                int tile_rows, uint32_t *d_coef_scratch, int cu_count, hipStream_t stream)
 {
@@ -487,6 +702,29 @@ hipError_t launch_satd_search5(const uint8_t *d_cur, long long cur_stride, const
 #endif
     if (tby == 8) X266_ME5(8); else if (tby == 4) X266_ME5(4); else if (tby == 1) X266_ME5(1); else X266_ME5(2);
 #undef X266_ME5
+    return hipGetLastError();
+}
+
+hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
+                              int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
+                              int tile_rows, hipStream_t stream)
+{
+    MeParams P;
+    P.cur = d_cur; P.ref = d_ref; P.cur_stride = cur_stride; P.ref_stride = ref_stride;
+    P.width = width; P.height = height; P.range = range;
+    P.blocks_x = width / 8; P.blocks_y = height / 8;
+    P.tiles_x = (P.blocks_x + kTileBlocksX - 1) / kTileBlocksX;
+    const int tby = tile_rows >= 4 ? 4 : (tile_rows == 1 ? 1 : 2);   // 0 (automatic) = 2: as fast as 4 on a 4K frame, finer-grained on small ones
+    const int tiles_y = (P.blocks_y + tby - 1) / tby;
+    const int span = 2 * range + 1;
+    const int n_rows = 8 * (tby - 1) + span;
+    P.best = d_best; P.costs = d_costs;
+    dim3 grid((unsigned)(P.tiles_x * tiles_y)), block(256);
+    const size_t lds = 256 + (size_t)(n_rows + 7) * kPitch;
+#define X266_SADS(T) do { if (d_costs) hipLaunchKernelGGL((sad_search_kernel<T, true>), grid, block, lds, stream, P); \
+                          else         hipLaunchKernelGGL((sad_search_kernel<T, false>), grid, block, lds, stream, P); } while (0)
+    if (tby == 4) X266_SADS(4); else if (tby == 1) X266_SADS(1); else X266_SADS(2);
+#undef X266_SADS
     return hipGetLastError();
 }
 

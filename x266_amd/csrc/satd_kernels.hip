@@ -112,16 +112,9 @@ __global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict_
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t n_groups = (n_blocks + 31) >> 5;           // 32 blocks per wave-iteration
-    size_t g, stride, end;
-    if (groups_per_wave) {                                  // streaming launch (see dct32_kernels.hip)
-        g = wave * groups_per_wave;
-        stride = 1;
-        end = g + groups_per_wave < n_groups ? g + groups_per_wave : n_groups;
-    } else {                                                // persistent grid-stride
-        g = wave;
-        stride = ((size_t)gridDim.x * blockDim.x) >> 6;
-        end = n_groups;
-    }
+    size_t g = wave * groups_per_wave;                      // streaming launch (see dct32_kernels.hip)
+    const size_t stride = 1;
+    const size_t end = g + groups_per_wave < n_groups ? g + groups_per_wave : n_groups;
     if (g >= end) return;
     const int blk = lane & 31, half = lane >> 5;
     const SatdOperands H = make_satd_operands(lane);
@@ -315,20 +308,12 @@ hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_block
     const size_t groups = (n_blocks + 31) / 32;
     const unsigned tpb = cfg.wg_threads;
     const size_t waves_per_wg = tpb / 64;
-    unsigned gpw = 0;
-    size_t wgs;
-    if (cfg.variant == 0) {                                    // streaming launch
-        gpw = units_per_wave_for(cfg, groups);
-        const size_t waves = (groups + gpw - 1) / gpw;
-        wgs = (waves + waves_per_wg - 1) / waves_per_wg;
-    } else {                                                   // persistent launch
-        wgs = (groups + waves_per_wg - 1) / waves_per_wg;
-        const size_t cap = (size_t)cfg.cu_count * (size_t)cfg.wgs_per_cu;
-        if (wgs > cap) wgs = cap;
-    }
+    const unsigned gpw = units_per_wave_for(cfg, groups);
+    const size_t waves = (groups + gpw - 1) / gpw;
+    const size_t wgs = (waves + waves_per_wg - 1) / waves_per_wg;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs), block(tpb);
-    if (cfg.lds_stage && cfg.variant == 0) {
+    if (cfg.lds_stage) {
         const size_t lds = waves_per_wg * (size_t)(cfg.lds_bytes_per_wave < 4096 ? 4096 : cfg.lds_bytes_per_wave) + (size_t)cfg.lds_pad_bytes;
         if (cfg.nontemporal & 1) hipLaunchKernelGGL((satd8x8_lds_kernel<true>), grid, block, lds, stream, d_diff, d_out, n_blocks, gpw);
         else                     hipLaunchKernelGGL((satd8x8_lds_kernel<false>), grid, block, lds, stream, d_diff, d_out, n_blocks, gpw);

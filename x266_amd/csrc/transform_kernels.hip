@@ -408,77 +408,6 @@ __global__ __launch_bounds__(256) void tr_tiles_kernel(const int16_t *__restrict
     }
 }
 
-// A/B variant ("tile_variant" = 1): the round-1 review's proposal.  Persistent workgroups of eight waves copy the operand
-// images of all sixteen classes (TileOpsSoA, 42 KiB) into LDS once and then walk the tiles grid-stride (wave w of W
-// takes tiles w, w + W, ...: at any moment the chip works on one dense window of the buffer, as the streaming launch
-// does); a tile's class byte still comes through the scalar cache, its images now through ds_read instead of L1.
-template <bool INVERSE, bool NT>
-__global__ __launch_bounds__(512) void tr_tiles_persistent_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t n_tiles,
-                                                                  const uint32_t *__restrict__ tile_offsets,
-                                                                  const uint8_t *__restrict__ tile_class, const TileOpsSoA *__restrict__ T)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
-    TileOpsSoA *L = reinterpret_cast<TileOpsSoA *>(stage);
-    {
-        const v4i *src = reinterpret_cast<const v4i *>(T);
-        v4i *dst = reinterpret_cast<v4i *>(stage);
-        for (unsigned i = threadIdx.x; i < sizeof(TileOpsSoA) / 16; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
-    unsigned char *slot = stage + ((sizeof(TileOpsSoA) + 127) & ~(size_t)127) + (threadIdx.x >> 6) * 2048;
-    const int lane = threadIdx.x & 63;
-    const size_t n_waves = (size_t)gridDim.x * (blockDim.x >> 6);
-    size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (t >= n_tiles) return;
-    t = (size_t)__builtin_amdgcn_readfirstlane((int)(t & 0xFFFFFFFFu)) | (t & ~(size_t)0xFFFFFFFFu);
-    int cls = tile_class_of(tile_class, t);
-    size_t base = (tile_offsets ? (size_t)tile_offsets[t] : t * 1024) * 2;
-    v4i g0 = load16<NT>(reinterpret_cast<const char *>(in) + base + lane * 16);
-    v4i g1 = load16<NT>(reinterpret_cast<const char *>(in) + base + 1024 + lane * 16);
-    for (; t < n_tiles; t += n_waves) {
-        const LaneConsts k = load_tile_consts(L, cls, lane);
-        v16i c2r;
-        if (INVERSE) {
-            const int *s0 = L->c2r[cls][lane >> 5];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c2r[r] = s0[r];
-        }
-        const int cur_cls = cls;
-        const size_t cur_base = base;
-        *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
-        *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
-        if (t + n_waves < n_tiles) {
-            cls = tile_class_of(tile_class, t + n_waves);
-            base = (tile_offsets ? (size_t)tile_offsets[t + n_waves] : (t + n_waves) * 1024) * 2;
-            g0 = load16<NT>(reinterpret_cast<const char *>(in) + base + lane * 16);
-            g1 = load16<NT>(reinterpret_cast<const char *>(in) + base + 1024 + lane * 16);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (INVERSE) {
-            switch (cur_cls & 3) {
-            case 0: inv_tile_in_slot<2>(slot, lane, k, c2r); break;
-            case 1: inv_tile_in_slot<3>(slot, lane, k, c2r); break;
-            case 2: inv_tile_in_slot<4>(slot, lane, k, c2r); break;
-            default: inv_tile_in_slot<5>(slot, lane, k, c2r); break;
-            }
-        } else {
-            switch (cur_cls & 3) {
-            case 0: fwd_tile_in_slot<2>(slot, lane, k); break;
-            case 1: fwd_tile_in_slot<3>(slot, lane, k); break;
-            case 2: fwd_tile_in_slot<4>(slot, lane, k); break;
-            default: fwd_tile_in_slot<5>(slot, lane, k); break;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
-        const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
-        __builtin_amdgcn_wave_barrier();
-        char *dst = reinterpret_cast<char *>(out) + cur_base + lane * 16;
-        store16m<NT ? 2 : 0>(dst, s0);
-        store16m<NT ? 2 : 0>(dst + 1024, s1);
-    }
-}
-
 }  // namespace
 
 hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
@@ -549,18 +478,6 @@ hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_
                                   const uint8_t *d_tile_class, const TileOpsSoA *d_class_ops, const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
-    if (cfg.variant == 1) {                                               // persistent workgroups, class images in LDS (A/B)
-        const bool ntp = !d_tile_offsets && (cfg.nontemporal & 3);
-        const size_t ldsp = ((sizeof(TileOpsSoA) + 127) & ~(size_t)127) + 8 * 2048;
-        size_t wgs = (size_t)cfg.cu_count * (size_t)(cfg.wgs_per_cu > 0 ? cfg.wgs_per_cu : 2);
-        if (wgs * 8 > n_tiles) wgs = (n_tiles + 7) / 8;
-        dim3 gridp((unsigned)wgs), blockp(512);
-#define X266_TTP(INV, NTV) hipLaunchKernelGGL((tr_tiles_persistent_kernel<INV, NTV>), gridp, blockp, ldsp, stream, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, d_class_ops)
-        if (inverse) { if (ntp) X266_TTP(true, true); else X266_TTP(true, false); }
-        else         { if (ntp) X266_TTP(false, true); else X266_TTP(false, false); }
-#undef X266_TTP
-        return hipGetLastError();
-    }
     const unsigned tpw = units_per_wave_for(cfg, n_tiles);
     const size_t waves = (n_tiles + tpw - 1) / tpw;
     const unsigned tpb = (unsigned)cfg.wg_threads;

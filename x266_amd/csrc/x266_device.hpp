@@ -51,12 +51,10 @@ __device__ __forceinline__ void store16m(void *p, const v4i &v)
 
 struct LaunchCfg {
     int cu_count;        // compute units of the device
-    int wgs_per_cu;      // persistent launch: resident workgroups per CU
     int adaptive;        // shrink units_per_wave on small batches so the grid still fills the chip
     int nontemporal;     // bit 0: nontemporal loads, bit 1: nontemporal stores in the line-dense (LDS-staged)
                          // kernels; bit 2: the same hints in the direct fragment-pattern kernels (harmful there);
                          // bit 3: line-dense stores use "sc1 nt" instead of "nt"
-    int variant;         // 0 = streaming launch (grid covers the batch), 1 = persistent grid-stride
     int units_per_wave;  // streaming launch: consecutive units (DCT blocks / 32-block SATD groups) per wave
     int wg_threads;      // workgroup size, multiple of 64
     int lds_pad_bytes;   // unused dynamic LDS per workgroup: caps resident waves per CU (fewer bytes in flight)
@@ -86,9 +84,6 @@ hipError_t launch_intra32_predict(const x266_intra_ref_t *d_refs, const uint8_t 
 hipError_t launch_intra32_costs(const x266_intra_ref_t *d_refs, const uint8_t *d_src, uint32_t *d_costs, uint8_t *d_best_mode,
                                 size_t n, hipStream_t stream);
 hipError_t launch_satd8x8_butterfly(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks, const LaunchCfg &cfg, hipStream_t stream);
-hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
-                             int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
-                             int tile_rows, int variant, hipStream_t stream);
 hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles, const uint32_t *d_tile_offsets,
                                   const uint8_t *d_tile_class, const TileOpsSoA *d_class_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_dct32_butterfly(const int16_t *d_in, int16_t *d_out, size_t n_blocks, hipStream_t stream);
@@ -107,12 +102,11 @@ hipError_t launch_satd8x8_from_tiles(const x266_ref_block_t *d_cur, const x266_r
 hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks,
                           const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
-                              int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
-                              int tile_rows, int variant, int row_pairs, uint32_t *d_coef_scratch, int cu_count, int wg_threads,
-                              int me_splits, hipStream_t stream);
-hipError_t launch_satd_search5(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
                                int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
                                int tile_rows, uint32_t *d_coef_scratch, int cu_count, hipStream_t stream);
+hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
+                              int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
+                              int tile_rows, hipStream_t stream);
 hipError_t launch_sad(int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out, size_t n_blocks, hipStream_t stream);
 hipError_t launch_tile_convert(bool pack, x266_ref_block_t *d_tiles, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
                                long long strd_y, long long strd_c, int width, int height, hipStream_t stream);

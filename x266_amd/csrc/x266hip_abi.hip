@@ -31,15 +31,10 @@ struct x266hip_ctx {
     DctOps *d_tr_inv[kTypes][3] = {};
     TileOpsSoA *d_tile_fwd = nullptr, *d_tile_inv = nullptr;   // all sixteen classes, structure of arrays (xTransformTilesDev)
     int tile_lds_per_wave = 4096;                   // mixed-class tile kernel: LDS charged per wave (resident-wave cap)
-    int tile_variant = 0;                           // mixed-class tile kernel: 1 = persistent workgroups with the class images in LDS (A/B)
-    int tile_wgs_per_cu = 2;                        // ... its workgroups per CU
     int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (next tile's loads issued before this tile's arithmetic)
     // options
-    int wgs_per_cu_dct = 8;
-    int wgs_per_cu_inv = 5;
-    int wgs_per_cu_satd = 8;
     int nontemporal = 11;            // see LaunchCfg: nt loads + "sc1 nt" stores in the line-dense kernels (+3-5 %), none on fragment loads
-    int dct_variant = 0, satd_variant = 0;          // 0 streaming launch, 1 persistent; dct 2 = VALU butterfly (comparison only)
+    int dct_variant = 0, satd_variant = 0;          // 0 = matrix-core kernels, 2 = VALU butterfly (comparison only; 1, the persistent launch of rounds 1-2, is gone)
     // streaming launch: consecutive units per wave (measured optimum on MI355X, profiles/r01_sweep.txt)
     int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 2;
     int dct_fwdinv_blocks_per_wave = 4;
@@ -47,23 +42,25 @@ struct x266hip_ctx {
     int wg_threads = 256;
     int satd_wg_threads = 128;                      // SATD batch (staged): two-wave workgroups, 2 groups per wave (profiles/r01_satd_staged_nt.txt)
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
-    int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (variant 4: 8, 4 or 2; SAD search: 2), else 1, 2, 4, 8 (8: variant 4 only)
-    int me_row_pairs = 2;                           // variant 2: candidate row pairs scored per coefficient fetch (1..3)
-    int me_variant = 5;                             // 1 = LDS coefficients, 2 = scalar coefficients, 3 = scalar coefficients, 16x4 units, position keys (me_kernels.hip)
+    int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (SATD search: 8, 4 or 2; SAD search: 2), else 1, 2, 4, 8 (8: SATD search only)
     int intra_rounds = 4;                           // intra prediction: rounds of seven predictions per wave (next round's reference sets prefetched)
-    int sad_me_variant = 2;                         // SAD search: 1 = four horizontally adjacent blocks per pass (round 1), 2 = one block column per pass, aligned, position keys
-    int me_wg_threads = 0;                          // variants 3, 4: workgroup size (0 = 256 for variant 3, 512 for variant 4: two 8-wave workgroups per CU)
-    int me_splits = 0;                              // variant 3: workgroups per tile (0 = chosen so that the last round of workgroups is full)
-    // variant 2 scratch (128 B per 8x8 block of the current frame), ONE PER STREAM: searches enqueued on
-    // different streams never share it, and a buffer that a recorded graph may reference is never freed
-    // before the context is (outgrown buffers are retired, not released)
+    // motion-search scratch (128 B per 8x8 block of the current frame), ONE PER STREAM: searches enqueued on
+    // different streams never share it.  The table is bounded (kMeScratchMax streams, least recently used evicted
+    // after waiting for its last search); a buffer that was handed out during a stream capture may be referenced by
+    // a recorded graph and is kept until the context is freed (outgrown ones are retired, not released).
     struct MeScratch {
         hipStream_t stream;
         uint32_t *p;
         size_t bytes;
+        hipEvent_t last_use;
+        unsigned long long stamp;
+        bool pinned;
+        bool capturing_now;
     };
+    static constexpr size_t kMeScratchMax = 8;
     std::vector<MeScratch> me_scratch;
     std::vector<void *> me_retired;
+    unsigned long long me_stamp = 0;
     int tr_lds_stage = 1;                           // transform set, contiguous batches: stage tiles through LDS
     int tr_tiles_per_wave = 1;                      // transform set: 32x32 tiles per wave
     int tr32_simple = 0;                            // diagnostic: run DCT-II 32 through the transform-set kernel
@@ -126,16 +123,14 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
 {
     LaunchCfg c;
     c.cu_count = ctx->prop.multiProcessorCount;
-    c.wgs_per_cu = op == 0 ? ctx->wgs_per_cu_dct : (op == 1 ? ctx->wgs_per_cu_inv : ctx->wgs_per_cu_satd);
     c.nontemporal = ctx->nontemporal;
     c.adaptive = ctx->adaptive_per_wave;
-    c.variant = op == 2 ? ctx->satd_variant : (ctx->dct_variant == 2 ? 0 : ctx->dct_variant);   // 2 = butterfly, forward only
     c.units_per_wave = op == 2 ? ctx->satd_groups_per_wave : (op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave);
     c.wg_threads = op == 2 ? ctx->satd_wg_threads : ctx->wg_threads;
     c.passthrough = ctx->passthrough;
     c.lds_stage = op == 2 ? ctx->satd_lds_stage : ctx->dct_lds_stage;
     c.lds_bytes_per_wave = op == 2 ? ctx->satd_lds_per_wave : (op == 1 ? ctx->dct_inv_lds_per_wave : ctx->dct_lds_per_wave);
-    if (op != 2 && ctx->dct_lds_stage && c.variant == 0) c.wg_threads = op == 1 ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
+    if (op != 2 && ctx->dct_lds_stage) c.wg_threads = op == 1 ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
     c.lds_pad_bytes = op == 2 ? ctx->lds_pad_satd : (op == 1 ? ctx->lds_pad_inv : ctx->lds_pad_dct);
     return c;
 }
@@ -265,7 +260,7 @@ void xHipCodecFree(x266hip_ctx *ctx)
             if (ctx->d_tr[type][l]) (void)hipFree(ctx->d_tr[type][l]);
             if (ctx->d_tr_inv[type][l]) (void)hipFree(ctx->d_tr_inv[type][l]);
         }
-    for (const x266hip_ctx::MeScratch &m : ctx->me_scratch) (void)hipFree(m.p);
+    for (const x266hip_ctx::MeScratch &m : ctx->me_scratch) { if (m.p) (void)hipFree(m.p); if (m.last_use) (void)hipEventDestroy(m.last_use); }
     for (void *q : ctx->me_retired) (void)hipFree(q);
     if (ctx->d_tile_fwd) (void)hipFree(ctx->d_tile_fwd);
     if (ctx->d_tile_inv) (void)hipFree(ctx->d_tile_inv);
@@ -299,21 +294,16 @@ struct OptionDesc {
 };
 
 static const OptionDesc kOptions[] = {
-    {"dct32_wgs_per_cu", &x266hip_ctx::wgs_per_cu_dct, 1, 64, 1},
-    {"dct32_inv_wgs_per_cu", &x266hip_ctx::wgs_per_cu_inv, 1, 64, 1},
-    {"satd_wgs_per_cu", &x266hip_ctx::wgs_per_cu_satd, 1, 64, 1},
     {"nontemporal", &x266hip_ctx::nontemporal, 0, 15, 1},
     {"adaptive_per_wave", &x266hip_ctx::adaptive_per_wave, 0, 1, 1},
-    {"dct32_variant", &x266hip_ctx::dct_variant, 0, 2, 1},
-    {"satd_variant", &x266hip_ctx::satd_variant, 0, 2, 1},
+    {"dct32_variant", &x266hip_ctx::dct_variant, 0, 2, 2},          // 0 or 2
+    {"satd_variant", &x266hip_ctx::satd_variant, 0, 2, 2},
     {"dct32_blocks_per_wave", &x266hip_ctx::dct_blocks_per_wave, 1, 4096, 1},
     {"dct32_inv_blocks_per_wave", &x266hip_ctx::dct_inv_blocks_per_wave, 1, 4096, 1},
     {"dct32_fwdinv_blocks_per_wave", &x266hip_ctx::dct_fwdinv_blocks_per_wave, 1, 4096, 1},
     {"satd_groups_per_wave", &x266hip_ctx::satd_groups_per_wave, 1, 4096, 1},
     {"tr_tiles_per_wave", &x266hip_ctx::tr_tiles_per_wave, 1, 64, 1},
     {"tile_tiles_per_wave", &x266hip_ctx::tile_tiles_per_wave, 0, 64, 1},
-    {"tile_variant", &x266hip_ctx::tile_variant, 0, 1, 1},
-    {"tile_wgs_per_cu", &x266hip_ctx::tile_wgs_per_cu, 1, 8, 1},
     {"tile_lds_bytes_per_wave", &x266hip_ctx::tile_lds_per_wave, 2048, 40960, 1},
     {"wg_threads", &x266hip_ctx::wg_threads, 64, 256, 64},
     {"satd_wg_threads", &x266hip_ctx::satd_wg_threads, 64, 256, 64},
@@ -329,12 +319,7 @@ static const OptionDesc kOptions[] = {
     {"dct32_inv_lds_pad_bytes", &x266hip_ctx::lds_pad_inv, 0, 160 * 1024, 1},
     {"satd_lds_pad_bytes", &x266hip_ctx::lds_pad_satd, 0, 160 * 1024, 1},
     {"me_tile_rows", &x266hip_ctx::me_tile_rows, 0, 8, 1},
-    {"me_variant", &x266hip_ctx::me_variant, 1, 5, 1},
-    {"sad_me_variant", &x266hip_ctx::sad_me_variant, 1, 2, 1},
     {"intra_rounds", &x266hip_ctx::intra_rounds, 1, 16, 1},
-    {"me_wg_threads", &x266hip_ctx::me_wg_threads, 0, 512, 64},
-    {"me_splits", &x266hip_ctx::me_splits, 0, 8, 1},
-    {"me_row_pairs", &x266hip_ctx::me_row_pairs, 1, 3, 1},
     {"diag_passthrough", &x266hip_ctx::passthrough, 0, 1, 1},
     {"diag_tr32_simple", &x266hip_ctx::tr32_simple, 0, 1, 1},
 };
@@ -483,8 +468,6 @@ int xTransformTilesDev(x266hip_ctx *ctx, int inverse, const int16_t *d_in, int16
     cfg.wg_threads = inverse ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
     cfg.lds_bytes_per_wave = ctx->tile_lds_per_wave;                    // dependent fetches per tile (class, images, data): more waves in flight pay here
     cfg.units_per_wave = ctx->tile_tiles_per_wave ? ctx->tile_tiles_per_wave : (inverse ? 2 : 1);   // measured optimum (profiles/r02_tiles_one_launch.txt)
-    cfg.variant = ctx->tile_variant;
-    cfg.wgs_per_cu = ctx->tile_wgs_per_cu;
     hipError_t e = launch_transform_tiles(inverse != 0, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class,
                                           inverse ? ctx->d_tile_inv : ctx->d_tile_fwd, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "tile transform launch", e);
@@ -600,6 +583,65 @@ int xTransformInvBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
     return X266HIP_OK;
 }
 
+// Coefficient scratch of the motion search for `stream`, at least as large as a width x height frame needs (tile-major
+// table of whole search tiles, partial edge tiles padded; tile heights 1, 2, 4, 8 all fit).  Allocation happens here,
+// i.e. on the first search of a stream or frame size -- or ahead of time through xHipMeScratchReserve, which is what a
+// host does before a stream capture or a real-time loop (hipMalloc is illegal under capture and synchronises).
+static int me_scratch_for(x266hip_ctx *ctx, hipStream_t stream, int width, int height, x266hip_ctx::MeScratch **out)
+{
+    const size_t need = (size_t)((width / 8 + 7) / 8) * 8 * (size_t)((height / 8 + 7) / 8) * 8 * 128;
+    x266hip_ctx::MeScratch *slot = nullptr;
+    for (x266hip_ctx::MeScratch &m : ctx->me_scratch)
+        if (m.stream == stream) slot = &m;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream) (void)hipStreamIsCapturing(stream, &cap);
+    (void)hipGetLastError();
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!slot) {
+        if (ctx->me_scratch.size() >= x266hip_ctx::kMeScratchMax && !capturing) {          // evict the least recently used stream's buffer
+            size_t victim = ctx->me_scratch.size();
+            for (size_t i = 0; i < ctx->me_scratch.size(); ++i)
+                if (!ctx->me_scratch[i].pinned && (victim == ctx->me_scratch.size() || ctx->me_scratch[i].stamp < ctx->me_scratch[victim].stamp)) victim = i;
+            if (victim < ctx->me_scratch.size()) {
+                x266hip_ctx::MeScratch &v = ctx->me_scratch[victim];
+                if (v.last_use) { (void)hipEventSynchronize(v.last_use); (void)hipEventDestroy(v.last_use); }
+                if (v.p) (void)hipFree(v.p);
+                ctx->me_scratch.erase(ctx->me_scratch.begin() + (long)victim);
+            }
+        }
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+        ctx->me_scratch.push_back({stream, nullptr, 0, ev, 0, false, false});
+        slot = &ctx->me_scratch.back();
+    }
+    if (need > slot->bytes) {
+        if (capturing) return fail(ctx, X266HIP_EINVAL, "motion search under stream capture needs xHipMeScratchReserve (or one search) beforehand");
+        void *fresh = nullptr;
+        if (hipMalloc(&fresh, need) != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "ME coefficient scratch");
+        if (slot->p) {
+            if (slot->pinned) ctx->me_retired.push_back(slot->p);        // a recorded graph may still use it
+            else { if (slot->last_use) (void)hipEventSynchronize(slot->last_use); (void)hipFree(slot->p); }
+        }
+        slot->p = (uint32_t *)fresh;
+        slot->bytes = need;
+        slot->pinned = false;
+    }
+    if (capturing) slot->pinned = true;
+    slot->capturing_now = capturing;
+    slot->stamp = ++ctx->me_stamp;
+    *out = slot;
+    return X266HIP_OK;
+}
+
+int xHipMeScratchReserve(x266hip_ctx *ctx, void *stream, int width, int height)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (width < 8 || height < 8) return fail(ctx, X266HIP_EINVAL, "xHipMeScratchReserve: frame size");
+    X_DEV(ctx);
+    x266hip_ctx::MeScratch *slot = nullptr;
+    return me_scratch_for(ctx, (hipStream_t)stream, width, height, &slot);
+}
+
 int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride, const uint8_t *d_ref,
                       intptr_t ref_stride, int width, int height, int range, x266_me_result_t *d_best,
                       uint32_t *d_costs, void *stream)
@@ -611,34 +653,14 @@ int xSatd8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_strid
     if (cur_stride < width || ref_stride < width + 2 * range) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: stride too small");
     if (((uintptr_t)d_best & 7u) || ((uintptr_t)d_costs & 3u)) return fail(ctx, X266HIP_EINVAL, "xSatd8x8SearchDev: unaligned output");
     X_DEV(ctx);
-    // tile-major table: whole search tiles (8 x up to 4 blocks), partial edge tiles padded (tile heights 1, 2, 4, 8 all fit)
-    const size_t need = (size_t)((width / 8 + 7) / 8) * 8 * (size_t)((height / 8 + 7) / 8) * 8 * 128      // coefficient table
-                        + (size_t)(width / 8) * (size_t)(height / 8) * 4;                                     // variant 3: one key per block
     uint32_t *d_me_coef = nullptr;
-    if (ctx->me_variant >= 2) {
-        x266hip_ctx::MeScratch *slot = nullptr;
-        for (x266hip_ctx::MeScratch &m : ctx->me_scratch)
-            if (m.stream == (hipStream_t)stream) slot = &m;
-        if (!slot) {
-            ctx->me_scratch.push_back({(hipStream_t)stream, nullptr, 0});
-            slot = &ctx->me_scratch.back();
-        }
-        if (need > slot->bytes) {                                     // must not happen inside a stream capture (hipMalloc)
-            void *fresh = nullptr;
-            if (hipMalloc(&fresh, need) != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "ME coefficient scratch");
-            if (slot->p) ctx->me_retired.push_back(slot->p);          // earlier launches / recorded graphs may still use it
-            slot->p = (uint32_t *)fresh;
-            slot->bytes = need;
-        }
-        d_me_coef = slot->p;
-    }
+    x266hip_ctx::MeScratch *slot = nullptr;
+    if (const int rc = me_scratch_for(ctx, (hipStream_t)stream, width, height, &slot)) return rc;
+    d_me_coef = slot->p;
     (void)hipGetLastError();
-    hipError_t e = ctx->me_variant == 5
-        ? launch_satd_search5(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
-                              d_best, d_costs, ctx->me_tile_rows, d_me_coef, ctx->prop.multiProcessorCount, (hipStream_t)stream)
-        : launch_satd_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
-                                      d_best, d_costs, ctx->me_tile_rows, ctx->me_variant, ctx->me_row_pairs, d_me_coef, ctx->prop.multiProcessorCount,
-                                      ctx->me_wg_threads, ctx->me_splits, (hipStream_t)stream);
+    hipError_t e = launch_satd_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
+                                      d_best, d_costs, ctx->me_tile_rows, d_me_coef, ctx->prop.multiProcessorCount, (hipStream_t)stream);
+    if (e == hipSuccess && slot->last_use && !slot->capturing_now) (void)hipEventRecord(slot->last_use, (hipStream_t)stream);   // what an eviction waits for
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "search launch", e);
     return X266HIP_OK;
 }
@@ -656,7 +678,7 @@ int xSad8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride
     if (((uintptr_t)d_best & 7u) || ((uintptr_t)d_costs & 3u)) return fail(ctx, X266HIP_EINVAL, "xSad8x8SearchDev: unaligned output");
     X_DEV(ctx);
     hipError_t e = launch_sad_search(d_cur, (long long)cur_stride, d_ref, (long long)ref_stride, width, height, range,
-                                     d_best, d_costs, ctx->me_tile_rows, ctx->sad_me_variant, (hipStream_t)stream);
+                                     d_best, d_costs, ctx->me_tile_rows, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "SAD search launch", e);
     return X266HIP_OK;
 }
