@@ -472,7 +472,7 @@ def main():
                 parity="metric = sad() of riscv/programs/benchmarks/sad/sad.c at n = 8; harness unpinned, as for the SATD search")
             del big, sm
 
-        # ---- BASELINE configs[3]: the VVC transform set, 2 GiB of residual per class
+        # ---- BASELINE configs[3]: the mixed transform set (DCT-II 4..32 + closed-form DST-VII 4/8/16), 2 GiB of residual per class
         if not args.no_transform_set:
             ts = {}
             zt = torch.empty_like(x)                       # own output buffer: z still holds the headline leg's result

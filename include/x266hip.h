@@ -114,9 +114,14 @@ int xDct32FwdInvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_coef,
  * (src_tb/satd.c:31-118), including its int16 wraparound.  d_out[n] uint32. */
 int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out,
                      size_t n_blocks, void *stream);
-/* The VVC transform set of BASELINE configs[3]: forward 2-D transforms of square N x N
- * int16 blocks (row-major, N*N samples each), type DCT-II with N in {4, 8, 16, 32} or
- * DST-VII with N in {4, 8, 16}.  Two passes with partialButterfly32's structure
+/* The mixed transform set of BASELINE configs[3]: forward 2-D transforms of square N x N
+ * int16 blocks (row-major, N*N samples each) built from two 1-D transform SLOTS: slot 0 with
+ * N in {4, 8, 16, 32}, by default the DCT-II (sub-matrices of g_t32; N = 32 is pinned by the reference),
+ * and slot 1 with N in {4, 8, 16}, by default the closed-form DST-VII
+ * round(64 sqrt(N) sqrt(4/(2N+1)) sin(pi (2k+1)(n+1)/(2N+1))) -- for N = 4 the table of H.266, for N = 8 / 16
+ * NOT claimed to be the standard's integers (those could not be checked offline; a host that holds the
+ * normative tables, or wants DCT-VIII, installs them with xTransformSetMatrix below).
+ * Two passes with partialButterfly32's structure
  * (src_tb/dct32.c:66-170): rows then columns, shifts log2N-1 and log2N+6, rounding
  * half up, truncating int16 stores; the DCT-II matrices are the sub-matrices of g_t32
  * that src/mkDct32.bsv:132-141 taps.  Only (DCT-II, 32) is pinned by upstream.
@@ -124,12 +129,21 @@ int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out,
  * d_offsets != NULL: block b lives at sample offset d_offsets[b] (a multiple of 8) in
  * both buffers -- the per-CTU mixed batches: one call per (type, size) class over a
  * shared residual / coefficient buffer pair. */
-#define X266_TR_DCT2 0            /* DCT-II horizontally and vertically */
-#define X266_TR_DST7 1            /* DST-VII horizontally and vertically */
-#define X266_TR_DST7_DCT2 2       /* DST-VII horizontally (along rows), DCT-II vertically: N = 4, 8, 16 */
-#define X266_TR_DCT2_DST7 3       /* DCT-II horizontally, DST-VII vertically */
+#define X266_TR_DCT2 0            /* slot 0 (DCT-II) horizontally and vertically */
+#define X266_TR_DST7 1            /* slot 1 (DST-VII) horizontally and vertically */
+#define X266_TR_DST7_DCT2 2       /* slot 1 horizontally (along rows), slot 0 vertically: N = 4, 8, 16 */
+#define X266_TR_DCT2_DST7 3       /* slot 0 horizontally, slot 1 vertically */
 int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d_in, int16_t *d_out,
                           size_t n_blocks, const uint32_t *d_offsets, void *stream);
+/* Caller-supplied 1-D transform matrices (the RTL re-uses one datapath for any tap set the same way,
+ * src/mkDct32.bsv:132-141, 385-387).  slot 0 / 1 = the "DCT-II" / "DST-VII" slot of the type codes above,
+ * size in {4, 8, 16}; m[k*size + n], row k = basis function, int8 (any values: the kernels only need the int8
+ * operand images rebuilt); m == NULL restores the built-in matrix.  Affects every entry point of the set --
+ * forward, inverse (which applies the transposes, columns first), the per-class and the one-launch calls --
+ * of THIS context from the next call on.  Synchronises the device (launches in flight read the old tables);
+ * not to be called concurrently with other calls on the context.  The 32-point DCT-II cannot be replaced. */
+int xTransformSetMatrix(x266hip_ctx *ctx, int slot, int size, const int8_t *m);
+int xTransformGetMatrix(const x266hip_ctx *ctx, int slot, int size, int8_t *m);
 /* Inverse transforms of the same set (no upstream counterpart): columns first, shifts 7 and 12
  * (8-bit video), int16 clipping after each pass; (DCT-II, 32) contiguous is xDct32InvBatchDev.
  * d_offsets as in the forward call. */

@@ -1,6 +1,8 @@
 /*
- * transform_oracle.c -- CPU statement of the VVC transform set of BASELINE
- * configs[3]: forward 2-D DCT-II N = 4, 8, 16, 32 and DST-VII N = 4, 8, 16.
+ * transform_oracle.c -- CPU statement of the mixed transform set of BASELINE
+ * configs[3]: forward 2-D DCT-II N = 4, 8, 16, 32 and closed-form DST-VII N = 4, 8, 16
+ * (N = 4 is the H.266 table; N = 8 / 16 are NOT claimed to be the standard's integers),
+ * plus the same passes with caller-supplied matrices.
  *
  * TEST INFRASTRUCTURE ONLY (see x266_oracle.h).
  * Parity: (DCT-II, 32) is PINNED -- it must equal orc_dct32_fwd, which is pinned to
@@ -81,17 +83,27 @@ static void tr_pass(const int16_t *m, int n, const int16_t *src, int16_t *dst, i
 static int htype_of(int type) { return (type == 1 || type == 2) ? ORC_TR_DST7 : ORC_TR_DCT2; }
 static int vtype_of(int type) { return (type == 1 || type == 3) ? ORC_TR_DST7 : ORC_TR_DCT2; }
 
-int orc_transform_fwd(int type, int n, const int16_t *in, int16_t *out, size_t n_blocks)
+/* The same two passes with CALLER-SUPPLIED matrices (mh along rows, mv vertically; row k = basis function): what
+ * xTransformSetMatrix installs in the product.  The pass structure is the pinned one (src_tb/dct32.c:66-170); the
+ * matrices are whatever the caller says they are. */
+int orc_transform_fwd_matrix(const int16_t *mh, const int16_t *mv, int n, const int16_t *in, int16_t *out, size_t n_blocks)
 {
-    int16_t m[32 * 32], mv[32 * 32], tmp[32 * 32];
-    if (type < 0 || type > 3 || orc_transform_matrix(htype_of(type), n, m) || orc_transform_matrix(vtype_of(type), n, mv)) return -1;
+    int16_t tmp[32 * 32];
+    if (!(n == 4 || n == 8 || n == 16 || n == 32)) return -1;
     int log2n = 0;
     while ((1 << log2n) < n) log2n++;
     for (size_t b = 0; b < n_blocks; b++) {
-        tr_pass(m, n, in + b * n * n, tmp, log2n - 1);
+        tr_pass(mh, n, in + b * n * n, tmp, log2n - 1);
         tr_pass(mv, n, tmp, out + b * n * n, log2n + 6);
     }
     return 0;
+}
+
+int orc_transform_fwd(int type, int n, const int16_t *in, int16_t *out, size_t n_blocks)
+{
+    int16_t m[32 * 32], mv[32 * 32];
+    if (type < 0 || type > 3 || orc_transform_matrix(htype_of(type), n, m) || orc_transform_matrix(vtype_of(type), n, mv)) return -1;
+    return orc_transform_fwd_matrix(m, mv, n, in, out, n_blocks);
 }
 
 /* Inverse of the above (UNPINNED): columns first, dst[j*n + c] = clip16((sum_k M[k][c]*src[k*n + j]
@@ -110,13 +122,20 @@ static void tr_inv_pass(const int16_t *m, int n, const int16_t *src, int16_t *ds
         }
 }
 
-int orc_transform_inv(int type, int n, const int16_t *in, int16_t *out, size_t n_blocks)
+int orc_transform_inv_matrix(const int16_t *mh, const int16_t *mv, int n, const int16_t *in, int16_t *out, size_t n_blocks)
 {
-    int16_t m[32 * 32], mv[32 * 32], tmp[32 * 32];
-    if (type < 0 || type > 3 || orc_transform_matrix(htype_of(type), n, m) || orc_transform_matrix(vtype_of(type), n, mv)) return -1;
+    int16_t tmp[32 * 32];
+    if (!(n == 4 || n == 8 || n == 16 || n == 32)) return -1;
     for (size_t b = 0; b < n_blocks; b++) {
         tr_inv_pass(mv, n, in + b * n * n, tmp, 7);                   /* columns first: the vertical inverse */
-        tr_inv_pass(m, n, tmp, out + b * n * n, 12);
+        tr_inv_pass(mh, n, tmp, out + b * n * n, 12);
     }
     return 0;
+}
+
+int orc_transform_inv(int type, int n, const int16_t *in, int16_t *out, size_t n_blocks)
+{
+    int16_t m[32 * 32], mv[32 * 32];
+    if (type < 0 || type > 3 || orc_transform_matrix(htype_of(type), n, m) || orc_transform_matrix(vtype_of(type), n, mv)) return -1;
+    return orc_transform_inv_matrix(m, mv, n, in, out, n_blocks);
 }

@@ -53,12 +53,15 @@ uint32_t orc_satd8x8(const int16_t diff[64]);
 void orc_satd8x8_batch(const int16_t *diff, uint32_t *out, size_t n_blocks);
 void orc_satd8x8_batch_mt(const int16_t *diff, uint32_t *out, size_t n_blocks, int threads);
 
-/* ---- VVC transform set (BASELINE configs[3]) -------- (DCT-II,32) PINNED, rest UNPINNED */
+/* ---- mixed transform set (BASELINE configs[3]): DCT-II + closed-form DST-VII -------- (DCT-II,32) PINNED, rest UNPINNED */
 #define ORC_TR_DCT2 0
 #define ORC_TR_DST7 1
 int orc_transform_matrix(int type, int n, int16_t *m /* n*n, row = frequency */);
 int orc_transform_fwd(int type, int n, const int16_t *in, int16_t *out, size_t n_blocks);
 int orc_transform_inv(int type, int n, const int16_t *in, int16_t *out, size_t n_blocks);   /* UNPINNED */
+/* the same passes with caller-supplied matrices (mh along rows, mv vertically; n*n int16, row k = basis function) */
+int orc_transform_fwd_matrix(const int16_t *mh, const int16_t *mv, int n, const int16_t *in, int16_t *out, size_t n_blocks);
+int orc_transform_inv_matrix(const int16_t *mh, const int16_t *mv, int n, const int16_t *in, int16_t *out, size_t n_blocks);
 
 /* ---- full-search harness around satd8x8 (BASELINE configs[2]) ---- cost PINNED, harness UNPINNED */
 /* ref points at pixel (0,0) of a frame padded by >= range; candidates in raster

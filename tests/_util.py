@@ -110,6 +110,17 @@ class Oracle:
         assert self.lib.orc_transform_inv(ttype, n, _P(x.ctypes.data), _P(out.ctypes.data), _SZ(x.shape[0])) == 0
         return out
 
+    def transform_matrix_passes(self, mh, mv, x, inverse=False):
+        """The set's two passes with caller-supplied n x n matrices (mh along rows, mv vertically; row k = basis function)."""
+        mh = np.ascontiguousarray(mh, np.int16)
+        mv = np.ascontiguousarray(mv, np.int16)
+        n = mh.shape[0]
+        x = np.ascontiguousarray(x, np.int16).reshape(-1, n * n)
+        out = np.empty_like(x)
+        fn = self.lib.orc_transform_inv_matrix if inverse else self.lib.orc_transform_fwd_matrix
+        assert fn(_P(mh.ctypes.data), _P(mv.ctypes.data), n, _P(x.ctypes.data), _P(out.ctypes.data), _SZ(x.shape[0])) == 0
+        return out
+
     def intra32_predict(self, refs, modes, ref_index=None):
         """refs [n_refs,129] uint8 (left[64] | top[65]); modes [n]; ref_index [n] or None -> [n,1024] uint8."""
         refs = np.ascontiguousarray(refs, np.uint8).reshape(-1, 129)

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): the VVC transform set of BASELINE configs[3] through
+"""GPU (-m gpu): the mixed transform set of BASELINE configs[3] (DCT-II + closed-form DST-VII) through
 xTransformFwdBatchDev, bit-exact against the oracle (DCT-II 4/8/16/32, DST-VII
 4/8/16; contiguous batches and per-CTU mixed batches placed by offset tables)."""
 import numpy as np

@@ -89,7 +89,7 @@ def test_prng_twins(oracle):
     assert splitmix64(0, 0, 1)[0] == np.uint64(0xE220A8397B1DCDAF)           # SplitMix64 reference value
 
 
-# ---- VVC transform set (BASELINE configs[3]) ---------------------------------------------
+# ---- mixed transform set (BASELINE configs[3]): DCT-II + closed-form DST-VII ---------------------------------------------
 def test_transform_set_matrices(oracle):
     g = oracle.table()
     for n in (4, 8, 16, 32):
@@ -110,6 +110,24 @@ def test_transform_set_matrices(oracle):
 def test_transform_set_generic_equals_pinned_dct32(oracle):
     x = np.concatenate([residual_np(40 * 1024, 31), fullrange_np(40 * 1024, 32)]).reshape(-1, 1024)
     assert np.array_equal(oracle.transform_fwd(0, 32, x), oracle.dct32_fwd(x))
+    # the caller-supplied-matrix passes (what xTransformSetMatrix installs) with g_t32 are the pinned transform too,
+    # forward and inverse, and with arbitrary int8 matrices they are the numpy statement
+    g = oracle.table()
+    assert np.array_equal(oracle.transform_matrix_passes(g, g, x), oracle.dct32_fwd(x))
+    z = oracle.dct32_fwd(x)
+    assert np.array_equal(oracle.transform_matrix_passes(g, g, z, inverse=True), oracle.dct32_inv(z))
+    rng = np.random.default_rng(5)
+    for n in (4, 8, 16):
+        mh, mv = rng.integers(-128, 128, (n, n)), rng.integers(-128, 128, (n, n))
+        s1, s2 = int(np.log2(n)) - 1, int(np.log2(n)) + 6
+        xb = fullrange_np(5 * n * n, 70 + n).reshape(5, n, n)
+        out = oracle.transform_matrix_passes(mh, mv, xb).reshape(5, n, n)
+        inv = oracle.transform_matrix_passes(mh, mv, xb, inverse=True).reshape(5, n, n)
+        for b in range(5):
+            y = ((np.einsum("kc,jc->kj", mh, xb[b].astype(np.int64)) + (1 << (s1 - 1))) >> s1).astype(np.int16)
+            assert np.array_equal(out[b], ((np.einsum("vj,kj->vk", mv, y.astype(np.int64)) + (1 << (s2 - 1))) >> s2).astype(np.int16))
+            t = np.clip((np.einsum("vy,vu->uy", mv, xb[b].astype(np.int64)) + 64) >> 7, -32768, 32767)        # columns first
+            assert np.array_equal(inv[b], np.clip((np.einsum("ux,uy->yx", mh, t) + 2048) >> 12, -32768, 32767).astype(np.int16))
 
 
 def test_transform_set_matches_numpy(oracle):

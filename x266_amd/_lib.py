@@ -75,6 +75,9 @@ def load_library():
     L.xSadBatchDev.argtypes = [_P, ctypes.c_int, _P, _P, _P, _SZ, _P]
     L.xTransformInvBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
     L.xTransformTilesDev.argtypes = [_P, ctypes.c_int, _P, _P, _SZ, _P, _P, _P]
+    L.xTransformSetMatrix.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P]
+    L.xTransformGetMatrix.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P]
+    L.xHipMeScratchReserve.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int]
     L.xSatd8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, _P, _P, _P]
     L.xSad8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
@@ -321,6 +324,20 @@ class Codec:
     def transform_tiles_dev(self, inverse, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, stream=0):
         self._check(self.L.xTransformTilesDev(self.ctx, int(inverse), d_in, d_out, n_tiles, d_tile_offsets or None, d_tile_class, stream),
                     "xTransformTilesDev")
+
+    def set_transform_matrix(self, slot, size, m=None):
+        """Install an N x N int8 matrix (row k = basis function) in 1-D transform slot 0 / 1; None restores the built-in."""
+        if m is None:
+            self._check(self.L.xTransformSetMatrix(self.ctx, slot, size, None), "xTransformSetMatrix")
+            return
+        m = np.ascontiguousarray(m, np.int8)
+        assert m.shape == (size, size)
+        self._check(self.L.xTransformSetMatrix(self.ctx, slot, size, m.ctypes.data), "xTransformSetMatrix")
+
+    def get_transform_matrix(self, slot, size):
+        m = np.empty((size, size), np.int8)
+        self._check(self.L.xTransformGetMatrix(self.ctx, slot, size, m.ctypes.data), "xTransformGetMatrix")
+        return m
 
     def transform_inv_dev(self, ttype, size, d_in, d_out, n_blocks, d_offsets=0, stream=0):
         self._check(self.L.xTransformInvBatchDev(self.ctx, ttype, size, d_in, d_out, n_blocks, d_offsets or None, stream), "xTransformInvBatchDev")

@@ -1,5 +1,5 @@
 // transform_kernels.hip -- forward DCT-II 4/8/16 and DST-VII 4/8/16 for gfx950
-// (BASELINE configs[3]: the mixed VVC transform set).
+// (BASELINE configs[3]: the mixed transform set: DCT-II + closed-form DST-VII, or caller-supplied matrices).
 //
 // Reference anchor: the N-point DCT-II matrices are sub-matrices of g_t32
 // (src_tb/dct32.c:30-64; the RTL re-uses the adder-tree taps for 4/8/16,

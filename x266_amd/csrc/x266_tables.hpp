@@ -149,7 +149,7 @@ inline void build_inv_ops(DctOps &o, bool natural_rows = false)
 }
 
 // ---------------------------------------------------------------------------
-// The VVC transform set beyond DCT-II 32 (BASELINE configs[3]; parity UNPINNED
+// The mixed transform set beyond DCT-II 32 (BASELINE configs[3]; parity UNPINNED
 // upstream -- DESIGN.md section 10).
 //  * DCT-II N = 4, 8, 16: rows 0, 32/N, 2*32/N, ... of g_t32 restricted to the
 //    first N columns (the taps mkDct32Core re-uses, src/mkDct32.bsv:132-141).

@@ -30,6 +30,10 @@ struct x266hip_ctx {
     DctOps *d_tr[kTypes][3] = {};                   // [type][log2N - 2], N = 4, 8, 16
     DctOps *d_tr_inv[kTypes][3] = {};
     TileOpsSoA *d_tile_fwd = nullptr, *d_tile_inv = nullptr;   // all sixteen classes, structure of arrays (xTransformTilesDev)
+    TileOpsSoA *h_tile_fwd = nullptr, *h_tile_inv = nullptr;   // their host copies (xTransformSetMatrix rewrites single classes)
+    // the two 1-D transform slots of the set, N = 4, 8, 16: slot 0 = DCT-II sub-matrices of g_t32, slot 1 = closed-form
+    // DST-VII unless the caller installed its own (xTransformSetMatrix); row k = basis function, N x N, row-major
+    int8_t slot_mat[2][3][256] = {};
     int tile_lds_per_wave = 4096;                   // mixed-class tile kernel: LDS charged per wave (resident-wave cap)
     int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (next tile's loads issued before this tile's arithmetic)
     // options
@@ -44,10 +48,10 @@ struct x266hip_ctx {
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
     int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (SATD search: 8, 4 or 2; SAD search: 2), else 1, 2, 4, 8 (8: SATD search only)
     int intra_rounds = 4;                           // intra prediction: rounds of seven predictions per wave (next round's reference sets prefetched)
-    // motion-search scratch (128 B per 8x8 block of the current frame), ONE PER STREAM: searches enqueued on
-    // different streams never share it.  The table is bounded (kMeScratchMax streams, least recently used evicted
-    // after waiting for its last search); a buffer that was handed out during a stream capture may be referenced by
-    // a recorded graph and is kept until the context is freed (outgrown ones are retired, not released).
+    // Internal device scratch, ONE BUFFER PER STREAM AND KIND, so that calls enqueued on different streams never share it:
+    // kind 0 = motion search (128 B per 8x8 block of the current frame).  Each table is bounded (kMeScratchMax streams, least recently used evicted after waiting for its
+    // last use); a buffer that was handed out during a stream capture may be referenced by a recorded graph and is kept
+    // until the context is freed (outgrown ones are retired, not released).
     struct MeScratch {
         hipStream_t stream;
         uint32_t *p;
@@ -58,7 +62,8 @@ struct x266hip_ctx {
         bool capturing_now;
     };
     static constexpr size_t kMeScratchMax = 8;
-    std::vector<MeScratch> me_scratch;
+    static constexpr int kScratchKinds = 1;
+    std::vector<MeScratch> scratch[kScratchKinds];
     std::vector<void *> me_retired;
     unsigned long long me_stamp = 0;
     int tr_lds_stage = 1;                           // transform set, contiguous batches: stage tiles through LDS
@@ -161,6 +166,94 @@ bool bad_ptrs(const void *a, const void *b, size_t n)
     return (((uintptr_t)a | (uintptr_t)b) & 15u) != 0;
 }
 
+// Scratch of kind `kind` for `stream`, at least `need` bytes.  Allocation happens here, i.e. on the first call of a stream or
+// size -- or ahead of time through xHipMeScratchReserve, which is what a host does before a stream
+// capture or a real-time loop (hipMalloc is illegal under capture and synchronises).
+int scratch_for(x266hip_ctx *ctx, int kind, hipStream_t stream, size_t need, x266hip_ctx::MeScratch **out)
+{
+    std::vector<x266hip_ctx::MeScratch> &table = ctx->scratch[kind];
+    x266hip_ctx::MeScratch *slot = nullptr;
+    for (x266hip_ctx::MeScratch &m : table)
+        if (m.stream == stream) slot = &m;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream) (void)hipStreamIsCapturing(stream, &cap);
+    (void)hipGetLastError();
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!slot) {
+        if (table.size() >= x266hip_ctx::kMeScratchMax && !capturing) {          // evict the least recently used stream's buffer
+            size_t victim = table.size();
+            for (size_t i = 0; i < table.size(); ++i)
+                if (!table[i].pinned && (victim == table.size() || table[i].stamp < table[victim].stamp)) victim = i;
+            if (victim < table.size()) {
+                x266hip_ctx::MeScratch &v = table[victim];
+                if (v.last_use) { (void)hipEventSynchronize(v.last_use); (void)hipEventDestroy(v.last_use); }
+                if (v.p) (void)hipFree(v.p);
+                table.erase(table.begin() + (long)victim);
+            }
+        }
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+        table.push_back({stream, nullptr, 0, ev, 0, false, false});
+        slot = &table.back();
+    }
+    if (need > slot->bytes) {
+        if (capturing) return fail(ctx, X266HIP_EINVAL, "internal scratch cannot be allocated under stream capture: reserve it (or run the call once) beforehand");
+        void *fresh = nullptr;
+        if (hipMalloc(&fresh, need) != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "internal scratch");
+        if (slot->p) {
+            if (slot->pinned) ctx->me_retired.push_back(slot->p);        // a recorded graph may still use it
+            else { if (slot->last_use) (void)hipEventSynchronize(slot->last_use); (void)hipFree(slot->p); }
+        }
+        slot->p = (uint32_t *)fresh;
+        slot->bytes = need;
+        slot->pinned = false;
+    }
+    if (capturing) slot->pinned = true;
+    slot->capturing_now = capturing;
+    slot->stamp = ++ctx->me_stamp;
+    *out = slot;
+    return X266HIP_OK;
+}
+
+// motion search: tile-major coefficient table of whole search tiles, partial edge tiles padded (tile heights 1, 2, 4, 8 all fit)
+int me_scratch_for(x266hip_ctx *ctx, hipStream_t stream, int width, int height, x266hip_ctx::MeScratch **out)
+{
+    return scratch_for(ctx, 0, stream, (size_t)((width / 8 + 7) / 8) * 8 * (size_t)((height / 8 + 7) / 8) * 8 * 128, out);
+}
+
+// built-in matrix of a 1-D transform slot: 0 = DCT-II (rows 0, 32/N, ... of g_t32, first N columns), 1 = closed-form DST-VII
+void default_slot_matrix(int slot, int n, int8_t *m)
+{
+    const Matrix32 d = make_transform_matrix(slot == 0 ? kTrDct2 : kTrDst7, n);
+    for (int k = 0; k < n; ++k)
+        for (int c = 0; c < n; ++c) m[k * n + c] = d.v[k][c];
+}
+
+Matrix32 block_diagonal(const int8_t *m, int n)
+{
+    Matrix32 r{};
+    for (int k = 0; k < 32; ++k)
+        for (int c = 0; c < 32; ++c) r.v[k][c] = k / n == c / n ? m[(k % n) * n + (c % n)] : (int8_t)0;
+    return r;
+}
+
+// operand images of class (type, N = 4 << l) from the context's slot matrices: the two per-class tables (allocated on first
+// use) and the class's entries of the host copies of the structure-of-arrays tables (the caller uploads those)
+bool upload_class(x266hip_ctx *ctx, int type, int l, DctOps *h)
+{
+    const int n = 4 << l;
+    const Matrix32 mh = block_diagonal(ctx->slot_mat[transform_htype(type) == kTrDst7][l], n);
+    const Matrix32 mv = block_diagonal(ctx->slot_mat[transform_vtype(type) == kTrDst7][l], n);
+    build_fwd_ops_general(*h, mh, mv, transform_shift1(n), transform_shift2(n));
+    tile_soa_set(*ctx->h_tile_fwd, type * 4 + l, *h);
+    if (!ctx->d_tr[type][l] && hipMalloc((void **)&ctx->d_tr[type][l], sizeof(DctOps)) != hipSuccess) return false;
+    if (hipMemcpy(ctx->d_tr[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) != hipSuccess) return false;
+    build_inv_ops_general(*h, mv, mh);
+    tile_soa_set(*ctx->h_tile_inv, type * 4 + l, *h);
+    if (!ctx->d_tr_inv[type][l] && hipMalloc((void **)&ctx->d_tr_inv[type][l], sizeof(DctOps)) != hipSuccess) return false;
+    return hipMemcpy(ctx->d_tr_inv[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
+}
+
 }  // namespace
 
 extern "C" {
@@ -217,27 +310,21 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
         ok = hipMalloc((void **)&ctx->d_inv_lds, sizeof(DctOps)) == hipSuccess &&
              hipMemcpy(ctx->d_inv_lds, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
     }
+    if (ok) {
+        ctx->h_tile_fwd = soa_f;
+        ctx->h_tile_inv = soa_i;
+        for (int slot = 0; slot < 2; ++slot)
+            for (int l = 0; l < 3; ++l) default_slot_matrix(slot, 4 << l, ctx->slot_mat[slot][l]);
+        ok = hipMalloc((void **)&ctx->d_tile_fwd, sizeof(TileOpsSoA)) == hipSuccess &&
+             hipMalloc((void **)&ctx->d_tile_inv, sizeof(TileOpsSoA)) == hipSuccess;
+    }
     for (int type = 0; type < x266hip_ctx::kTypes && ok; ++type)
-        for (int l = 0; l < 3 && ok; ++l) {
-            const int n = 4 << l;
-            const Matrix32 mh = make_transform_matrix(transform_htype(type), n), mv = make_transform_matrix(transform_vtype(type), n);
-            build_fwd_ops_general(*h, mh, mv, transform_shift1(n), transform_shift2(n));
-            tile_soa_set(*soa_f, type * 4 + l, *h);
-            ok = hipMalloc((void **)&ctx->d_tr[type][l], sizeof(DctOps)) == hipSuccess &&
-                 hipMemcpy(ctx->d_tr[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
-            if (!ok) break;
-            build_inv_ops_general(*h, mv, mh);
-            tile_soa_set(*soa_i, type * 4 + l, *h);
-            ok = hipMalloc((void **)&ctx->d_tr_inv[type][l], sizeof(DctOps)) == hipSuccess &&
-                 hipMemcpy(ctx->d_tr_inv[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
-        }
-    if (ok) ok = hipMalloc((void **)&ctx->d_tile_fwd, sizeof(TileOpsSoA)) == hipSuccess &&
-                 hipMalloc((void **)&ctx->d_tile_inv, sizeof(TileOpsSoA)) == hipSuccess &&
-                 hipMemcpy(ctx->d_tile_fwd, soa_f, sizeof(TileOpsSoA), hipMemcpyHostToDevice) == hipSuccess &&
+        for (int l = 0; l < 3 && ok; ++l) ok = upload_class(ctx, type, l, h);
+    if (ok) ok = hipMemcpy(ctx->d_tile_fwd, soa_f, sizeof(TileOpsSoA), hipMemcpyHostToDevice) == hipSuccess &&
                  hipMemcpy(ctx->d_tile_inv, soa_i, sizeof(TileOpsSoA), hipMemcpyHostToDevice) == hipSuccess;
     delete h;
-    delete soa_f;
-    delete soa_i;
+    if (!ctx->h_tile_fwd) { delete soa_f; delete soa_i; }
+
     if (!ok) {
         xHipCodecFree(ctx);
         return X266HIP_ENOMEM;
@@ -260,10 +347,13 @@ void xHipCodecFree(x266hip_ctx *ctx)
             if (ctx->d_tr[type][l]) (void)hipFree(ctx->d_tr[type][l]);
             if (ctx->d_tr_inv[type][l]) (void)hipFree(ctx->d_tr_inv[type][l]);
         }
-    for (const x266hip_ctx::MeScratch &m : ctx->me_scratch) { if (m.p) (void)hipFree(m.p); if (m.last_use) (void)hipEventDestroy(m.last_use); }
+    for (auto &table : ctx->scratch)
+        for (const x266hip_ctx::MeScratch &m : table) { if (m.p) (void)hipFree(m.p); if (m.last_use) (void)hipEventDestroy(m.last_use); }
     for (void *q : ctx->me_retired) (void)hipFree(q);
     if (ctx->d_tile_fwd) (void)hipFree(ctx->d_tile_fwd);
     if (ctx->d_tile_inv) (void)hipFree(ctx->d_tile_inv);
+    delete ctx->h_tile_fwd;
+    delete ctx->h_tile_inv;
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
     if (ctx->d_inv) (void)hipFree(ctx->d_inv);
     if (ctx->d_inv_lds) (void)hipFree(ctx->d_inv_lds);
@@ -457,6 +547,36 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
     return X266HIP_OK;
 }
 
+int xTransformSetMatrix(x266hip_ctx *ctx, int slot, int size, const int8_t *m)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (slot < 0 || slot > 1) return fail(ctx, X266HIP_EINVAL, "xTransformSetMatrix: slot must be 0 or 1");
+    if (size != 4 && size != 8 && size != 16)
+        return fail(ctx, X266HIP_EINVAL, "xTransformSetMatrix: size must be 4, 8 or 16 (the 32-point DCT-II is the reference's g_t32 and stays)");
+    X_DEV(ctx);
+    if (hipDeviceSynchronize() != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "xTransformSetMatrix: device synchronisation");   // launches in flight read the tables
+    const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
+    if (m) std::memcpy(ctx->slot_mat[slot][l], m, (size_t)size * size);
+    else default_slot_matrix(slot, size, ctx->slot_mat[slot][l]);
+    DctOps *h = new (std::nothrow) DctOps;
+    if (!h) return fail(ctx, X266HIP_ENOMEM, "xTransformSetMatrix");
+    bool ok = true;
+    for (int type = 0; type < x266hip_ctx::kTypes && ok; ++type)
+        if ((transform_htype(type) == kTrDst7) == (slot == 1) || (transform_vtype(type) == kTrDst7) == (slot == 1)) ok = upload_class(ctx, type, l, h);
+    delete h;
+    if (ok) ok = hipMemcpy(ctx->d_tile_fwd, ctx->h_tile_fwd, sizeof(TileOpsSoA), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(ctx->d_tile_inv, ctx->h_tile_inv, sizeof(TileOpsSoA), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) return fail(ctx, X266HIP_EDEVICE, "xTransformSetMatrix: table upload");
+    return X266HIP_OK;
+}
+
+int xTransformGetMatrix(const x266hip_ctx *ctx, int slot, int size, int8_t *m)
+{
+    if (!ctx || !m || slot < 0 || slot > 1 || (size != 4 && size != 8 && size != 16)) return X266HIP_EINVAL;
+    std::memcpy(m, ctx->slot_mat[slot][size == 4 ? 0 : (size == 8 ? 1 : 2)], (size_t)size * size);
+    return X266HIP_OK;
+}
+
 int xTransformTilesDev(x266hip_ctx *ctx, int inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles,
                        const uint32_t *d_tile_offsets, const uint8_t *d_tile_class, void *stream)
 {
@@ -580,56 +700,6 @@ int xTransformInvBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
     hipError_t e = size == 32 ? launch_transform_small_inv(5, d_in, d_out, n, ctx->d_inv_lds, d_offsets, cfg, (hipStream_t)stream)
                               : launch_transform_small_inv(l + 2, d_in, d_out, n, ctx->d_tr_inv[type][l], d_offsets, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "inverse transform launch", e);
-    return X266HIP_OK;
-}
-
-// Coefficient scratch of the motion search for `stream`, at least as large as a width x height frame needs (tile-major
-// table of whole search tiles, partial edge tiles padded; tile heights 1, 2, 4, 8 all fit).  Allocation happens here,
-// i.e. on the first search of a stream or frame size -- or ahead of time through xHipMeScratchReserve, which is what a
-// host does before a stream capture or a real-time loop (hipMalloc is illegal under capture and synchronises).
-static int me_scratch_for(x266hip_ctx *ctx, hipStream_t stream, int width, int height, x266hip_ctx::MeScratch **out)
-{
-    const size_t need = (size_t)((width / 8 + 7) / 8) * 8 * (size_t)((height / 8 + 7) / 8) * 8 * 128;
-    x266hip_ctx::MeScratch *slot = nullptr;
-    for (x266hip_ctx::MeScratch &m : ctx->me_scratch)
-        if (m.stream == stream) slot = &m;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (stream) (void)hipStreamIsCapturing(stream, &cap);
-    (void)hipGetLastError();
-    const bool capturing = cap != hipStreamCaptureStatusNone;
-    if (!slot) {
-        if (ctx->me_scratch.size() >= x266hip_ctx::kMeScratchMax && !capturing) {          // evict the least recently used stream's buffer
-            size_t victim = ctx->me_scratch.size();
-            for (size_t i = 0; i < ctx->me_scratch.size(); ++i)
-                if (!ctx->me_scratch[i].pinned && (victim == ctx->me_scratch.size() || ctx->me_scratch[i].stamp < ctx->me_scratch[victim].stamp)) victim = i;
-            if (victim < ctx->me_scratch.size()) {
-                x266hip_ctx::MeScratch &v = ctx->me_scratch[victim];
-                if (v.last_use) { (void)hipEventSynchronize(v.last_use); (void)hipEventDestroy(v.last_use); }
-                if (v.p) (void)hipFree(v.p);
-                ctx->me_scratch.erase(ctx->me_scratch.begin() + (long)victim);
-            }
-        }
-        hipEvent_t ev = nullptr;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
-        ctx->me_scratch.push_back({stream, nullptr, 0, ev, 0, false, false});
-        slot = &ctx->me_scratch.back();
-    }
-    if (need > slot->bytes) {
-        if (capturing) return fail(ctx, X266HIP_EINVAL, "motion search under stream capture needs xHipMeScratchReserve (or one search) beforehand");
-        void *fresh = nullptr;
-        if (hipMalloc(&fresh, need) != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "ME coefficient scratch");
-        if (slot->p) {
-            if (slot->pinned) ctx->me_retired.push_back(slot->p);        // a recorded graph may still use it
-            else { if (slot->last_use) (void)hipEventSynchronize(slot->last_use); (void)hipFree(slot->p); }
-        }
-        slot->p = (uint32_t *)fresh;
-        slot->bytes = need;
-        slot->pinned = false;
-    }
-    if (capturing) slot->pinned = true;
-    slot->capturing_now = capturing;
-    slot->stamp = ++ctx->me_stamp;
-    *out = slot;
     return X266HIP_OK;
 }
 
