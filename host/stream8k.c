@@ -8,7 +8,7 @@
  * It validates before it times: every frame of the pipelined, sharded run must equal, bit for bit, what
  * one device computes for the same frame with the plain batch calls.
  *
- *   usage: stream8k [n_ranks (0 = all visible devices)] [frames] [width] [height]      exit code 0 on success
+ *   usage: stream8k [n_ranks (0 = all visible devices)] [frames] [width] [height] [fused (1) | two launches (0)]      exit code 0 on success
  *          n_ranks > visible devices: ranks share devices round-robin (a test mode: RCCL refuses two ranks on one
  *          device, so the node uses its peer-copy transport -- the whole schedule still runs, with real transfers)
  *   prints one JSON line: frames/s, devices, transport, bit_exact
@@ -39,6 +39,7 @@ int main(int argc, char **argv)
     int n_dev = argc > 1 ? atoi(argv[1]) : 0;
     const int frames = argc > 2 ? atoi(argv[2]) : 200;
     const int width = argc > 3 ? atoi(argv[3]) : 7680, height = argc > 4 ? atoi(argv[4]) : 4320;
+    const int fused = argc > 5 ? atoi(argv[5]) : 1;
     x266hip_node *node = NULL;
     x266hip_ctx *hip = NULL;
     const int visible = xHipDeviceCount();
@@ -71,7 +72,34 @@ int main(int argc, char **argv)
     }
     CHECK(xHipStreamSync(hip, NULL));
 
+    /* what the frame's kernels cost by themselves on one device: HIP events around back-to-back launches of the lane kernels */
+    double kernel_us = 0.0;
+    {
+        void *e0 = NULL, *e1 = NULL;
+        double ms = 0.0;
+        const int reps = 200;
+        CHECK(xHipEventCreate(hip, &e0));
+        CHECK(xHipEventCreate(hip, &e1));
+        for (int pass = 0; pass < 2; pass++) {                      /* pass 0 warms the clocks */
+            CHECK(xHipEventRecord(hip, e0, NULL));
+            for (int i = 0; i < reps; i++) {
+                if (fused) CHECK(xDct32SatdFrameDev(hip, (const int16_t *)d_in[i % IN_RING][0], (int16_t *)d_out[i % OUT_RING][0], n_dct,
+                                                    (const int16_t *)d_in[i % IN_RING][1], (uint32_t *)d_out[i % OUT_RING][1], n_satd, NULL));
+                else {
+                    CHECK(xDct32FwdBatchDev(hip, (const int16_t *)d_in[i % IN_RING][0], (int16_t *)d_out[i % OUT_RING][0], n_dct, NULL));
+                    CHECK(xSatd8x8BatchDev(hip, (const int16_t *)d_in[i % IN_RING][1], (uint32_t *)d_out[i % OUT_RING][1], n_satd, NULL));
+                }
+            }
+            CHECK(xHipEventRecord(hip, e1, NULL));
+            CHECK(xHipEventElapsedMs(hip, e0, e1, &ms));
+        }
+        kernel_us = ms * 1e3 / reps;
+        xHipEventDestroy(hip, e0);
+        xHipEventDestroy(hip, e1);
+    }
+
     x266hip_nstream *st = NULL;
+    CHECK(xHipNodeSetOption(node, "fused_frame_lanes", fused));
     CHECK(xNodeFrameStreamCreate(node, width, height, &st));
     char *got = malloc(out_bytes[0] > out_bytes[1] ? out_bytes[0] : out_bytes[1]);
     char *want = malloc(out_bytes[0] > out_bytes[1] ? out_bytes[0] : out_bytes[1]);
@@ -108,7 +136,8 @@ int main(int argc, char **argv)
     for (int f = 0; f < frames; f++) {
         const void *in[2] = {d_in[f % IN_RING][0], d_in[f % IN_RING][1]};
         void *out[2] = {d_out[f % OUT_RING][0], d_out[f % OUT_RING][1]};
-        CHECK(xNodeStreamPush(st, in, out, NULL, NULL, NULL));
+        /* the inputs are resident: "produced" on the frame's own slot stream, so the push needs no producer event */
+        CHECK(xNodeStreamPush(st, in, out, NULL, xNodeStreamNextSlotStream(st), NULL));
     }
     CHECK(xNodeStreamFlush(st));
     const double dt = now_s() - t0;
@@ -119,10 +148,12 @@ int main(int argc, char **argv)
         if (memcmp(got, want, out_bytes[l])) { exact = 0; fprintf(stderr, "last timed frame, lane %d differs\n", l); }
     }
     printf("{\"workload\": \"%dx%d frame stream: %zu DCT32 + %zu SATD blocks per frame\", \"ranks\": %d, \"visible_devices\": %d, \"transport\": \"%s\", "
-           "\"frames\": %d, \"frames_per_s\": %.1f, \"ms_per_frame\": %.4f, \"dct32_blocks_per_s\": %.4e, \"satd8x8_blocks_per_s\": %.4e, "
+           "\"frames\": %d, \"frames_per_s\": %.1f, \"ms_per_frame\": %.4f, \"kernel_us_per_frame\": %.2f, \"launches_per_frame\": %d, "
+           "\"kernel_share_of_frame_time\": %.3f, \"dct32_blocks_per_s\": %.4e, \"satd8x8_blocks_per_s\": %.4e, "
            "\"bit_exact_vs_single_device\": %s}\n",
            width, height, n_dct, n_satd, n_dev, visible, n_dev == 1 ? "none (one rank)" : rccl ? "rccl send/recv groups" : "hipMemcpyPeerAsync",
-           frames, frames / dt, dt / frames * 1e3, n_dct * frames / dt, n_satd * frames / dt, exact ? "true" : "false");
+           frames, frames / dt, dt / frames * 1e3, kernel_us, fused ? 1 : 2, kernel_us * 1e-6 / (dt / frames),
+           n_dct * frames / dt, n_satd * frames / dt, exact ? "true" : "false");
     free(got); free(want);
     xNodeStreamFree(st);
     for (int r = 0; r < IN_RING; r++) for (int l = 0; l < 2; l++) { xHipFree(hip, d_in[r][l]); xHipFree(hip, d_ref[r][l]); }

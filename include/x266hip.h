@@ -104,6 +104,17 @@ int xDct32FwdBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out,
  * column pass shift 7, row pass shift 12, int16 clipping after each pass). */
 int xDct32InvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out,
                       size_t n_blocks, void *stream);
+/* The two lanes of a frame in ONE launch: xDct32FwdBatchDev of one batch and xSatd8x8BatchDev of another, bit-identical
+ * to the two calls (BASELINE configs[4]: a 7680x4320 frame is 32 400 DCT32 blocks + 518 400 SATD blocks, ~15 us of kernel
+ * each -- submissions, not arithmetic, pace a frame stream on one GPU).  Either count may be 0. */
+int xDct32SatdFrameDev(x266hip_ctx *ctx, const int16_t *d_dct_in, int16_t *d_dct_out, size_t n_dct_blocks,
+                       const int16_t *d_diff, uint32_t *d_satd_out, size_t n_satd_blocks, void *stream);
+/* The 1-D pass by itself: partialButterfly32(src, dst, shift, line = 32) (src_tb/dct32.c:66-170; the RTL's first stage,
+ * src/mkDct32.bsv:213-284) on every 32x32 block of the batch, i.e. dst[k*32 + j] = (int16)((sum_n g_t32[k][n] *
+ * src[j*32 + n] + (1 << (shift-1))) >> shift) -- note the TRANSPOSED store.  xDct32PassDev(shift 4) followed by
+ * xDct32PassDev(shift 11) is xDct32FwdBatchDev; on its own it lets a testbench compare the intermediate of a DUT.
+ * Exact for every int16 input at shifts 1..15.  (A checking entry point: one block per wave, not a tuned kernel.) */
+int xDct32PassDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out, size_t n_blocks, int shift, void *stream);
 /* Forward and inverse in one pass over the batch: d_coef = forward(d_in) (may be NULL when only
  * the reconstruction is wanted), d_recon = inverse(forward(d_in)) -- the transform half of an
  * encoder's reconstruction loop; SURVEY 8(d) "fused fwd+inv", 6144 bytes per block instead of
@@ -304,7 +315,15 @@ int xHipEventElapsedMs(x266hip_ctx *ctx, void *start, void *stop, double *ms);
 /* Transport is RCCL point-to-point: ONE ncclGroupStart/End of               */
 /* ncclSend/ncclRecv per step, so that all of the root's xGMI links and both  */
 /* directions of each are busy at once; librccl.so.1 is opened on first use   */
-/* (dlopen), so hosts that never create a node do not load it.  Two process    */
+/* (dlopen), so hosts that never create a node do not load it; a process that   */
+/* has already loaded an RCCL (e.g. torch's bundled one) shares that copy.  The  */
+/* environment variable X266HIP_RCCL_LIB, when set, names the library to open   */
+/* INSTEAD (another RCCL build; the repository's tests point it at their        */
+/* single-box model of RCCL's semantics) -- xHipNodeRcclInfo tells which        */
+/* library and version a process ended up with.  A failed communication step    */
+/* aborts the node's communicators (ncclCommAbort) so that no rank is left in a */
+/* group that cannot complete; the node is then good for xHipNodeFree only and   */
+/* every rank must treat the failure the same way.  Two process                  */
 /* models, same calls afterwards:                                             */
 /*   xHipNodeInit      one process drives n devices (ncclCommInitAll)         */
 /*   xHipNodeInitRank  one process per GPU (ncclCommInitRank); every rank     */
@@ -341,6 +360,9 @@ int  xHipNodeSetOption(x266hip_node *node, const char *key, int value);
 /* Communication self-check: every rank sends a pattern to the next rank and receives from the previous
  * one inside one RCCL group (with one rank: to itself), then all ranks all-reduce a checksum. */
 int  xHipNodeSelfTest(x266hip_node *node);
+/* The RCCL this process uses: NCCL_VERSION_CODE-style version (0 if the library has no ncclGetVersion) and the path of
+ * the shared object (dladdr).  X266HIP_ECOMM when no RCCL could be opened. */
+int  xHipNodeRcclInfo(int *version, char *path, size_t path_cap);
 
 /* A stream of frames, each a fixed set of "lanes" (one batch per lane).  op: 0 = DCT32 forward
  * (2048 B in / 2048 B out per unit), 1 = DCT32 inverse, 2 = 8x8 SATD (128 B in / 4 B out).
@@ -364,6 +386,10 @@ void xNodeStreamFree(x266hip_nstream *s);
  * receives t. */
 int  xNodeStreamPush(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units,
                      void *producer_stream, long *ticket);
+/* The root-device stream on which the NEXT pushed frame's kernels will run (NULL on processes that do not drive the
+ * root).  A producer that enqueues the frame's inputs on this stream and passes it as producer_stream needs no event:
+ * stream order already puts the frame's kernels behind it (one event record and one stream wait less per frame). */
+void *xNodeStreamNextSlotStream(x266hip_nstream *s);
 /* Issues the two draining steps and blocks until every pushed frame's results are in place. */
 int  xNodeStreamFlush(x266hip_nstream *s);
 /* Blocks the host until the results of step `ticket` are complete in their d_out buffers (root), or

@@ -383,6 +383,14 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommAbort(ncclComm_t comm) { return ncclCommDestroy(comm); }      // nothing is ever in flight here: every transfer is host-synchronous
+
+ncclResult_t ncclGetVersion(int *version)
+{
+    if (version) *version = 0;                                           // "the model", not a release of RCCL
+    return ncclSuccess;
+}
+
 ncclResult_t ncclGroupStart(void)
 {
     ++g_depth;

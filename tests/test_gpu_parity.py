@@ -48,6 +48,46 @@ def test_dct32_fwd_config0_single_block(codec, oracle):
     assert np.array_equal(out, oracle.dct32_fwd(x))
 
 
+def test_dct32_one_dimensional_pass(codec, oracle):
+    """xDct32PassDev = partialButterfly32(src, dst, shift, 32) (src_tb/dct32.c:66-170), transposed store: the golden
+    pass-1 intermediate of block 0 (generated from the real reference), the oracle's pass on random / full-range / extreme
+    blocks at the reference's two shifts and others, and pass(4) then pass(11) = the 2-D transform."""
+    g = _golden("dct32_fwd.npz")
+    assert np.array_equal(codec.dct32_pass(g["inputs"][:1], 4)[0], g["pass1_block0"])
+    x = _mixed(700, 1024, 55)
+    for shift in (4, 11, 1, 7, 15):
+        got = codec.dct32_pass(x, shift)
+        for b in (0, 1, 233, 466, 699):                                  # the oracle's pass is one block per call
+            assert np.array_equal(got[b], oracle.dct32_pass(x[b], shift)), (shift, b)
+    assert np.array_equal(codec.dct32_pass(codec.dct32_pass(x, 4), 11), oracle.dct32_fwd(x, threads=8))
+    for n in (1, 2, 3, 5, 63):                                           # ragged counts (four blocks per workgroup)
+        assert np.array_equal(codec.dct32_pass(x[:n], 4), codec.dct32_pass(x, 4)[:n])
+    buf = codec.alloc(4096)
+    assert codec.L.xDct32PassDev(codec.ctx, buf.ptr, buf.ptr + 2048, 1, 0, None) < 0     # shift out of range
+    assert codec.L.xDct32PassDev(codec.ctx, buf.ptr, buf.ptr + 2048, 1, 16, None) < 0
+
+
+@pytest.mark.parametrize("n_dct,n_satd", [(0, 1), (1, 0), (1, 1), (3, 33), (257, 4099), (4050, 64800), (32400, 518400)])
+def test_frame_lanes_in_one_launch(codec, oracle, n_dct, n_satd):
+    """xDct32SatdFrameDev: the DCT32 forward lane and the SATD lane of a frame as one grid (the launch the node layer's
+    frame stream issues per frame and rank) -- equal to the oracle, i.e. to the two separate calls; ragged counts, the
+    per-GPU shard of an 8K frame over eight GPUs (4050 + 64800) and the whole 8K frame."""
+    x = residual_np(max(n_dct, 1) * 1024, 0x300 + n_dct).reshape(-1, 1024)
+    d = fullrange_np(max(n_satd, 1) * 64, 0x400 + n_satd).reshape(-1, 64)
+    din, dout = codec.alloc(x.nbytes), codec.alloc(x.nbytes)
+    sin, sout = codec.alloc(d.nbytes), codec.alloc(max(n_satd, 4) * 4)
+    din.upload(x)
+    sin.upload(d)
+    P = ctypes.c_void_p
+    codec.L.xDct32SatdFrameDev.argtypes = [P, P, P, ctypes.c_size_t, P, P, ctypes.c_size_t, P]
+    assert codec.L.xDct32SatdFrameDev(codec.ctx, din.ptr, dout.ptr, n_dct, sin.ptr, sout.ptr, n_satd, None) == 0
+    codec.stream_sync()
+    if n_dct:
+        assert np.array_equal(dout.download(np.int16, n_dct * 1024).reshape(-1, 1024), oracle.dct32_fwd(x[:n_dct], threads=8))
+    if n_satd:
+        assert np.array_equal(sout.download(np.uint32, n_satd), oracle.satd8x8(d[:n_satd], threads=8))
+
+
 def test_dct32_fwd_random_vs_oracle(codec, oracle):
     x = _mixed(4000, 1024, 101)
     assert np.array_equal(codec.dct32_fwd(x), oracle.dct32_fwd(x, threads=8))

@@ -142,3 +142,19 @@ def test_two_rank_sharded_run_matches_single(oracle, tmp_path):
     z = oracle.dct32_fwd(oracle.fill_residual(n * 1024, 0x266))
     want = int(z.view(np.uint16).astype(np.uint64).sum())
     assert int(res[0]) == want and int(res[1]) == n and int(res[2]) == 2
+
+
+def test_python_fallback_of_the_plan_functions_equals_the_c_functions():
+    """x266_amd/shard.py falls back to a Python restatement of xShardRange / xMeStripePlan when libx266hip.so cannot be
+    loaded (a host without libamdhip64): same numbers as the C functions the node layer itself uses."""
+    from x266_amd import shard
+    from x266_amd.node import me_stripe_plan, shard_range
+    for n in (0, 1, 7, 8, 9, 1000, 32400, 518400, (1 << 20) + 3):
+        for world in (1, 2, 3, 5, 8):
+            for rank in range(world):
+                assert shard.shard_range_py(n, rank, world) == tuple(shard_range(n, rank, world))
+    for height in (8, 64, 544, 1080 - 1080 % 8, 2160):
+        for rng in (0, 1, 16, 64):
+            for n_stripes in (1, 2, 3, 8, 300):
+                for stripe in range(min(n_stripes, 9)):
+                    assert shard.me_stripe_py(height, rng, stripe, n_stripes) == me_stripe_plan(height, rng, stripe, n_stripes)

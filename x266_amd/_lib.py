@@ -75,6 +75,7 @@ def load_library():
     L.xSadBatchDev.argtypes = [_P, ctypes.c_int, _P, _P, _P, _SZ, _P]
     L.xTransformInvBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
     L.xTransformTilesDev.argtypes = [_P, ctypes.c_int, _P, _P, _SZ, _P, _P, _P]
+    L.xDct32PassDev.argtypes = [_P, _P, _P, _SZ, ctypes.c_int, _P]
     L.xTransformSetMatrix.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P]
     L.xTransformGetMatrix.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P]
     L.xHipMeScratchReserve.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int]
@@ -324,6 +325,15 @@ class Codec:
     def transform_tiles_dev(self, inverse, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, stream=0):
         self._check(self.L.xTransformTilesDev(self.ctx, int(inverse), d_in, d_out, n_tiles, d_tile_offsets or None, d_tile_class, stream),
                     "xTransformTilesDev")
+
+    def dct32_pass(self, x, shift):
+        """numpy convenience around xDct32PassDev: [n, 1024] int16 -> the 1-D pass of every block, stored transposed."""
+        x = np.ascontiguousarray(x, np.int16).reshape(-1, 1024)
+        din, dout = self.alloc(max(x.nbytes, 16)), self.alloc(max(x.nbytes, 16))
+        din.upload(x)
+        self._check(self.L.xDct32PassDev(self.ctx, din.ptr, dout.ptr, x.shape[0], int(shift), None), "xDct32PassDev")
+        self.stream_sync()
+        return dout.download(np.int16, x.size).reshape(-1, 1024)
 
     def set_transform_matrix(self, slot, size, m=None):
         """Install an N x N int8 matrix (row k = basis function) in 1-D transform slot 0 / 1; None restores the built-in."""

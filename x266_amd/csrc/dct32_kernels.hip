@@ -142,10 +142,7 @@ __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ 
 // Chunk (row r, quarter q) lives at r*64 + ((q ^ ((r >> 2) & 3)) << 4): every one of
 // the four DS accesses is bank-conflict-free.  Waves never share a slot, so there is
 // no barrier, only the in-order LDS queue of the wave itself.
-__device__ __forceinline__ unsigned lds_slot(unsigned row, unsigned quarter)
-{
-    return row * 64u + ((quarter ^ ((row >> 2) & 3u)) << 4);
-}
+// (lds_slot itself lives in x266_mfma_blocks.hpp: the fused frame kernel of satd_kernels.hip stages DCT32 tiles the same way)
 
 template <int MODE, int NT = 0>
 __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restrict__ in,
@@ -372,6 +369,39 @@ __global__ __launch_bounds__(256) void dct32_from_tiles_kernel(const x266_ref_bl
     store16m<NT ? 2 : 0>(dst + 1024, s1);
 }
 
+
+// ---- the 1-D pass on its own (partialButterfly32, src_tb/dct32.c:66-170; RTL stage src/mkDct32.bsv:213-284) --------
+// dst[k*32 + j] = (int16)((sum_n g[k][n] * src[j*32 + n] + (1 << (shift-1))) >> shift): one MFMA pass of the forward
+// kernel with the accumulators stored TRANSPOSED, as the reference does.  Lane (c, h) holds frequency kappa(c) for the 16
+// input rows j = acc_row(r, h): four runs of four consecutive j, i.e. four 8-byte stores per lane.  An entry point for
+// checking a Bluesim DUT's (or this library's) intermediate against the reference -- not a throughput kernel.
+__global__ __launch_bounds__(256) void dct32_pass_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t n_blocks,
+                                                         const DctOps *__restrict__ ops, int shift)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t b = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= n_blocks) return;
+    const LaneConsts k = load_consts(ops, lane);
+    const char *src = reinterpret_cast<const char *>(in) + b * 2048 + (size_t)(lane & 31) * 64 + (size_t)(lane >> 5) * 32;
+    const v4i w0 = load16<false>(src), w1 = load16<false>(src + 16);
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v4i lo, hi;
+    split_planes(w0, w1, lo, hi);
+    const int c = k.c1 - (1 << 3) + (1 << (shift - 1));               // the table holds the constant of shift 4
+    v16i acc = mfma(hi, k.p1, zero);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)c);
+    acc = mfma(lo, k.p1, acc);
+    const int freq = kappa(lane & 31), h = lane >> 5;
+    char *dst = reinterpret_cast<char *>(out) + b * 2048 + (size_t)freq * 64 + (size_t)h * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t d0 = bperm((uint32_t)(acc[4 * q + 1] >> shift), (uint32_t)(acc[4 * q] >> shift), 0x05040100u);
+        const uint32_t d1 = bperm((uint32_t)(acc[4 * q + 3] >> shift), (uint32_t)(acc[4 * q + 2] >> shift), 0x05040100u);
+        *reinterpret_cast<uint2 *>(dst + q * 16) = make_uint2(d0, d1);
+    }
+}
+
 }  // namespace
 
 // ---- launchers ---------------------------------------------------------------
@@ -405,6 +435,15 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
     if (cfg.nontemporal & 4) { if (mode == 0) X266_LAUNCH(0, true); else if (mode == 1) X266_LAUNCH(1, true); else X266_LAUNCH(2, true); }
     else                 { if (mode == 0) X266_LAUNCH(0, false); else if (mode == 1) X266_LAUNCH(1, false); else X266_LAUNCH(2, false); }
 #undef X266_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_dct32_pass(const int16_t *d_in, int16_t *d_out, size_t n_blocks, int shift, const DctOps *d_fwd_ops, hipStream_t stream)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const size_t wgs = (n_blocks + 3) / 4;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dct32_pass_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, d_in, d_out, n_blocks, d_fwd_ops, shift);
     return hipGetLastError();
 }
 

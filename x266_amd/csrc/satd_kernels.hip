@@ -135,15 +135,11 @@ __global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict_
 // (whole 128-byte lines per instruction, see dct32_kernels.hip) and turned into block-per-lane
 // order through a wave-private LDS slot.  Chunk (block n, row j) lives at
 // n*128 + ((j ^ ((n >> 1) & 7)) << 4): linear writes and fragment reads are conflict-free.
+// the body, per wave: `wave` = index of the wave in the launch, `slot` = its 4 KiB of LDS
 template <bool NT>
-__global__ __launch_bounds__(256) void satd8x8_lds_kernel(const int16_t *__restrict__ diff,
-                                                          uint32_t *__restrict__ out, size_t n_blocks,
-                                                          unsigned groups_per_wave)
+__device__ __forceinline__ void satd8x8_lds_wave(const int16_t *__restrict__ diff, uint32_t *__restrict__ out, size_t n_blocks,
+                                                 unsigned groups_per_wave, size_t wave, unsigned char *slot, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 4 KiB per wave (+ occupancy padding)
-    const int lane = threadIdx.x & 63;
-    unsigned char *slot = stage + (threadIdx.x >> 6) * 4096;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t n_groups = (n_blocks + 31) >> 5;
     size_t g = wave * groups_per_wave;
     const size_t end = g + groups_per_wave < n_groups ? g + groups_per_wave : n_groups;
@@ -177,6 +173,47 @@ __global__ __launch_bounds__(256) void satd8x8_lds_kernel(const int16_t *__restr
         const uint32_t cost = satd_group(H, w0, w1, w2, w3);
         const size_t b = g * 32 + blk;
         if (b < n_blocks && half == 0) out[b] = cost;
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void satd8x8_lds_kernel(const int16_t *__restrict__ diff,
+                                                          uint32_t *__restrict__ out, size_t n_blocks,
+                                                          unsigned groups_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 4 KiB per wave (+ occupancy padding)
+    satd8x8_lds_wave<NT>(diff, out, n_blocks, groups_per_wave, ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6,
+                         stage + (threadIdx.x >> 6) * 4096, (int)(threadIdx.x & 63));
+}
+
+// ---- the two lanes of a frame in ONE launch (BASELINE configs[4]: a 7680x4320 frame = 32 400 DCT32 blocks + 518 400
+// SATD blocks) ----------------------------------------------------------------------------------
+// Per frame the kernels are ~15 us each: two submissions plus their events cost more than they run.  One grid: the first
+// dct_wgs workgroups transform one DCT32 block per wave (the staged forward kernel's body, 8 KiB of LDS charged per
+// wave as there), the rest score SATD groups (the staged SATD kernel's body).  Both halves are one-wave-per-unit
+// already, so the fused grid is just the two grids back to back; the two lanes also fill each other's tails.
+__global__ __launch_bounds__(128) void frame_lanes_kernel(const int16_t *__restrict__ dct_in, int16_t *__restrict__ dct_out, size_t n_dct,
+                                                          const DctOps *__restrict__ ops, unsigned dct_wgs,
+                                                          const int16_t *__restrict__ diff, uint32_t *__restrict__ satd_out, size_t n_satd,
+                                                          unsigned groups_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 8 KiB per wave
+    const int lane = threadIdx.x & 63;
+    const unsigned wave_in_wg = threadIdx.x >> 6;
+    unsigned char *slot = stage + wave_in_wg * 8192;
+    if (blockIdx.x < dct_wgs) {                                             // wave-uniform, in fact workgroup-uniform
+        const size_t b = (size_t)blockIdx.x * 2 + wave_in_wg;
+        if (b >= n_dct) return;
+        const char *src = reinterpret_cast<const char *>(dct_in) + b * 2048 + lane * 16;
+        const v4i g0 = load16<true>(src), g1 = load16<true>(src + 1024);
+        const LaneConsts k = load_consts(ops, lane);
+        v4i s0, s1;
+        fwd_tile_staged<4, 11>(slot, lane, k, g0, g1, s0, s1);
+        char *dst = reinterpret_cast<char *>(dct_out) + b * 2048 + lane * 16;
+        store16m<2>(dst, s0);
+        store16m<2>(dst + 1024, s1);
+    } else {
+        satd8x8_lds_wave<true>(diff, satd_out, n_satd, groups_per_wave, (size_t)(blockIdx.x - dct_wgs) * 2 + wave_in_wg, slot, lane);
     }
 }
 
@@ -321,6 +358,20 @@ hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_block
     }
     if (cfg.nontemporal & 4) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
     else                 hipLaunchKernelGGL((satd8x8_kernel<false>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_lanes(const int16_t *d_dct_in, int16_t *d_dct_out, size_t n_dct, const DctOps *d_fwd_ops,
+                              const int16_t *d_diff, uint32_t *d_satd_out, size_t n_satd, const LaunchCfg &satd_cfg, hipStream_t stream)
+{
+    if (n_dct == 0 && n_satd == 0) return hipSuccess;
+    const size_t dct_wgs = (n_dct + 1) / 2;
+    const size_t groups = (n_satd + 31) / 32;
+    const unsigned gpw = groups ? units_per_wave_for(satd_cfg, groups) : 1u;
+    const size_t satd_wgs = ((groups + gpw - 1) / gpw + 1) / 2;
+    if (dct_wgs + satd_wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(frame_lanes_kernel, dim3((unsigned)(dct_wgs + satd_wgs)), dim3(128), (size_t)(2 * 8192), stream,
+                       d_dct_in, d_dct_out, n_dct, d_fwd_ops, (unsigned)dct_wgs, d_diff, d_satd_out, n_satd, gpw);
     return hipGetLastError();
 }
 

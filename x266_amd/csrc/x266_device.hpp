@@ -87,6 +87,7 @@ hipError_t launch_satd8x8_butterfly(const int16_t *d_diff, uint32_t *d_out, size
 hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles, const uint32_t *d_tile_offsets,
                                   const uint8_t *d_tile_class, const TileOpsSoA *d_class_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_dct32_butterfly(const int16_t *d_in, int16_t *d_out, size_t n_blocks, hipStream_t stream);
+hipError_t launch_dct32_pass(const int16_t *d_in, int16_t *d_out, size_t n_blocks, int shift, const DctOps *d_fwd_ops, hipStream_t stream);
 hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,
                                const DctOps *d_fwd_ops, const DctOps *d_inv_lds_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_blocks,
@@ -99,6 +100,8 @@ hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d
                                       const uint32_t *d_offsets, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_satd8x8_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, uint32_t *d_out,
                                      int width, int height, const LaunchCfg &cfg, hipStream_t stream);
+hipError_t launch_frame_lanes(const int16_t *d_dct_in, int16_t *d_dct_out, size_t n_dct, const DctOps *d_fwd_ops,
+                              const int16_t *d_diff, uint32_t *d_satd_out, size_t n_satd, const LaunchCfg &satd_cfg, hipStream_t stream);
 hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks,
                           const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,

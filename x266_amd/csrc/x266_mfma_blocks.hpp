@@ -122,6 +122,38 @@ __device__ __forceinline__ void fwd_block(const v4i &w0, const v4i &w1, const La
     fwd_finish<S1, S2>(acc, k, o0, o1);
 }
 
+// ---- one 32x32 tile through a wave-private 2 KiB LDS slot (dct32_kernels.hip, "LDS-staged variant") ----------
+// Chunk (row r, quarter q) lives at r*64 + ((q ^ ((r >> 2) & 3)) << 4): linear writes, row-per-lane fragment reads and
+// the way back are all bank-conflict-free.
+__device__ __forceinline__ unsigned lds_slot(unsigned row, unsigned quarter)
+{
+    return row * 64u + ((quarter ^ ((row >> 2) & 3u)) << 4);
+}
+
+// g0 / g1: the lane's two 16-byte pieces of the tile in LINEAR order (bytes lane*16 and 1024 + lane*16);
+// returns the transformed tile's pieces in the same linear order.
+template <int S1, int S2>
+__device__ __forceinline__ void fwd_tile_staged(unsigned char *slot, int lane, const LaneConsts &k, const v4i &g0, const v4i &g1, v4i &s0, v4i &s1)
+{
+    const unsigned c = lane & 31, h = lane >> 5;
+    const unsigned lin0 = lds_slot(lane >> 2, lane & 3), lin1 = lds_slot(16 + (lane >> 2), lane & 3);
+    const unsigned frag0 = lds_slot(c, 2 * h), frag1 = lds_slot(c, 2 * h + 1);
+    *reinterpret_cast<v4i *>(slot + lin0) = g0;
+    *reinterpret_cast<v4i *>(slot + lin1) = g1;
+    __builtin_amdgcn_wave_barrier();
+    const v4i a0 = *reinterpret_cast<const v4i *>(slot + frag0);
+    const v4i a1 = *reinterpret_cast<const v4i *>(slot + frag1);
+    v4i o0, o1;
+    fwd_block<S1, S2>(a0, a1, k, o0, o1);
+    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<v4i *>(slot + frag0) = o0;
+    *reinterpret_cast<v4i *>(slot + frag1) = o1;
+    __builtin_amdgcn_wave_barrier();
+    s0 = *reinterpret_cast<const v4i *>(slot + lin0);
+    s1 = *reinterpret_cast<const v4i *>(slot + lin1);
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---- inverse passes (see dct32_kernels.hip, section "inverse") --------------------------------
 
 // {clip16(lo), clip16(hi)} packed into one dword: v_cvt_pk_i16_i32 (full rate, profiles/r01_alubench.txt)

@@ -457,6 +457,29 @@ int xDct32InvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out, siz
     return launch_op(ctx, 1, d_in, d_out, n, (hipStream_t)stream);
 }
 
+int xDct32SatdFrameDev(x266hip_ctx *ctx, const int16_t *d_dct_in, int16_t *d_dct_out, size_t n_dct_blocks,
+                       const int16_t *d_diff, uint32_t *d_satd_out, size_t n_satd_blocks, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (bad_ptrs(d_dct_in, d_dct_out, n_dct_blocks) || bad_ptrs(d_diff, d_satd_out, n_satd_blocks))
+        return fail(ctx, X266HIP_EINVAL, "xDct32SatdFrameDev: NULL or unaligned buffer");
+    X_DEV(ctx);
+    const hipError_t e = launch_frame_lanes(d_dct_in, d_dct_out, n_dct_blocks, ctx->d_fwd, d_diff, d_satd_out, n_satd_blocks, cfg_for(ctx, 2), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "frame lanes launch", e);
+    return X266HIP_OK;
+}
+
+int xDct32PassDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_out, size_t n, int shift, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xDct32PassDev: NULL or unaligned buffer");
+    if (shift < 1 || shift > 15) return fail(ctx, X266HIP_EINVAL, "xDct32PassDev: shift must be 1..15");
+    X_DEV(ctx);
+    const hipError_t e = launch_dct32_pass(d_in, d_out, n, shift, ctx->d_fwd, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "1-D pass launch", e);
+    return X266HIP_OK;
+}
+
 int xDct32FwdInvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n, void *stream)
 {
     if (!ctx) return X266HIP_EINVAL;

@@ -42,12 +42,15 @@ struct Rccl {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;       // optional
+    decltype(&ncclGetVersion) GetVersion = nullptr;     // optional
     std::string why;
 };
 
 void load_rccl(Rccl &r)
 {
-    // X266HIP_RCCL_LIB names the library to use instead (another RCCL build; the tests' RCCL model)
+    // X266HIP_RCCL_LIB (documented in include/x266hip.h) names the library to use instead: another RCCL build, or the
+    // tests' single-box RCCL model.  Which library was loaded is reported by xHipNodeRcclInfo.
     const char *names[] = {std::getenv("X266HIP_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char *n : names) {
         if (!n || !*n) continue;
@@ -72,6 +75,10 @@ void load_rccl(Rccl &r)
     X_SYM(AllReduce, "ncclAllReduce");
     X_SYM(GetErrorString, "ncclGetErrorString");
 #undef X_SYM
+    if (ok) {
+        r.CommAbort = (decltype(r.CommAbort))dlsym(r.handle, "ncclCommAbort");
+        r.GetVersion = (decltype(r.GetVersion))dlsym(r.handle, "ncclGetVersion");
+    }
     if (!ok) {
         r.why = "librccl.so.1 lacks an expected symbol";
         dlclose(r.handle);
@@ -127,6 +134,10 @@ struct x266hip_node {
     bool have_rccl = false;
     int transport = 0;                     // 0 RCCL groups, 1 peer copies (single process only)
     int me_local_copy = 0;
+    int fused_frame_lanes = 1;             // frame streams (DCT32 forward + SATD lanes): one launch per frame and rank
+    bool failed = false;                   // a communication step failed: the communicators were aborted, the node only remains to be freed
+    struct x266hip_nstream *sg_stream[3] = {};   // xNodeBatchScatterGather's internal stream per op (grow-only, freed with the node)
+    size_t sg_cap[3] = {};
     std::vector<LocalRank> local;
     std::string err;
 };
@@ -208,6 +219,19 @@ int open_rank(x266hip_node *node, LocalRank &lr)
     N_HIP(node, hipStreamCreateWithFlags(&lr.compute_stream, hipStreamNonBlocking));
     N_HIP(node, hipStreamCreateWithFlags(&lr.compute_stream_odd, hipStreamNonBlocking));
     return X266HIP_OK;
+}
+
+// A step failed on a multi-rank node: peers may sit in an RCCL group that will never complete.  Abort the communicators
+// (ncclCommAbort, when the library has it) so that neither they nor this process's stream synchronisations hang; the
+// node is then good for xHipNodeFree only.  Every rank must treat a failed step the same way.
+void abort_comms(x266hip_node *node)
+{
+    if (!node || node->failed || node->world < 2) return;
+    node->failed = true;
+    Rccl *R = rccl();
+    if (!R || !R->CommAbort) return;
+    for (LocalRank &lr : node->local)
+        if (lr.comm) { (void)R->CommAbort(lr.comm); lr.comm = nullptr; }
 }
 
 LocalRank *root_rank(x266hip_node *node)
@@ -312,6 +336,8 @@ int xMeStripePlan(int height, int range, int stripe, int n_stripes, int *block_r
 void xHipNodeFree(x266hip_node *node)
 {
     if (!node) return;
+    for (x266hip_nstream *&sg : node->sg_stream)
+        if (sg) { xNodeStreamFree(sg); sg = nullptr; }
     Rccl *R = rccl();
     for (LocalRank &lr : node->local) {
         DeviceScope dev(lr.device);
@@ -447,12 +473,34 @@ int xHipNodeSetOption(x266hip_node *node, const char *key, int value)
         node->transport = value;
         return X266HIP_OK;
     }
+    if (!std::strcmp(key, "fused_frame_lanes")) {
+        if (value != 0 && value != 1) return nfail(node, X266HIP_EINVAL, "fused_frame_lanes must be 0 or 1");
+        node->fused_frame_lanes = value;
+        return X266HIP_OK;
+    }
     if (!std::strcmp(key, "me_local_copy")) {
         if (value != 0 && value != 1) return nfail(node, X266HIP_EINVAL, "me_local_copy must be 0 or 1");
         node->me_local_copy = value;
         return X266HIP_OK;
     }
     return nfail(node, X266HIP_EINVAL, "unknown node option");
+}
+
+int xHipNodeRcclInfo(int *version, char *path, size_t path_cap)
+{
+    Rccl *R = rccl();
+    if (!R) return X266HIP_ECOMM;
+    if (version) {
+        int v = 0;
+        if (R->GetVersion) (void)R->GetVersion(&v);
+        *version = v;
+    }
+    if (path && path_cap) {
+        Dl_info info;
+        const char *p = dladdr((void *)R->GroupStart, &info) && info.dli_fname ? info.dli_fname : "";
+        std::snprintf(path, path_cap, "%s", p);
+    }
+    return X266HIP_OK;
 }
 
 int xHipNodeSelfTest(x266hip_node *node)
@@ -590,9 +638,10 @@ int xNodeFrameStreamCreate(x266hip_node *node, int width, int height, x266hip_ns
 namespace {
 
 // Step t: transfers {inputs of frame t, results of frame t-2}, then kernels of frame t.
-int stream_step(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units, void *producer_stream, bool has_frame)
+int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units, void *producer_stream, bool has_frame)
 {
     x266hip_node *node = s->node;
+    if (node->failed) return nfail(node, X266HIP_ECOMM, "an earlier step of this node failed and its communicators were aborted");
     const int W = node->world, root = node->root;
     const long t = s->n_steps;
     const int slot = (int)(t % x266hip_nstream::kSlots);
@@ -625,10 +674,18 @@ int stream_step(x266hip_nstream *s, const void *const *d_in, void *const *d_out,
             N_HIP(node, hipEventSynchronize(p.ev_done[slot]));
             if (W > 1) N_HIP(node, hipStreamWaitEvent(lr.comm_stream, p.ev_done[slot], 0));
         }
+        // ... and its transfers (step t-2's group on the communication stream) must have completed: with one process per
+        // GPU nothing else keeps the root from running many groups ahead of lagging peers, and both the buffer-ownership
+        // rule of xNodeStreamPush (inputs reusable after two later steps) and xNodeStreamWait's "long done" rest on this bound
+        if (p.xfer_recorded[slot]) N_HIP(node, hipEventSynchronize(p.ev_xfer[slot]));
         if (lr.rank == root && has_frame) {                           // inputs come from the caller's stream
-            N_HIP(node, hipEventRecord(p.ev_producer, (hipStream_t)producer_stream));
-            if (W > 1) N_HIP(node, hipStreamWaitEvent(lr.comm_stream, p.ev_producer, 0));
-            N_HIP(node, hipStreamWaitEvent(slot ? lr.compute_stream_odd : lr.compute_stream, p.ev_producer, 0));
+            hipStream_t cs = slot ? lr.compute_stream_odd : lr.compute_stream;
+            const bool in_order = W == 1 && producer_stream && (hipStream_t)producer_stream == cs;   // produced on the slot's own stream: stream order suffices
+            if (!in_order) {
+                N_HIP(node, hipEventRecord(p.ev_producer, (hipStream_t)producer_stream));
+                if (W > 1) N_HIP(node, hipStreamWaitEvent(lr.comm_stream, p.ev_producer, 0));
+                N_HIP(node, hipStreamWaitEvent(cs, p.ev_producer, 0));
+            }
         }
     }
     if (node->transport == 1 && has_frame && drives_root) {           // peer copies run on the PEERS' streams and read the root's frame
@@ -683,19 +740,38 @@ int stream_step(x266hip_nstream *s, const void *const *d_in, void *const *d_out,
         if (!has_frame) continue;
         hipStream_t cs = slot ? lr.compute_stream_odd : lr.compute_stream;   // the slot's own stream: frame t-2 (same buffers) is ahead of frame t on it
         if (lr.rank != root) N_HIP(node, hipStreamWaitEvent(cs, p.ev_xfer[slot], 0));   // the root works in place: nothing to wait for
+        const void *lane_in[4] = {};
+        void *lane_out[4] = {};
+        size_t lane_n[4] = {};
         for (int l = 0; l < s->n_lanes; ++l) {
             size_t b, e;
             shard(cur.units[l], lr.rank, W, &b, &e);
-            const void *in = lr.rank == root ? (const void *)(cur.d_in[l] + b * kInUnit[s->op[l]]) : p.in[slot][l];
-            void *out = lr.rank == root ? (void *)(cur.d_out[l] + b * kOutUnit[s->op[l]]) : p.out[slot][l];
-            rc = launch(node, lr, s->op[l], in, out, e - b, cs);
-            if (rc) return rc;
+            lane_in[l] = lr.rank == root ? (const void *)(cur.d_in[l] + b * kInUnit[s->op[l]]) : p.in[slot][l];
+            lane_out[l] = lr.rank == root ? (void *)(cur.d_out[l] + b * kOutUnit[s->op[l]]) : p.out[slot][l];
+            lane_n[l] = e - b;
+        }
+        if (s->n_lanes == 2 && s->op[0] == 0 && s->op[1] == 2 && node->fused_frame_lanes) {
+            // the frame stream's two lanes (DCT32 forward + SATD): one grid instead of two submissions
+            N_X(node, lr, xDct32SatdFrameDev(lr.ctx, (const int16_t *)lane_in[0], (int16_t *)lane_out[0], lane_n[0],
+                                             (const int16_t *)lane_in[1], (uint32_t *)lane_out[1], lane_n[1], cs));
+        } else {
+            for (int l = 0; l < s->n_lanes; ++l) {
+                rc = launch(node, lr, s->op[l], lane_in[l], lane_out[l], lane_n[l], cs);
+                if (rc) return rc;
+            }
         }
         N_HIP(node, hipEventRecord(p.ev_done[slot], cs));
         p.done_recorded[slot] = true;
     }
     s->n_steps = t + 1;
     return X266HIP_OK;
+}
+
+int stream_step(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units, void *producer_stream, bool has_frame)
+{
+    const int rc = stream_step_impl(s, d_in, d_out, units, producer_stream, has_frame);
+    if (rc != X266HIP_OK && rc != X266HIP_EINVAL) abort_comms(s->node);     // argument errors are detected before anything is posted
+    return rc;
 }
 
 }  // namespace
@@ -708,6 +784,14 @@ int xNodeStreamPush(x266hip_nstream *s, const void *const *d_in, void *const *d_
     if (!s) return X266HIP_EINVAL;
     if (ticket) *ticket = s->n_steps;
     return stream_step(s, d_in, d_out, units, producer_stream, true);
+}
+
+void *xNodeStreamNextSlotStream(x266hip_nstream *s)
+{
+    if (!s) return nullptr;
+    LocalRank *r = root_rank(s->node);
+    if (!r) return nullptr;
+    return (s->n_steps % x266hip_nstream::kSlots) ? (void *)r->compute_stream_odd : (void *)r->compute_stream;
 }
 
 int xNodeStreamFlush(x266hip_nstream *s)
@@ -751,9 +835,16 @@ int xNodeBatchScatterGather(x266hip_node *node, int op, const void *d_in, void *
         if (node->world > 1 && chunk_units > n_units / 4) chunk_units = n_units / 4 > floor_units ? n_units / 4 : floor_units;
     }
     if (chunk_units > n_units) chunk_units = n_units;
-    x266hip_nstream *s = nullptr;
-    int rc = xNodeStreamCreate(node, 1, &op, &chunk_units, &s);
-    if (rc) return rc;
+    // one internal stream per op, kept on the node (grow-only): creating one per call means slot allocations, events and
+    // -- on release -- hipFree's device synchronisation inside what callers time
+    int rc = X266HIP_OK;
+    if (!node->sg_stream[op] || node->sg_cap[op] < chunk_units) {
+        if (node->sg_stream[op]) { xNodeStreamFree(node->sg_stream[op]); node->sg_stream[op] = nullptr; }
+        rc = xNodeStreamCreate(node, 1, &op, &chunk_units, &node->sg_stream[op]);
+        if (rc) return rc;
+        node->sg_cap[op] = chunk_units;
+    }
+    x266hip_nstream *s = node->sg_stream[op];
     const bool drives_root = root_rank(node) != nullptr;
     for (size_t done = 0; done < n_units && rc == X266HIP_OK; done += chunk_units) {
         const size_t cnt = n_units - done < chunk_units ? n_units - done : chunk_units;
@@ -762,7 +853,6 @@ int xNodeBatchScatterGather(x266hip_node *node, int op, const void *d_in, void *
         rc = xNodeStreamPush(s, &in, &out, &cnt, nullptr, nullptr);
     }
     if (rc == X266HIP_OK) rc = xNodeStreamFlush(s);
-    xNodeStreamFree(s);
     return rc;
 }
 

@@ -40,6 +40,9 @@ def _lib():
     L.xHipNodeLastError.restype = ctypes.c_char_p
     L.xHipNodeSetOption.argtypes = [_P, ctypes.c_char_p, ctypes.c_int]
     L.xHipNodeSelfTest.argtypes = [_P]
+    L.xHipNodeRcclInfo.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, _SZ]
+    L.xNodeStreamNextSlotStream.argtypes = [_P]
+    L.xNodeStreamNextSlotStream.restype = _P
     L.xNodeStreamCreate.argtypes = [_P, ctypes.c_int, _P, _P, ctypes.POINTER(_P)]
     L.xNodeFrameStreamCreate.argtypes = [_P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_P)]
     L.xNodeStreamFree.argtypes = [_P]
@@ -135,6 +138,15 @@ class Node:
     def self_test(self):
         self._check(self.L.xHipNodeSelfTest(self.h), "xHipNodeSelfTest")
 
+    @staticmethod
+    def rccl_info():
+        """(version, path) of the RCCL this process loaded for the node layer; (0, "") when none could be opened."""
+        v = ctypes.c_int()
+        buf = ctypes.create_string_buffer(1024)
+        if _lib().xHipNodeRcclInfo(ctypes.byref(v), buf, 1024) != 0:
+            return 0, ""
+        return v.value, buf.value.decode()
+
     def frame_stream(self, width, height):
         s = _P()
         self._check(self.L.xNodeFrameStreamCreate(self.h, width, height, ctypes.byref(s)), "xNodeFrameStreamCreate")
@@ -171,6 +183,10 @@ class NodeStream:
         self.node._check(self.node.L.xNodeStreamPush(self.s, a_in, a_out, a_units, producer_stream or None, ctypes.byref(t)),
                          "xNodeStreamPush")
         return t.value
+
+    def next_slot_stream(self):
+        """The root-device stream the next pushed frame's kernels run on (0 where this process does not drive the root)."""
+        return self.node.L.xNodeStreamNextSlotStream(self.s) or 0
 
     def flush(self):
         self.node._check(self.node.L.xNodeStreamFlush(self.s), "xNodeStreamFlush")
