@@ -1,0 +1,88 @@
+"""The host side under AddressSanitizer + UndefinedBehaviorSanitizer ("race detection / sanitizers").
+
+libx266hip_asan.so (make -C x266_amd/csrc asan) is the library's own sources with the HOST code instrumented; tests/asan
+holds small C drivers and the plain-C hosts of host/ linked against it.  CPU part: the host-only entry points (plan
+functions, tables, packing, the no-device error paths) and the oracle's C restatements on full-range / extreme data (where
+int16 wrap-around code would hide undefined behaviour).  GPU part: the node layer's stream schedule -- streams, events,
+slot rings, scatter-gather, the RCCL groups -- with 1, 2, 3 and 8 ranks on the one device (peer-copy transport and the
+RCCL code path under tests/rccl_model), the BDPI protocol host and the batch host.  Any report aborts the program."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from _util import ROOT
+
+ASAN_DIR = os.path.join(ROOT, "tests", "asan")
+# With a GPU in the process: the HIP runtime maps its own low ranges (protect_shadow_gap) and keeps allocations for the process
+# lifetime (leaks: its, not ours); and ROCm 7.2's ASan runtime fails an internal CHECK (sanitizer_allocator_device.h:125,
+# "dev_runtime_unloaded_") when a HIP worker thread flushes its free-quarantine after the device runtime has gone at exit --
+# after main() returned, in the sanitizer itself -- so the quarantine is off there (heap overflows, double frees and UB are
+# still caught; use-after-free only until the chunk is reused).  The CPU-only drivers run with the full quarantine.
+GPU_ASAN = "protect_shadow_gap=0:detect_leaks=0:abort_on_error=1:quarantine_size_mb=0"
+
+
+def _built(name):
+    exe = os.path.join(ASAN_DIR, name)
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", ASAN_DIR, "--no-print-directory"])
+    assert os.path.exists(exe), "tests/asan/%s is not built (make -C tests/asan)" % name
+    return exe
+
+
+def test_host_only_entry_points_under_asan_ubsan():
+    # leak checking where it can be ours: with a GPU present xHipDeviceCount starts the HIP runtime, whose allocations live as long as the process
+    opts = GPU_ASAN if os.path.exists("/dev/kfd") else "detect_leaks=1:abort_on_error=1"
+    r = subprocess.run([_built("plan_driver")], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS=opts, UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "plan_driver ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
+def test_oracle_under_asan_ubsan_computes_the_same_numbers():
+    san = subprocess.run([_built("oracle_driver")], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert san.returncode == 0, san.stderr[-3000:]
+    assert "runtime error" not in san.stderr and "AddressSanitizer" not in san.stderr
+    plain = subprocess.run([_built("oracle_driver_plain")], capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0 and san.stdout == plain.stdout and len(san.stdout.splitlines()) >= 15
+
+
+def _run_host(exe, args, model=False, timeout=900):
+    env = dict(os.environ, ASAN_OPTIONS=GPU_ASAN, UBSAN_OPTIONS="print_stacktrace=1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if model:
+        lib = os.path.join(ROOT, "tests", "rccl_model", "librccl_model.so")
+        if not os.path.exists(lib):
+            pytest.skip("tests/rccl_model is not built")
+        env["X266HIP_RCCL_LIB"] = lib
+    r = subprocess.run([exe] + [str(a) for a in args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+    return r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,model", [(1, False), (2, False), (3, False), (2, True), (3, True), (8, True)])
+def test_stream_schedule_under_asan_ubsan(ranks, model):
+    """host/stream8k.c against the instrumented library: one process, `ranks` ranks on the one GPU -- peer-copy transport
+    (RCCL refuses two ranks on a device) or, under the RCCL model, the ncclGroupStart/Send/Recv/End path itself."""
+    size = (7680, 4320) if ranks == 1 else (1920, 1088)
+    r = _run_host(_built("stream8k_asan"), [ranks, 24, size[0], size[1]], model=model)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ranks"] == ranks and d["bit_exact_vs_single_device"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 3])
+def test_one_process_per_rank_under_asan_ubsan(ranks):
+    r = _run_host(_built("stream8k_ranks_asan"), [ranks, 8, 1920, 1088], model=ranks > 1)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["processes"] == ranks and d["bit_exact_vs_single_device"] is True
+
+
+@pytest.mark.gpu
+def test_bdpi_and_batch_hosts_under_asan_ubsan():
+    _run_host(_built("tb_protocol_asan"), ["dct", 3])
+    _run_host(_built("tb_protocol_asan"), ["satd", 8])
+    _run_host(_built("batch_example_asan"), [])
