@@ -294,6 +294,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_ranks(value):
+        """the value of every rank, in rank order (control-plane all-gather)"""
+        if dist is None:
+            return [value]
+        t = torch.zeros(world, dtype=torch.float64, device=ctrl)
+        t[rank] = value
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
     events = [codec.event_create() for _ in range(max(K, 8) + 1)]
 
     def timed_leg(fn, steps=None, warmup=None):
@@ -319,8 +328,11 @@ def main():
         barrier()
         wall = max_over_ranks(time.perf_counter() - t0)
         d = [codec.event_elapsed_ms(events[i], events[i + 1]) for i in range(steps)]
-        return {"wall_s": wall, "steps": steps, "ms_per_step": wall / steps * 1e3, "kernel_ms_mean": sum(d) / steps,
-                "kernel_ms_median": statistics.median(d), "clock_prewarm_launches": pre}
+        # kernel time like wall time: the slowest rank's (every rank runs the same launches on its own shard)
+        mean_all = all_ranks(sum(d) / steps)
+        med_all = all_ranks(statistics.median(d))
+        return {"wall_s": wall, "steps": steps, "ms_per_step": wall / steps * 1e3, "kernel_ms_mean": max(mean_all),
+                "kernel_ms_median": max(med_all), "kernel_ms_mean_by_rank": mean_all if world > 1 else None, "clock_prewarm_launches": pre}
 
     def rate(leg, units_per_step):
         return world * units_per_step * leg["steps"] / leg["wall_s"]
@@ -334,6 +346,8 @@ def main():
         return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel_ms_per_launch": leg["kernel_ms_mean"], "kernel_ms_median": leg["kernel_ms_median"],
+                "kernel_ms_per_launch_is": "HIP events on the launching stream around the timed launches; with several ranks the slowest rank's mean",
+                "frac_by_rank": [bytes_per_unit * n_units / (m * 1e-3) / HBM_PEAK_BYTES_PER_S for m in leg["kernel_ms_mean_by_rank"]] if leg.get("kernel_ms_mean_by_rank") else None,
                 "frac_at_median": bytes_per_unit * n_units / (leg["kernel_ms_median"] * 1e-3) / HBM_PEAK_BYTES_PER_S,
                 "algorithmic_bytes_per_launch": bytes_per_unit * n_units}
 
@@ -627,6 +641,13 @@ def main():
                     dist.broadcast_object_list(uid, src=0, device=torch.device("cuda", local_rank) if ctrl == "cuda" else None)
                 node = Node.for_rank(local_rank, rank, world, uid[0])      # xHipNodeInitRank: one process per GPU, also at N = 1
                 node.self_test()                                            # RCCL ring send/recv + all-reduce, checked
+                ver, path = Node.rccl_info()
+                infos = [None] * world
+                if dist is not None:
+                    dist.all_gather_object(infos, "%s (version %d)" % (path, ver))
+                else:
+                    infos = ["%s (version %d)" % (path, ver)]
+                also["rccl_by_rank"] = infos                                # which library each rank's node layer talks to (torch's bundled one or ROCm's)
                 fw8, fh8 = 7680, 4320
                 nd8, ns8 = (fw8 // 32) * (fh8 // 32), (fw8 // 8) * (fh8 // 8)
                 IN_RING, OUT_RING = 3, 4
@@ -644,7 +665,8 @@ def main():
                     if rank == 0:
                         a, b = fin[f % IN_RING]
                         c, e = fout[f % OUT_RING]
-                        st8.push([a.data_ptr(), b.data_ptr()], [c.data_ptr(), e.data_ptr()])
+                        # resident inputs: "produced" on the frame's own slot stream, so the push needs no producer event
+                        st8.push([a.data_ptr(), b.data_ptr()], [c.data_ptr(), e.data_ptr()], producer_stream=st8.next_slot_stream())
                     else:
                         st8.push()
                 F = args.stream8k
@@ -667,10 +689,24 @@ def main():
                     codec.satd8x8_dev(b.data_ptr(), e1.data_ptr(), ns8, stream)
                     torch.cuda.synchronize()
                     exact8 = bool(torch.equal(c, c1) and torch.equal(e, e1))
+                kernel_us = None
+                if rank == 0 and world == 1:                                # what the frame's one launch costs by itself, back to back on one stream
+                    a, b = fin[0]
+                    c, e = fout[0]
+                    frame_fn = lambda: codec.frame_lanes_dev(a.data_ptr(), c.data_ptr(), nd8, b.data_ptr(), e.data_ptr(), ns8, stream)
+                    for _ in range(200):
+                        frame_fn()
+                    codec.event_record(events[0], stream)
+                    for _ in range(200):
+                        frame_fn()
+                    codec.event_record(events[1], stream)
+                    kernel_us = codec.event_elapsed_ms(events[0], events[1]) / 200 * 1e3
                 peers = world - 1
                 link_bytes = (nd8 * 2048 + ns8 * 128) / world              # one peer's input shard of a frame, over one link
                 also["stream8k"] = {
                     "frames_per_s": F / wall8, "ms_per_frame": wall8 / F * 1e3, "frames": F,
+                    "kernel_us": kernel_us, "launches_per_frame_and_rank": 1,
+                    "kernel_share_of_frame_time": (kernel_us * 1e-6 / (wall8 / F)) if kernel_us else None,
                     "dct32_blocks_per_s": nd8 * F / wall8, "satd8x8_blocks_per_s": ns8 * F / wall8,
                     "frame": "7680x4320: %d DCT32 blocks (66.4 MB) + %d SATD blocks (66.4 MB)" % (nd8, ns8),
                     "path": "C ABI node layer (xNodeStreamPush / Flush): per step one RCCL group carries frame t's shards root -> peers and "
@@ -694,6 +730,10 @@ def main():
                 barrier()
                 wall_sg = max_over_ranks(time.perf_counter() - t0) / 4
                 also["dct32_scatter_gather"] = {"value": nsg / wall_sg, "unit": "blocks/s", "blocks": nsg,
+                                                "link_bound_blocks_per_s": (world * XGMI_LINK_BYTES_PER_S / 2048.0) if world > 1 else None,
+                                                "link_bound": "every peer's shard crosses ONE xGMI link (~153 GB/s per direction, inputs one way, results the other): "
+                                                              "<= 153e9 / 2048 = 7.5e7 blocks/s per peer, i.e. world x 7.5e7 with the root computing its own shard in place"
+                                                              if world > 1 else None,
                                                 "note": "root-resident batch cut into chunks (8 MiB of input per rank), pipelined through the node stream "
                                                         "(xNodeBatchScatterGather); at N = 1 no transfer"}
                 if not args.no_me:

@@ -78,9 +78,7 @@ def test_frame_lanes_in_one_launch(codec, oracle, n_dct, n_satd):
     sin, sout = codec.alloc(d.nbytes), codec.alloc(max(n_satd, 4) * 4)
     din.upload(x)
     sin.upload(d)
-    P = ctypes.c_void_p
-    codec.L.xDct32SatdFrameDev.argtypes = [P, P, P, ctypes.c_size_t, P, P, ctypes.c_size_t, P]
-    assert codec.L.xDct32SatdFrameDev(codec.ctx, din.ptr, dout.ptr, n_dct, sin.ptr, sout.ptr, n_satd, None) == 0
+    codec.frame_lanes_dev(din.ptr, dout.ptr, n_dct, sin.ptr, sout.ptr, n_satd)
     codec.stream_sync()
     if n_dct:
         assert np.array_equal(dout.download(np.int16, n_dct * 1024).reshape(-1, 1024), oracle.dct32_fwd(x[:n_dct], threads=8))

@@ -76,6 +76,7 @@ def load_library():
     L.xTransformInvBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
     L.xTransformTilesDev.argtypes = [_P, ctypes.c_int, _P, _P, _SZ, _P, _P, _P]
     L.xDct32PassDev.argtypes = [_P, _P, _P, _SZ, ctypes.c_int, _P]
+    L.xDct32SatdFrameDev.argtypes = [_P, _P, _P, _SZ, _P, _P, _SZ, _P]
     L.xTransformSetMatrix.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P]
     L.xTransformGetMatrix.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P]
     L.xHipMeScratchReserve.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int]
@@ -325,6 +326,9 @@ class Codec:
     def transform_tiles_dev(self, inverse, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, stream=0):
         self._check(self.L.xTransformTilesDev(self.ctx, int(inverse), d_in, d_out, n_tiles, d_tile_offsets or None, d_tile_class, stream),
                     "xTransformTilesDev")
+
+    def frame_lanes_dev(self, d_dct_in, d_dct_out, n_dct, d_diff, d_satd_out, n_satd, stream=0):
+        self._check(self.L.xDct32SatdFrameDev(self.ctx, d_dct_in, d_dct_out, n_dct, d_diff, d_satd_out, n_satd, stream), "xDct32SatdFrameDev")
 
     def dct32_pass(self, x, shift):
         """numpy convenience around xDct32PassDev: [n, 1024] int16 -> the 1-D pass of every block, stored transposed."""
