@@ -2,7 +2,7 @@
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun; outputs under gpurun_out/).
 #   tools/run_profiles.sh <round-tag, e.g. r02> <suffix>
 # Kernel-trace + stats in one pass; every PMC group in its own pass (never with sys/hip/hsa traces).
-T=${1:-r02}
+T=${1:-r03}
 S=${2:-x}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp

@@ -662,21 +662,29 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
     P.blocks_x = width / 8; P.blocks_y = height / 8;
     P.tiles_x = (P.blocks_x + kTileBlocksX - 1) / kTileBlocksX;
     if (tile_rows <= 0) {
-        // Tile height by frame size.  Measured (profiles/r02_me_sizes.txt, R = 64, 256 CUs): a launch of T tiles takes about
-        // L + (ceil(T / CUs) - 1) * S with (L, S) = (0.40, 0.30) ms for 8-row tiles, (0.23, 0.167) for 4 and (0.146, 0.098) for 2
-        // -- a lone tile costs L whatever the chip could do next to it, and tall tiles halve the position transforms per
-        // block.  4K frames want 8 rows, a 544-row stripe 4, a 360p frame 2; only the ratios matter, they hold for any range.
+        // Tile height by frame size (profiles/r03_me_variants.txt, R = 64, 256 CUs; only the ratios matter, they hold for any
+        // range).  Two 8-wave workgroups are resident per CU whatever the height (110 VGPRs), so a launch of T tiles is
+        // floor(T / slots) full rounds of R_h each plus a last, partly filled one: up to one workgroup per CU it costs what a
+        // lone tile costs (A_h: the workgroup has its CU to itself), from there to a full round it grows to R_h; behind full
+        // rounds it overlaps their ragged end (x 0.9).  Tall tiles halve the position transforms per block (R_8 < 2 R_4),
+        // short ones waste less of a thin launch: 4K wants 8 rows, a 544-row stripe 4, 360p 2.
         const int cus = cu_count > 0 ? cu_count : 256;
-        const float L[3] = {4.0f, 2.3f, 1.46f}, S[3] = {3.0f, 1.67f, 0.98f};
+        const long long slots = 2LL * cus;
+        const float R[3] = {0.565f, 0.312f, 0.182f}, A[3] = {0.35f, 0.20f, 0.13f};
         const int cand[3] = {8, 4, 2};
         float best_t = 0.f;
         for (int c = 0; c < 3; ++c) {
             const long long tiles = (long long)P.tiles_x * ((P.blocks_y + cand[c] - 1) / cand[c]);
-            const float t = L[c] + (float)((tiles + cus - 1) / cus - 1) * S[c];
+            const long long full = tiles / slots, rest = tiles % slots;
+            float t = (float)full * R[c];
+            if (rest) {
+                const float part = rest <= cus ? A[c] : A[c] + (R[c] - A[c]) * (float)(rest - cus) / (float)(slots - cus);
+                t += full ? 0.9f * part : part;
+            }
             if (c == 0 || t < best_t) { best_t = t; tile_rows = cand[c]; }
         }
     }
-    const int tby = tile_rows >= 8 ? 8 : (tile_rows >= 4 ? 4 : (tile_rows == 1 ? 1 : 2));
+    const int tby = tile_rows >= 8 ? 8 : (tile_rows >= 4 ? 4 : 2);     // 1 is served by 2-row tiles (partial tiles are handled anyway)
     const int tiles_y = (P.blocks_y + tby - 1) / tby;
     const int span = 2 * range + 1;
     const int n_rows = 8 * (tby - 1) + span;
@@ -700,7 +708,7 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
 #define X266_ME5(T) do { if (d_costs) hipLaunchKernelGGL((satd_search_kernel<T, true, 512, 4>), grid, block, lds, stream, P, cf); \
                          else         hipLaunchKernelGGL((satd_search_kernel<T, false, 512, 4>), grid, block, lds, stream, P, cf); } while (0)
 #endif
-    if (tby == 8) X266_ME5(8); else if (tby == 4) X266_ME5(4); else if (tby == 1) X266_ME5(1); else X266_ME5(2);
+    if (tby == 8) X266_ME5(8); else if (tby == 4) X266_ME5(4); else X266_ME5(2);
 #undef X266_ME5
     return hipGetLastError();
 }
@@ -714,7 +722,8 @@ hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const u
     P.width = width; P.height = height; P.range = range;
     P.blocks_x = width / 8; P.blocks_y = height / 8;
     P.tiles_x = (P.blocks_x + kTileBlocksX - 1) / kTileBlocksX;
-    const int tby = tile_rows >= 4 ? 4 : (tile_rows == 1 ? 1 : 2);   // 0 (automatic) = 2: as fast as 4 on a 4K frame, finer-grained on small ones
+    (void)tile_rows;
+    const int tby = 2;                                               // two block rows per tile whatever "me_tile_rows" says: faster than 4 on a 4K frame (1.21 against 1.27 ms) and finer-grained on small ones
     const int tiles_y = (P.blocks_y + tby - 1) / tby;
     const int span = 2 * range + 1;
     const int n_rows = 8 * (tby - 1) + span;
@@ -723,7 +732,7 @@ hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const u
     const size_t lds = 256 + (size_t)(n_rows + 7) * kPitch;
 #define X266_SADS(T) do { if (d_costs) hipLaunchKernelGGL((sad_search_kernel<T, true>), grid, block, lds, stream, P); \
                           else         hipLaunchKernelGGL((sad_search_kernel<T, false>), grid, block, lds, stream, P); } while (0)
-    if (tby == 4) X266_SADS(4); else if (tby == 1) X266_SADS(1); else X266_SADS(2);
+    X266_SADS(2);
 #undef X266_SADS
     return hipGetLastError();
 }

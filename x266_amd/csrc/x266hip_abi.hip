@@ -46,7 +46,7 @@ struct x266hip_ctx {
     int wg_threads = 256;
     int satd_wg_threads = 128;                      // SATD batch (staged): two-wave workgroups, 2 groups per wave (profiles/r01_satd_staged_nt.txt)
     int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
-    int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (SATD search: 8, 4 or 2; SAD search: 2), else 1, 2, 4, 8 (8: SATD search only)
+    int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (SATD search: 8, 4 or 2; SAD search: 2), else 2, 4, 8 (8: SATD search only; 1 is served by 2)
     int intra_rounds = 4;                           // intra prediction: rounds of seven predictions per wave (next round's reference sets prefetched)
     // Internal device scratch, ONE BUFFER PER STREAM AND KIND, so that calls enqueued on different streams never share it:
     // kind 0 = motion search (128 B per 8x8 block of the current frame).  Each table is bounded (kMeScratchMax streams, least recently used evicted after waiting for its
