@@ -650,7 +650,7 @@ def main():
                 also["rccl_by_rank"] = infos                                # which library each rank's node layer talks to (torch's bundled one or ROCm's)
                 fw8, fh8 = 7680, 4320
                 nd8, ns8 = (fw8 // 32) * (fh8 // 32), (fw8 // 8) * (fh8 // 8)
-                IN_RING, OUT_RING = 3, 4
+                IN_RING, OUT_RING = 4, 5
                 fin = fout = None
                 if rank == 0:
                     fin = [(torch.empty(nd8 * 1024, dtype=torch.int16, device="cuda"), torch.empty(ns8 * 64, dtype=torch.int16, device="cuda")) for _ in range(IN_RING)]

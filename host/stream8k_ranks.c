@@ -20,8 +20,8 @@
 
 #include "../include/x266hip.h"
 
-#define IN_RING 3
-#define OUT_RING 4
+#define IN_RING 4
+#define OUT_RING 5
 #define N_VAL (OUT_RING + 2)
 #define MAX_RANKS 64
 

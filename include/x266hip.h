@@ -380,10 +380,11 @@ void xNodeStreamFree(x266hip_nstream *s);
  * received into these buffers directly); ignored on other processes (may be NULL).  units[lane]
  * (NULL: the stream's max_units) must be the same on every rank.  producer_stream: the root-device
  * stream the inputs were produced on (ordering by event; NULL = the default stream).
- * Inputs of a step may be overwritten, and its ticket waited for, once two later steps have been issued
- * (Push or Flush); until then its buffers belong to the stream -- the kernels of consecutive frames run on
- * two alternating streams and may overlap, so frames t and t+1 must not share buffers.  *ticket (may be NULL)
- * receives t. */
+ * A step's ticket may be waited for once TWO later steps have been issued (Push or Flush); its inputs may be
+ * overwritten once THREE later steps have been issued (or its ticket has been waited for): until then its buffers belong
+ * to the stream -- the kernels of three consecutive frames run on three streams and may overlap (only a third frame in
+ * flight covers the ramp and tail of ~30 us kernels), so frames t, t+1 and t+2 must not share buffers: input rings of four,
+ * output rings of five or more.  *ticket (may be NULL) receives t. */
 int  xNodeStreamPush(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units,
                      void *producer_stream, long *ticket);
 /* The root-device stream on which the NEXT pushed frame's kernels will run (NULL on processes that do not drive the

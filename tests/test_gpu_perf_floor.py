@@ -116,12 +116,12 @@ def test_other_baseline_config_legs_stay_above_their_floors():
     node = Node.for_rank(0, 0, 1, Node.unique_id())
     nd, ns = (7680 // 32) * (4320 // 32), (7680 // 8) * (4320 // 8)
     st = node.frame_stream(7680, 4320)
-    fin = [(x[i * nd * 1024:(i + 1) * nd * 1024], x[(8 + i) * ns * 64:(9 + i) * ns * 64]) for i in range(3)]
-    fout = [(z[i * nd * 1024:(i + 1) * nd * 1024], torch.empty(ns, dtype=torch.int32, device="cuda")) for i in range(4)]
+    fin = [(x[i * nd * 1024:(i + 1) * nd * 1024], x[(8 + i) * ns * 64:(9 + i) * ns * 64]) for i in range(4)]
+    fout = [(z[i * nd * 1024:(i + 1) * nd * 1024], torch.empty(ns, dtype=torch.int32, device="cuda")) for i in range(5)]
 
     def push(f):
-        a, b = fin[f % 3]
-        c, e = fout[f % 4]
+        a, b = fin[f % 4]
+        c, e = fout[f % 5]
         st.push([a.data_ptr(), b.data_ptr()], [c.data_ptr(), e.data_ptr()], producer_stream=st.next_slot_stream())
     for f in range(200):
         push(f)

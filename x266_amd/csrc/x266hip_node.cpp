@@ -116,8 +116,9 @@ struct LocalRank {
     int rank = 0;
     x266hip_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
-    hipStream_t comm_stream = nullptr, compute_stream = nullptr;
-    hipStream_t compute_stream_odd = nullptr;  // frames of odd steps: consecutive frames share nothing, so their kernels may overlap
+    static constexpr int kComputeStreams = 3;  // = x266hip_nstream::kSlots: frame t runs on stream t % 3 -- consecutive frames share nothing, so their kernels may overlap
+    hipStream_t comm_stream = nullptr;
+    hipStream_t compute[kComputeStreams] = {};  // [0] also carries everything that is not a frame stream (motion search stripes)
     std::vector<DevBuf> me_bufs;           // motion-search stripe buffers (cur, ref, best per owned stripe)
     DevBuf selftest;
 };
@@ -147,7 +148,10 @@ struct x266hip_nstream {
     int n_lanes = 0;
     int op[4] = {};
     size_t max_units[4] = {};
-    static constexpr int kSlots = 2, kRing = 4;
+    // three slots: a frame's kernels take ~30 us, and only a third frame in flight covers the ramp and tail of the two before it
+    // (one-rank 8K stream: 36.8 -> 34.3 us per frame); kRing >= kSlots + 3 step records
+    static constexpr int kSlots = 3, kRing = 6;
+    static_assert(kSlots == LocalRank::kComputeStreams, "one compute stream per slot");
     struct Step {
         bool has_frame = false;
         size_t units[4] = {};
@@ -216,8 +220,7 @@ int open_rank(x266hip_node *node, LocalRank &lr)
     if (rc != X266HIP_OK) return nfail(node, rc, "xHipCodecInit failed for a node device");
     DeviceScope dev(lr.device);
     N_HIP(node, hipStreamCreateWithFlags(&lr.comm_stream, hipStreamNonBlocking));
-    N_HIP(node, hipStreamCreateWithFlags(&lr.compute_stream, hipStreamNonBlocking));
-    N_HIP(node, hipStreamCreateWithFlags(&lr.compute_stream_odd, hipStreamNonBlocking));
+    for (hipStream_t &cs : lr.compute) N_HIP(node, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     return X266HIP_OK;
 }
 
@@ -342,15 +345,13 @@ void xHipNodeFree(x266hip_node *node)
     for (LocalRank &lr : node->local) {
         DeviceScope dev(lr.device);
         if (lr.comm_stream) (void)hipStreamSynchronize(lr.comm_stream);
-        if (lr.compute_stream) (void)hipStreamSynchronize(lr.compute_stream);
-        if (lr.compute_stream_odd) (void)hipStreamSynchronize(lr.compute_stream_odd);
+        for (hipStream_t cs : lr.compute) if (cs) (void)hipStreamSynchronize(cs);
         if (lr.comm && R) (void)R->CommDestroy(lr.comm);
         for (DevBuf &b : lr.me_bufs)
             if (b.p) (void)hipFree(b.p);
         if (lr.selftest.p) (void)hipFree(lr.selftest.p);
         if (lr.comm_stream) (void)hipStreamDestroy(lr.comm_stream);
-        if (lr.compute_stream) (void)hipStreamDestroy(lr.compute_stream);
-        if (lr.compute_stream_odd) (void)hipStreamDestroy(lr.compute_stream_odd);
+        for (hipStream_t cs : lr.compute) if (cs) (void)hipStreamDestroy(cs);
         if (lr.ctx) xHipCodecFree(lr.ctx);
     }
     delete node;
@@ -567,8 +568,7 @@ void xNodeStreamFree(x266hip_nstream *s)
         LocalRank &lr = s->node->local[i];
         DeviceScope dev(lr.device);
         (void)hipStreamSynchronize(lr.comm_stream);
-        (void)hipStreamSynchronize(lr.compute_stream);
-        (void)hipStreamSynchronize(lr.compute_stream_odd);
+        for (hipStream_t cs : lr.compute) (void)hipStreamSynchronize(cs);
         x266hip_nstream::PerRank &p = s->per[i];
         for (int sl = 0; sl < x266hip_nstream::kSlots; ++sl) {
             for (int l = 0; l < 4; ++l) {
@@ -663,9 +663,10 @@ int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d
     }
     const x266hip_nstream::Step *old = t >= 2 ? &s->ring[(t - 2) % x266hip_nstream::kRing] : nullptr;
     if (old && !old->has_frame) old = nullptr;
+    const int old_slot = (int)((t + x266hip_nstream::kSlots - 2) % x266hip_nstream::kSlots);   // frame t-2's slot
 
-    // (1) the slot's previous frame (t-2) must have finished its kernels: its input slot is about to be
-    //     overwritten and its output slot is about to be sent.  Host wait = bounded run-ahead (two frames).
+    // (1) the slot's previous frame (t-3) must have finished its kernels: its input slot is about to be
+    //     overwritten (its output slot was sent at step t-1).  Host wait = bounded run-ahead (three frames).
     for (size_t i = 0; i < node->local.size(); ++i) {
         LocalRank &lr = node->local[i];
         x266hip_nstream::PerRank &p = s->per[i];
@@ -674,12 +675,15 @@ int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d
             N_HIP(node, hipEventSynchronize(p.ev_done[slot]));
             if (W > 1) N_HIP(node, hipStreamWaitEvent(lr.comm_stream, p.ev_done[slot], 0));
         }
-        // ... and its transfers (step t-2's group on the communication stream) must have completed: with one process per
-        // GPU nothing else keeps the root from running many groups ahead of lagging peers, and both the buffer-ownership
-        // rule of xNodeStreamPush (inputs reusable after two later steps) and xNodeStreamWait's "long done" rest on this bound
+        if (W > 1 && old) {                                            // frame t-2's results leave in this step: behind its kernels (device-side wait)
+            if (p.done_recorded[old_slot]) N_HIP(node, hipStreamWaitEvent(lr.comm_stream, p.ev_done[old_slot], 0));
+        }
+        // ... and the transfers of the step that last used this slot (step t-3's group on the communication stream) must have
+        // completed: with one process per GPU nothing else keeps the root from running many groups ahead of lagging peers, and
+        // both the buffer-ownership rule of xNodeStreamPush (inputs reusable after three later steps) and xNodeStreamWait rest on it
         if (p.xfer_recorded[slot]) N_HIP(node, hipEventSynchronize(p.ev_xfer[slot]));
         if (lr.rank == root && has_frame) {                           // inputs come from the caller's stream
-            hipStream_t cs = slot ? lr.compute_stream_odd : lr.compute_stream;
+            hipStream_t cs = lr.compute[slot];
             const bool in_order = W == 1 && producer_stream && (hipStream_t)producer_stream == cs;   // produced on the slot's own stream: stream order suffices
             if (!in_order) {
                 N_HIP(node, hipEventRecord(p.ev_producer, (hipStream_t)producer_stream));
@@ -721,7 +725,7 @@ int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d
                     size_t b, e;
                     shard(st->units[l], lr.rank, W, &b, &e);
                     if (e == b) continue;
-                    xs.push_back({(int)i, phase == 1, root, phase == 0 ? p.in[slot][l] : p.out[slot][l], (e - b) * unit});
+                    xs.push_back({(int)i, phase == 1, root, phase == 0 ? p.in[slot][l] : p.out[old_slot][l], (e - b) * unit});
                 }
             }
         }
@@ -738,7 +742,7 @@ int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d
             p.xfer_recorded[slot] = true;
         }
         if (!has_frame) continue;
-        hipStream_t cs = slot ? lr.compute_stream_odd : lr.compute_stream;   // the slot's own stream: frame t-2 (same buffers) is ahead of frame t on it
+        hipStream_t cs = lr.compute[slot];   // the slot's own stream: frame t-2 (same buffers) is ahead of frame t on it
         if (lr.rank != root) N_HIP(node, hipStreamWaitEvent(cs, p.ev_xfer[slot], 0));   // the root works in place: nothing to wait for
         const void *lane_in[4] = {};
         void *lane_out[4] = {};
@@ -791,7 +795,7 @@ void *xNodeStreamNextSlotStream(x266hip_nstream *s)
     if (!s) return nullptr;
     LocalRank *r = root_rank(s->node);
     if (!r) return nullptr;
-    return (s->n_steps % x266hip_nstream::kSlots) ? (void *)r->compute_stream_odd : (void *)r->compute_stream;
+    return (void *)r->compute[s->n_steps % x266hip_nstream::kSlots];
 }
 
 int xNodeStreamFlush(x266hip_nstream *s)
@@ -804,8 +808,7 @@ int xNodeStreamFlush(x266hip_nstream *s)
     for (LocalRank &lr : s->node->local) {
         DeviceScope dev(lr.device);
         N_HIP(s->node, hipStreamSynchronize(lr.comm_stream));
-        N_HIP(s->node, hipStreamSynchronize(lr.compute_stream));
-        N_HIP(s->node, hipStreamSynchronize(lr.compute_stream_odd));
+        for (hipStream_t cs : lr.compute) N_HIP(s->node, hipStreamSynchronize(cs));
     }
     return X266HIP_OK;
 }
@@ -814,11 +817,22 @@ int xNodeStreamWait(x266hip_nstream *s, long ticket)
 {
     if (!s || ticket < 0) return X266HIP_EINVAL;
     if (ticket + 2 >= s->n_steps) return nfail(s->node, X266HIP_EINVAL, "xNodeStreamWait: the step's results travel two steps later (Push or Flush first)");
-    if (ticket + 2 + x266hip_nstream::kSlots < s->n_steps) return X266HIP_OK;     // its events have been reused: long done
-    const int slot = (int)((ticket + 2) % x266hip_nstream::kSlots);
-    for (size_t i = 0; i < s->node->local.size(); ++i) {
-        DeviceScope dev(s->node->local[i].device);
-        if (s->per[i].xfer_recorded[slot]) N_HIP(s->node, hipEventSynchronize(s->per[i].ev_xfer[slot]));
+    constexpr long K = x266hip_nstream::kSlots;
+    // the frame's kernels: their event is host-synchronised anyway when the slot comes round again (step ticket + K)
+    if (s->n_steps <= ticket + K) {
+        const int slot = (int)(ticket % K);
+        for (size_t i = 0; i < s->node->local.size(); ++i) {
+            DeviceScope dev(s->node->local[i].device);
+            if (s->per[i].done_recorded[slot]) N_HIP(s->node, hipEventSynchronize(s->per[i].ev_done[slot]));
+        }
+    }
+    // its results' way back: step ticket + 2's transfers (likewise synchronised at step ticket + 2 + K)
+    if (s->n_steps <= ticket + 2 + K) {
+        const int slot = (int)((ticket + 2) % K);
+        for (size_t i = 0; i < s->node->local.size(); ++i) {
+            DeviceScope dev(s->node->local[i].device);
+            if (s->per[i].xfer_recorded[slot]) N_HIP(s->node, hipEventSynchronize(s->per[i].ev_xfer[slot]));
+        }
     }
     return X266HIP_OK;
 }
@@ -943,11 +957,11 @@ int xNodeSatd8x8Search(x266hip_node *node, const uint8_t *d_cur, intptr_t cur_st
     }
     for (const Work &w : work) {
         LocalRank &lr = node->local[w.local];
-        N_X(node, lr, xSatd8x8SearchDev(lr.ctx, w.cur, cur_stride, w.ref_origin, ref_stride, width, w.rows, range, w.best, nullptr, lr.compute_stream));
+        N_X(node, lr, xSatd8x8SearchDev(lr.ctx, w.cur, cur_stride, w.ref_origin, ref_stride, width, w.rows, range, w.best, nullptr, lr.compute[0]));
     }
     for (LocalRank &lr : node->local) {
         DeviceScope dev(lr.device);
-        N_HIP(node, hipStreamSynchronize(lr.compute_stream));
+        N_HIP(node, hipStreamSynchronize(lr.compute[0]));
     }
     for (const CopyBack &c : copy_back) {                             // the root's own copied stripes
         LocalRank &lr = node->local[c.local];
