@@ -23,8 +23,9 @@ cases = (("7 classes cycling", torch.tensor([3, 2, 6, 1, 5, 0, 4], device="cuda"
 for label, cls in cases:
     for inv in (0, 1):
         tk = "dct32_inv_wg_threads" if inv else "dct32_wg_threads"
-        for tpb, lds in ((64, 3072), (64, 4096), (64, 5120), (64, 6144), (64, 8192), (128, 4096)):
-            for tpw in (1, 2):
+        shapes = [tuple(int(u) for u in v.split(":")) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [(64, 6144), (64, 8192), (64, 10240), (128, 8192), (256, 8192)]   # threads per workgroup : LDS bytes per wave
+        for tpb, lds in shapes:
+            for tpw in ([int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 4)):
                 cd.set_option(tk, tpb); cd.set_option("tile_tiles_per_wave", tpw); cd.set_option("tile_lds_bytes_per_wave", lds)
                 ms = timed(lambda: cd.transform_tiles_dev(inv, x.data_ptr(), z.data_ptr(), nt, 0, cls.data_ptr()))
                 print("%-18s inv=%d tpb=%3d lds/wave=%d tiles/wave=%d: %.4f ms %.2f TB/s frac %.3f" % (label, inv, tpb, lds, tpw, ms, nt * 4096 / ms / 1e9, nt * 4096 / ms / 1e9 / 8), flush=True)

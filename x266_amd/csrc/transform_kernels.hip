@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
 
 // The inverse of fwd_tile_in_slot: the first contraction runs over the tile's ROW index, so each lane reads
 // its COLUMN out of the staged tile (16 x ds_read_u16), exactly as the staged DCT32 inverse does.
-template <int LOGN>
-__device__ __forceinline__ void inv_tile_in_slot(unsigned char *slot, int lane, const LaneConsts &k, const v16i &c2r)
+template <int LOGN, class C2RGroup>
+__device__ __forceinline__ void inv_tile_in_slot_with(unsigned char *slot, int lane, const LaneConsts &k, C2RGroup c2r_group)
 {
     constexpr int N = 1 << LOGN;
     constexpr int PER = 32 / N, PIECES = N >= 16 ? 1 : 16 / N;
@@ -231,7 +231,7 @@ __device__ __forceinline__ void inv_tile_in_slot(unsigned char *slot, int lane, 
     __builtin_amdgcn_wave_barrier();
     v4i lo, hi, r0, r1;
     split_planes(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, lo, hi);
-    inv_passes(lo, hi, k, c2r, r0, r1);
+    inv_passes_with(lo, hi, k, c2r_group, r0, r1);
     const uint32_t z[8] = {(uint32_t)r0[0], (uint32_t)r0[1], (uint32_t)r0[2], (uint32_t)r0[3],
                            (uint32_t)r1[0], (uint32_t)r1[1], (uint32_t)r1[2], (uint32_t)r1[3]};
 #pragma unroll
@@ -245,6 +245,12 @@ __device__ __forceinline__ void inv_tile_in_slot(unsigned char *slot, int lane, 
             *reinterpret_cast<uint2 *>(slot + frag[q]) = make_uint2(z[2 * q], z[2 * q + 1]);
         }
     }
+}
+
+template <int LOGN>
+__device__ __forceinline__ void inv_tile_in_slot(unsigned char *slot, int lane, const LaneConsts &k, const v16i &c2r)
+{
+    inv_tile_in_slot_with<LOGN>(slot, lane, k, [&](int g) { return v4i{c2r[4 * g], c2r[4 * g + 1], c2r[4 * g + 2], c2r[4 * g + 3]}; });
 }
 
 __device__ __forceinline__ v16i load_c2r(const DctOps *__restrict__ ops, int h)
@@ -319,12 +325,15 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
 // A CTU's residual is a sequence of 32x32 regions ("tiles", 1024 samples), each cut into (32/N)^2 blocks of ONE
 // (type, size) class, block-major.  The per-class calls above walk the buffer once per class; this kernel walks it
 // once: tile t carries its class in tile_class[t] (type * 4 + log2N - 2) and sits at sample offset tile_offsets[t]
-// (NULL: t * 1024), the wave fetches that class's operand images (L1/L2-resident, 7 x 3.5 KiB) and runs the same
-// staged pipeline.  Consecutive tiles are consecutive memory, so the access stream is that of a contiguous batch.
-// The operand images of all sixteen classes come from ONE structure-of-arrays table (TileOpsSoA, x266_tables.hpp):
-// dense 1 KiB runs per class.  A wave walks `tiles_per_wave` consecutive tiles and issues the NEXT tile's class byte
-// and data loads before the current tile's arithmetic, so the class -> images -> compute chain of one tile runs
-// under the memory latency of the next.
+// (NULL: t * 1024).  Consecutive tiles are consecutive memory, so the access stream is that of a contiguous batch.
+//
+// Round 3: the operand images are no longer fetched per class from memory (class byte -> images -> first pass: two
+// dependent round trips where the per-class kernels have one, 6-7 % of the launch, profiles/r03_tiles_one_launch.txt).
+// Every wave copies the set's 1-D matrices in compact form (TileTab, 2 KiB, L2-resident) into LDS with its first two
+// loads -- they do not depend on the class, so they travel with the tile's data -- and builds the class's images from
+// there once the class byte has arrived: the block-diagonal 32x32 operand of an N-point transform is the N x N matrix
+// repeated along the diagonal, so a lane's 16 operand bytes are at most 16 bytes of ONE matrix row, masked to the
+// K-slots that fall into the lane's diagonal block.
 // class byte of tile t through the scalar cache: the aligned dword that holds it (t is wave-uniform, so this is an
 // s_load_dword and the class lands in an SGPR without a vector-memory round trip), for any alignment of the table
 __device__ __forceinline__ int tile_class_of(const uint8_t *__restrict__ tile_class, size_t t)
@@ -334,77 +343,176 @@ __device__ __forceinline__ int tile_class_of(const uint8_t *__restrict__ tile_cl
     return (int)((w >> (8 * (unsigned)(a & 3))) & 15u);
 }
 
-__device__ __forceinline__ LaneConsts load_tile_consts(const TileOpsSoA *__restrict__ T, int cls, int lane)
+// Operand bytes B[16h + t][idx], t = 0..15, of blockdiag(M) given as rows: M[idx % N][(16h + t) % N] where the K-slot
+// 16h + t lies in block idx / N, else 0.  `m` = the compact N x N matrix in LDS whose ROW idx % N holds those bytes.
+template <int LOGN>
+__device__ __forceinline__ v4i image_row_segment(const unsigned char *m, unsigned idx, unsigned h)
 {
-    LaneConsts k;
-    k.p1 = *reinterpret_cast<const v4i *>(T->p1[cls][lane]);
-    k.p2 = *reinterpret_cast<const v4i *>(T->p2[cls][lane]);
-    k.tr = v4i{0, 0, 0, 0};
-    k.c1 = T->c12[cls][lane][0];
-    k.c2 = T->c12[cls][lane][1];
-    return k;
+    constexpr unsigned N = 1u << LOGN;
+    const unsigned rr = idx & (N - 1), b = idx >> LOGN;
+    if constexpr (LOGN == 5) {
+        return *reinterpret_cast<const v4i *>(m + rr * 32 + 16 * h);
+    } else if constexpr (LOGN == 4) {                                    // K-slots 16h .. 16h+15 = block h
+        const v4i v = *reinterpret_cast<const v4i *>(m + rr * 16);
+        const int keep = b == h ? -1 : 0;
+        return v4i{v[0] & keep, v[1] & keep, v[2] & keep, v[3] & keep};
+    } else if constexpr (LOGN == 3) {                                    // dwords 0,1 = block 2h, dwords 2,3 = block 2h + 1
+        const uint2 w = *reinterpret_cast<const uint2 *>(m + rr * 8);
+        const int k0 = b == 2 * h ? -1 : 0, k1 = b == 2 * h + 1 ? -1 : 0;
+        return v4i{(int)w.x & k0, (int)w.y & k0, (int)w.x & k1, (int)w.y & k1};
+    } else {                                                             // dword q = block 4h + q
+        const int w = *reinterpret_cast<const int *>(m + rr * 4);
+        return v4i{b == 4 * h ? w : 0, b == 4 * h + 1 ? w : 0, b == 4 * h + 2 ? w : 0, b == 4 * h + 3 ? w : 0};
+    }
 }
 
+// Forward pass 2: B[acc_row(t, h)][c], i.e. dword q holds columns 4h + 8q .. +3 of row c of blockdiag(M).
+template <int LOGN>
+__device__ __forceinline__ v4i image_acc_rows(const unsigned char *m, unsigned c, unsigned h)
+{
+    constexpr unsigned N = 1u << LOGN;
+    const unsigned rr = c & (N - 1), b = c >> LOGN;
+    if constexpr (LOGN == 5) {
+        const int *q = reinterpret_cast<const int *>(m + rr * 32 + 4 * h);
+        return v4i{q[0], q[2], q[4], q[6]};
+    } else if constexpr (LOGN == 4) {                                    // columns 4h + 8q: block q >> 1, dword h + 2 (q & 1) of the row
+        const int *q = reinterpret_cast<const int *>(m + rr * 16 + 4 * h);
+        const int w0 = q[0], w1 = q[2];
+        return v4i{b == 0 ? w0 : 0, b == 0 ? w1 : 0, b == 1 ? w0 : 0, b == 1 ? w1 : 0};
+    } else if constexpr (LOGN == 3) {                                    // block q, dword h of the row
+        const int w = *reinterpret_cast<const int *>(m + rr * 8 + 4 * h);
+        return v4i{b == 0 ? w : 0, b == 1 ? w : 0, b == 2 ? w : 0, b == 3 ? w : 0};
+    } else {                                                             // block h + 2q, the row's one dword
+        const int w = *reinterpret_cast<const int *>(m + rr * 4);
+        return v4i{b == h ? w : 0, b == h + 2 ? w : 0, b == h + 4 ? w : 0, b == h + 6 ? w : 0};
+    }
+}
+
+// tab: the wave's LDS copy of the TileTab; hs / vs: the slots (0 / 1) of the class's horizontal and vertical transform
+template <int LOGN>
+__device__ __forceinline__ void fwd_tile_of_class(unsigned char *slot, const unsigned char *tab, int lane, unsigned hs, unsigned vs)
+{
+    constexpr unsigned N = 1u << LOGN;
+    constexpr int S1 = LOGN - 1, S2 = LOGN + 6;
+    const unsigned c = lane & 31, h = lane >> 5, kc = (unsigned)kappa((int)c);
+    const unsigned mh = tile_tab_mat(0, LOGN - 2) + (LOGN == 5 ? 0u : hs * 336u), mv = tile_tab_mat(0, LOGN - 2) + (LOGN == 5 ? 0u : vs * 336u);
+    const unsigned sh = tile_tab_sum(0, LOGN - 2) + (LOGN == 5 ? 0u : hs * 112u), sv = tile_tab_sum(0, LOGN - 2) + (LOGN == 5 ? 0u : vs * 112u);
+    LaneConsts k;
+    k.p1 = image_row_segment<LOGN>(tab + mh, kc, h);                     // pass 1: M[kappa(c)][16h + t]
+    k.p2 = image_acc_rows<LOGN>(tab + mv, c, h);                         // pass 2: M[c][acc_row(t, h)]
+    k.tr = v4i{0, 0, 0, 0};
+    k.c1 = (1 << (S1 - 1)) + reinterpret_cast<const int *>(tab + sh)[kc & (N - 1)];
+    k.c2 = (1 << (S2 - 1)) + reinterpret_cast<const int *>(tab + sv)[c & (N - 1)];
+    fwd_tile_in_slot<LOGN>(slot, lane, k);
+}
+
+// The inverse reads the table built from the TRANSPOSED matrices: pass A (vertical, columns first) M[16h + t][c] and
+// pass B (horizontal) M[16h + t][kappa(c)] are both row segments there.
+template <int LOGN>
+__device__ __forceinline__ void inv_tile_of_class(unsigned char *slot, const unsigned char *tab, int lane, unsigned hs, unsigned vs)
+{
+    constexpr unsigned N = 1u << LOGN;
+    const unsigned c = lane & 31, h = lane >> 5, kc = (unsigned)kappa((int)c);
+    const unsigned mh = tile_tab_mat(0, LOGN - 2) + (LOGN == 5 ? 0u : hs * 336u), mv = tile_tab_mat(0, LOGN - 2) + (LOGN == 5 ? 0u : vs * 336u);
+    const unsigned sh = tile_tab_sum(0, LOGN - 2) + (LOGN == 5 ? 0u : hs * 112u), sv = tile_tab_sum(0, LOGN - 2) + (LOGN == 5 ? 0u : vs * 112u);
+    LaneConsts k;
+    k.p1 = image_row_segment<LOGN>(tab + mv, c, h);
+    k.p2 = image_row_segment<LOGN>(tab + mh, kc, h);
+    k.tr = v4i{0, 0, 0, 0};
+    k.c1 = (1 << 6) + reinterpret_cast<const int *>(tab + sv)[c & (N - 1)];
+    k.c2 = 0;
+    // pass-B constants per accumulator register: output column x = 16h + r, i.e. sum (16h + r) % N of the horizontal matrix
+    const v4i *sums = reinterpret_cast<const v4i *>(tab + sh);
+    inv_tile_in_slot_with<LOGN>(slot, lane, k, [&](int g) {
+        constexpr int G = (int)N / 4;                                    // v4i groups holding the N sums
+        const v4i v = LOGN == 5 ? sums[4 * h + g] : sums[g % (G < 4 ? G : 4)];
+        return v4i{v[0] + (1 << 11), v[1] + (1 << 11), v[2] + (1 << 11), v[3] + (1 << 11)};
+    });
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ void tile_of_class(unsigned char *slot, const unsigned char *tab, int lane, int cls)
+{
+    const unsigned type = (unsigned)cls >> 2;                           // 0 DCT-II, 1 DST-VII, 2 h = slot 1 / v = slot 0, 3 the other way (wave-uniform)
+    const unsigned hs = (type == 1 || type == 2) ? 1u : 0u, vs = (type == 1 || type == 3) ? 1u : 0u;
+    if (INVERSE) {
+        switch (cls & 3) {
+        case 0: inv_tile_of_class<2>(slot, tab, lane, hs, vs); break;
+        case 1: inv_tile_of_class<3>(slot, tab, lane, hs, vs); break;
+        case 2: inv_tile_of_class<4>(slot, tab, lane, hs, vs); break;
+        default: inv_tile_of_class<5>(slot, tab, lane, hs, vs); break;
+        }
+    } else {
+        switch (cls & 3) {
+        case 0: fwd_tile_of_class<2>(slot, tab, lane, hs, vs); break;
+        case 1: fwd_tile_of_class<3>(slot, tab, lane, hs, vs); break;
+        case 2: fwd_tile_of_class<4>(slot, tab, lane, hs, vs); break;
+        default: fwd_tile_of_class<5>(slot, tab, lane, hs, vs); break;
+        }
+    }
+}
+
+// A wave takes its tiles two at a time: both tiles' data, their class bytes and (once) the table are requested with the
+// wave's first instructions and parked in LDS as they arrive -- nothing is held in registers across a tile's passes.
+// LDS per wave: table 2 KiB, two tile slots of 2 KiB.
 template <bool INVERSE, bool NT>
 __global__ __launch_bounds__(256) void tr_tiles_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t n_tiles,
                                                        const uint32_t *__restrict__ tile_offsets,
-                                                       const uint8_t *__restrict__ tile_class, const TileOpsSoA *__restrict__ T,
-                                                       unsigned tiles_per_wave)
+                                                       const uint8_t *__restrict__ tile_class, const TileTab *__restrict__ T,
+                                                       unsigned tiles_per_wave, unsigned lds_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
-    unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+    unsigned char *tab = stage + (threadIdx.x >> 6) * lds_per_wave;
+    unsigned char *slot0 = tab + 2048, *slot1 = tab + 4096;
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     size_t t = wave * tiles_per_wave;
     const size_t t_end = t + tiles_per_wave < n_tiles ? t + tiles_per_wave : n_tiles;
     if (t >= t_end) return;
-    // prologue: first tile's class, position and data
     t = (size_t)__builtin_amdgcn_readfirstlane((int)(t & 0xFFFFFFFFu)) | (t & ~(size_t)0xFFFFFFFFu);   // provably wave-uniform
-    int cls = tile_class_of(tile_class, t);
-    size_t base = (tile_offsets ? (size_t)tile_offsets[t] : t * 1024) * 2;
-    v4i g0 = load16<NT>(reinterpret_cast<const char *>(in) + base + lane * 16);
-    v4i g1 = load16<NT>(reinterpret_cast<const char *>(in) + base + 1024 + lane * 16);
-    for (; t < t_end; ++t) {
-        const LaneConsts k = load_tile_consts(T, cls, lane);
-        v16i c2r;
-        if (INVERSE) {
-            const int *__restrict__ s0 = T->c2r[cls][0], *__restrict__ s1 = T->c2r[cls][1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c2r[r] = (lane >> 5) ? s1[r] : s0[r];
+    bool first = true;
+    for (; t < t_end; t += 2) {
+        const bool two = t + 1 < t_end;                                 // wave-uniform
+        const int cls0 = tile_class_of(tile_class, t), cls1 = tile_class_of(tile_class, two ? t + 1 : t);
+        const size_t base0 = (tile_offsets ? (size_t)tile_offsets[t] : t * 1024) * 2;
+        const size_t base1 = two ? (tile_offsets ? (size_t)tile_offsets[t + 1] : (t + 1) * 1024) * 2 : base0;
+        const v4i a0 = load16<NT>(reinterpret_cast<const char *>(in) + base0 + lane * 16);
+        const v4i a1 = load16<NT>(reinterpret_cast<const char *>(in) + base0 + 1024 + lane * 16);
+        if (first) {
+            const char *src = reinterpret_cast<const char *>(T->b) + lane * 16;
+            const v4i q0 = *reinterpret_cast<const v4i *>(src), q1 = *reinterpret_cast<const v4i *>(src + 1024);
+            *reinterpret_cast<v4i *>(tab + lane * 16) = q0;
+            *reinterpret_cast<v4i *>(tab + 1024 + lane * 16) = q1;
+            first = false;
         }
-        const int cur_cls = cls;
-        const size_t cur_base = base;
-        *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
-        *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
-        if (t + 1 < t_end) {                                            // next tile: loads in flight during this tile's passes
-            cls = tile_class_of(tile_class, t + 1);
-            base = (tile_offsets ? (size_t)tile_offsets[t + 1] : (t + 1) * 1024) * 2;
-            g0 = load16<NT>(reinterpret_cast<const char *>(in) + base + lane * 16);
-            g1 = load16<NT>(reinterpret_cast<const char *>(in) + base + 1024 + lane * 16);
+        if (two) {
+            const v4i b0 = load16<NT>(reinterpret_cast<const char *>(in) + base1 + lane * 16);
+            const v4i b1 = load16<NT>(reinterpret_cast<const char *>(in) + base1 + 1024 + lane * 16);
+            *reinterpret_cast<v4i *>(slot1 + lane * 16) = b0;
+            *reinterpret_cast<v4i *>(slot1 + 1024 + lane * 16) = b1;
+        }
+        *reinterpret_cast<v4i *>(slot0 + lane * 16) = a0;
+        *reinterpret_cast<v4i *>(slot0 + 1024 + lane * 16) = a1;
+        __builtin_amdgcn_wave_barrier();
+        tile_of_class<INVERSE>(slot0, tab, lane, cls0);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const v4i s0 = *reinterpret_cast<const v4i *>(slot0 + lane * 16);
+            const v4i s1 = *reinterpret_cast<const v4i *>(slot0 + 1024 + lane * 16);
+            char *dst = reinterpret_cast<char *>(out) + base0 + lane * 16;
+            store16m<NT ? 2 : 0>(dst, s0);
+            store16m<NT ? 2 : 0>(dst + 1024, s1);
+        }
+        if (two) {
+            tile_of_class<INVERSE>(slot1, tab, lane, cls1);
+            __builtin_amdgcn_wave_barrier();
+            const v4i s0 = *reinterpret_cast<const v4i *>(slot1 + lane * 16);
+            const v4i s1 = *reinterpret_cast<const v4i *>(slot1 + 1024 + lane * 16);
+            char *dst = reinterpret_cast<char *>(out) + base1 + lane * 16;
+            store16m<NT ? 2 : 0>(dst, s0);
+            store16m<NT ? 2 : 0>(dst + 1024, s1);
         }
         __builtin_amdgcn_wave_barrier();
-        if (INVERSE) {
-            switch (cur_cls & 3) {                                          // wave-uniform
-            case 0: inv_tile_in_slot<2>(slot, lane, k, c2r); break;
-            case 1: inv_tile_in_slot<3>(slot, lane, k, c2r); break;
-            case 2: inv_tile_in_slot<4>(slot, lane, k, c2r); break;
-            default: inv_tile_in_slot<5>(slot, lane, k, c2r); break;
-            }
-        } else {
-            switch (cur_cls & 3) {
-            case 0: fwd_tile_in_slot<2>(slot, lane, k); break;
-            case 1: fwd_tile_in_slot<3>(slot, lane, k); break;
-            case 2: fwd_tile_in_slot<4>(slot, lane, k); break;
-            default: fwd_tile_in_slot<5>(slot, lane, k); break;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
-        const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
-        __builtin_amdgcn_wave_barrier();
-        char *dst = reinterpret_cast<char *>(out) + cur_base + lane * 16;
-        store16m<NT ? 2 : 0>(dst, s0);
-        store16m<NT ? 2 : 0>(dst + 1024, s1);
     }
 }
 
@@ -475,7 +583,7 @@ hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d
 namespace x266 {
 
 hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles, const uint32_t *d_tile_offsets,
-                                  const uint8_t *d_tile_class, const TileOpsSoA *d_class_ops, const LaunchCfg &cfg, hipStream_t stream)
+                                  const uint8_t *d_tile_class, const TileTab *d_tab, const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
     const unsigned tpw = units_per_wave_for(cfg, n_tiles);
@@ -483,10 +591,11 @@ hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_
     const unsigned tpb = (unsigned)cfg.wg_threads;
     const size_t wpw = tpb / 64, wgs = (waves + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
+    const unsigned per_wave = (unsigned)(cfg.lds_bytes_per_wave < 6144 ? 6144 : (cfg.lds_bytes_per_wave + 15) & ~15);   // table + two tiles, then padding
+    const size_t lds = wpw * (size_t)per_wave;
     dim3 grid((unsigned)wgs), block(tpb);
     const bool nt = !d_tile_offsets && (cfg.nontemporal & 3);           // streaming hints only when the tiles are the whole buffer in order
-#define X266_TT(INV, NTV) hipLaunchKernelGGL((tr_tiles_kernel<INV, NTV>), grid, block, lds, stream, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, d_class_ops, tpw)
+#define X266_TT(INV, NTV) hipLaunchKernelGGL((tr_tiles_kernel<INV, NTV>), grid, block, lds, stream, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, d_tab, tpw, per_wave)
     if (inverse) { if (nt) X266_TT(true, true); else X266_TT(true, false); }
     else         { if (nt) X266_TT(false, true); else X266_TT(false, false); }
 #undef X266_TT

@@ -64,7 +64,7 @@ struct LaunchCfg {
 };
 
 struct DctOps;
-struct TileOpsSoA;
+struct TileTab;
 
 // Units (blocks, groups, tiles) one wave loops over: the configured count, reduced on small batches
 // until the launch has at least two full rounds of resident waves (about 40 per CU).
@@ -85,7 +85,7 @@ hipError_t launch_intra32_costs(const x266_intra_ref_t *d_refs, const uint8_t *d
                                 size_t n, hipStream_t stream);
 hipError_t launch_satd8x8_butterfly(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles, const uint32_t *d_tile_offsets,
-                                  const uint8_t *d_tile_class, const TileOpsSoA *d_class_ops, const LaunchCfg &cfg, hipStream_t stream);
+                                  const uint8_t *d_tile_class, const TileTab *d_tab, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_dct32_butterfly(const int16_t *d_in, int16_t *d_out, size_t n_blocks, hipStream_t stream);
 hipError_t launch_dct32_pass(const int16_t *d_in, int16_t *d_out, size_t n_blocks, int shift, const DctOps *d_fwd_ops, hipStream_t stream);
 hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,

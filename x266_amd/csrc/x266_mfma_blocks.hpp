@@ -164,9 +164,11 @@ __device__ __forceinline__ uint32_t sat_pack16(int lo, int hi)
     return __builtin_bit_cast(uint32_t, r);
 }
 
-// passes A and B on column data: zlo / zhi = byte planes of 16 samples of ONE COLUMN per lane
-__device__ __forceinline__ void inv_passes(const v4i &zlo, const v4i &zhi, const LaneConsts &k,
-                                           const v16i &c2r, v4i &o0, v4i &o1)
+// passes A and B on column data: zlo / zhi = byte planes of 16 samples of ONE COLUMN per lane.
+// c2r_group(g): the pass-B constants of accumulator registers 4g .. 4g+3 (fetched where they are used: four live, not sixteen)
+template <class C2RGroup>
+__device__ __forceinline__ void inv_passes_with(const v4i &zlo, const v4i &zhi, const LaneConsts &k,
+                                                C2RGroup c2r_group, v4i &o0, v4i &o1)
 {
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // pass A (columns): data = A, coefficients = B, per-lane constant
@@ -188,7 +190,11 @@ __device__ __forceinline__ void inv_passes(const v4i &zlo, const v4i &zhi, const
     // pass B (rows): coefficients = A, data = B, per-register constant
     acc = mfma(k.p2, thi2, zero);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)c2r[r]);
+    for (int g = 0; g < 4; ++g) {
+        const v4i c = c2r_group(g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * g + i] = (int)(((uint32_t)acc[4 * g + i] << 8) + (uint32_t)c[i]);
+    }
     acc = mfma(k.p2, tlo2, acc);
 
     uint32_t z[8];
@@ -196,6 +202,12 @@ __device__ __forceinline__ void inv_passes(const v4i &zlo, const v4i &zhi, const
     for (int m = 0; m < 8; ++m) z[m] = sat_pack16(acc[2 * m] >> 12, acc[2 * m + 1] >> 12);
     o0 = v4i{(int)z[0], (int)z[1], (int)z[2], (int)z[3]};
     o1 = v4i{(int)z[4], (int)z[5], (int)z[6], (int)z[7]};
+}
+
+__device__ __forceinline__ void inv_passes(const v4i &zlo, const v4i &zhi, const LaneConsts &k,
+                                           const v16i &c2r, v4i &o0, v4i &o1)
+{
+    inv_passes_with(zlo, zhi, k, [&](int g) { return v4i{c2r[4 * g], c2r[4 * g + 1], c2r[4 * g + 2], c2r[4 * g + 3]}; }, o0, o1);
 }
 
 }  // namespace x266

@@ -65,15 +65,16 @@ struct DctOps {
     int32_t    c2r[64][16];   // inverse pass-2 constants, per lane and accumulator reg
 };
 
-// Operand images of ALL sixteen tile classes for the mixed-class tile kernel (xTransformTilesDev), structure of
-// arrays: a wave's fetch of one class is three dense runs (1 KiB + 1 KiB + 512 B = 20 cache lines) instead of the
-// 64-byte-strided records above (128 line touches), and the seven classes of a VVC CTU (17.5 KiB) stay L1-resident.
-struct TileOpsSoA {
-    uint32_t p1[16][64][4];
-    uint32_t p2[16][64][4];
-    int32_t  c12[16][64][2];
-    int32_t  c2r[16][2][16];   // inverse: pass-B constants of lane half 0 / 1
-};
+// The 1-D matrices of the whole transform set in compact form, for the mixed-class tile kernel (xTransformTilesDev):
+// 2 KiB that every wave copies into LDS with its first two instructions, so that the operand images of a tile's class
+// are LDS reads behind the class byte instead of a second trip to memory (transform_kernels.hip).
+//   [0, 1024)      the 32-point matrix (DCT-II, g_t32), 32 x 32 int8, row k = basis function
+//   [1024, 1696)   slot 0 then slot 1, each: N = 4 (16 B), N = 8 (64 B), N = 16 (256 B), N x N int8 row-major
+//   [1696, 2048)   int32 128 * (row sum), same order: 32 + 2 x (4 + 8 + 16) values -- the byte-plane offset fix
+// The inverse kernels get the same table built from the TRANSPOSED matrices (their contractions run over the rows).
+struct TileTab { alignas(16) uint8_t b[2048]; };
+constexpr unsigned tile_tab_mat(unsigned slot, unsigned l) { return l == 3 ? 0u : 1024u + slot * 336u + (l == 0 ? 0u : (l == 1 ? 16u : 80u)); }
+constexpr unsigned tile_tab_sum(unsigned slot, unsigned l) { return l == 3 ? 1696u : 1824u + slot * 112u + (l == 0 ? 0u : (l == 1 ? 16u : 48u)); }
 
 inline uint32_t pack4(const int8_t *b)
 {
@@ -271,15 +272,30 @@ inline void build_inv_ops_general(DctOps &o, const Matrix32 &ma, const Matrix32 
     }
 }
 
-inline void tile_soa_set(TileOpsSoA &t, int cls, const DctOps &o)
+// slot_mat[slot][l]: the N x N matrices of the two 1-D transform slots, N = 4 << l (x266hip_abi.hip)
+inline void build_tile_tab(TileTab &t, const int8_t (*slot_mat)[3][256], bool transposed)
 {
-    for (int l = 0; l < 64; ++l) {
-        for (int q = 0; q < 4; ++q) { t.p1[cls][l][q] = o.lane[l].p1[q]; t.p2[cls][l][q] = o.lane[l].p2[q]; }
-        t.c12[cls][l][0] = o.lane[l].c1;
-        t.c12[cls][l][1] = o.lane[l].c2;
-    }
-    for (int h = 0; h < 2; ++h)
-        for (int r = 0; r < 16; ++r) t.c2r[cls][h][r] = o.c2r[32 * h][r];
+    constexpr Table32 g = make_table32();
+    std::memset(t.b, 0, sizeof t.b);
+    auto put = [&](unsigned mat_off, unsigned sum_off, int n, auto at) {
+        for (int k = 0; k < n; ++k) {
+            int sum = 0;
+            for (int c = 0; c < n; ++c) {
+                const int v = transposed ? at(c, k) : at(k, c);
+                t.b[mat_off + (unsigned)(k * n + c)] = static_cast<uint8_t>(static_cast<int8_t>(v));
+                sum += v;
+            }
+            const int32_t fix = 128 * sum;
+            std::memcpy(&t.b[sum_off + 4u * (unsigned)k], &fix, 4);
+        }
+    };
+    put(tile_tab_mat(0, 3), tile_tab_sum(0, 3), 32, [&](int k, int c) { return (int)g.v[k][c]; });
+    for (int slot = 0; slot < 2; ++slot)
+        for (int l = 0; l < 3; ++l) {
+            const int n = 4 << l;
+            const int8_t *m = slot_mat[slot][l];
+            put(tile_tab_mat((unsigned)slot, (unsigned)l), tile_tab_sum((unsigned)slot, (unsigned)l), n, [&](int k, int c) { return (int)m[k * n + c]; });
+        }
 }
 
 // transform type codes of the API: 0 DCT-II both ways, 1 DST-VII both ways, 2 horizontal DST-VII + vertical DCT-II,

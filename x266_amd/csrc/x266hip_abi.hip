@@ -29,12 +29,11 @@ struct x266hip_ctx {
     static constexpr int kTypes = 4;                // DCT-II, DST-VII, and the two mixed horizontal / vertical pairs
     DctOps *d_tr[kTypes][3] = {};                   // [type][log2N - 2], N = 4, 8, 16
     DctOps *d_tr_inv[kTypes][3] = {};
-    TileOpsSoA *d_tile_fwd = nullptr, *d_tile_inv = nullptr;   // all sixteen classes, structure of arrays (xTransformTilesDev)
-    TileOpsSoA *h_tile_fwd = nullptr, *h_tile_inv = nullptr;   // their host copies (xTransformSetMatrix rewrites single classes)
+    TileTab *d_tile_fwd = nullptr, *d_tile_inv = nullptr;      // the set's 1-D matrices in compact form, as is / transposed (xTransformTilesDev)
     // the two 1-D transform slots of the set, N = 4, 8, 16: slot 0 = DCT-II sub-matrices of g_t32, slot 1 = closed-form
     // DST-VII unless the caller installed its own (xTransformSetMatrix); row k = basis function, N x N, row-major
     int8_t slot_mat[2][3][256] = {};
-    int tile_lds_per_wave = 4096;                   // mixed-class tile kernel: LDS charged per wave (resident-wave cap)
+    int tile_lds_per_wave = 6144;                   // mixed-class tile kernel: LDS charged per wave (resident-wave cap)
     int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (next tile's loads issued before this tile's arithmetic)
     // options
     int nontemporal = 11;            // see LaunchCfg: nt loads + "sc1 nt" stores in the line-dense kernels (+3-5 %), none on fragment loads
@@ -237,21 +236,28 @@ Matrix32 block_diagonal(const int8_t *m, int n)
     return r;
 }
 
-// operand images of class (type, N = 4 << l) from the context's slot matrices: the two per-class tables (allocated on first
-// use) and the class's entries of the host copies of the structure-of-arrays tables (the caller uploads those)
+// operand images of class (type, N = 4 << l) from the context's slot matrices: the two per-class tables (allocated on first use)
 bool upload_class(x266hip_ctx *ctx, int type, int l, DctOps *h)
 {
     const int n = 4 << l;
     const Matrix32 mh = block_diagonal(ctx->slot_mat[transform_htype(type) == kTrDst7][l], n);
     const Matrix32 mv = block_diagonal(ctx->slot_mat[transform_vtype(type) == kTrDst7][l], n);
     build_fwd_ops_general(*h, mh, mv, transform_shift1(n), transform_shift2(n));
-    tile_soa_set(*ctx->h_tile_fwd, type * 4 + l, *h);
     if (!ctx->d_tr[type][l] && hipMalloc((void **)&ctx->d_tr[type][l], sizeof(DctOps)) != hipSuccess) return false;
     if (hipMemcpy(ctx->d_tr[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) != hipSuccess) return false;
     build_inv_ops_general(*h, mv, mh);
-    tile_soa_set(*ctx->h_tile_inv, type * 4 + l, *h);
     if (!ctx->d_tr_inv[type][l] && hipMalloc((void **)&ctx->d_tr_inv[type][l], sizeof(DctOps)) != hipSuccess) return false;
     return hipMemcpy(ctx->d_tr_inv[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+// the mixed-class tile kernel's compact tables from the context's slot matrices
+bool upload_tile_tabs(x266hip_ctx *ctx)
+{
+    TileTab t;
+    build_tile_tab(t, ctx->slot_mat, false);
+    if (hipMemcpy(ctx->d_tile_fwd, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess) return false;
+    build_tile_tab(t, ctx->slot_mat, true);
+    return hipMemcpy(ctx->d_tile_inv, &t, sizeof t, hipMemcpyHostToDevice) == hipSuccess;
 }
 
 }  // namespace
@@ -291,13 +297,11 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
         return X266HIP_EDEVICE;
     }
     DctOps *h = new (std::nothrow) DctOps;
-    TileOpsSoA *soa_f = new (std::nothrow) TileOpsSoA(), *soa_i = new (std::nothrow) TileOpsSoA();
-    bool ok = h != nullptr && soa_f != nullptr && soa_i != nullptr;
+    bool ok = h != nullptr;
     if (ok) ok = hipMalloc((void **)&ctx->d_fwd, sizeof(DctOps)) == hipSuccess &&
                  hipMalloc((void **)&ctx->d_inv, sizeof(DctOps)) == hipSuccess;
     if (ok) {
         build_fwd_ops(*h);
-        for (int type = 0; type < x266hip_ctx::kTypes; ++type) tile_soa_set(*soa_f, type * 4 + 3, *h);   // size 32 exists for DCT-II only; the other slots stay valid
         ok = hipMemcpy(ctx->d_fwd, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok) {
@@ -306,24 +310,19 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
     }
     if (ok) {
         build_inv_ops(*h, true);
-        for (int type = 0; type < x266hip_ctx::kTypes; ++type) tile_soa_set(*soa_i, type * 4 + 3, *h);
         ok = hipMalloc((void **)&ctx->d_inv_lds, sizeof(DctOps)) == hipSuccess &&
              hipMemcpy(ctx->d_inv_lds, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok) {
-        ctx->h_tile_fwd = soa_f;
-        ctx->h_tile_inv = soa_i;
         for (int slot = 0; slot < 2; ++slot)
             for (int l = 0; l < 3; ++l) default_slot_matrix(slot, 4 << l, ctx->slot_mat[slot][l]);
-        ok = hipMalloc((void **)&ctx->d_tile_fwd, sizeof(TileOpsSoA)) == hipSuccess &&
-             hipMalloc((void **)&ctx->d_tile_inv, sizeof(TileOpsSoA)) == hipSuccess;
+        ok = hipMalloc((void **)&ctx->d_tile_fwd, sizeof(TileTab)) == hipSuccess &&
+             hipMalloc((void **)&ctx->d_tile_inv, sizeof(TileTab)) == hipSuccess;
     }
     for (int type = 0; type < x266hip_ctx::kTypes && ok; ++type)
         for (int l = 0; l < 3 && ok; ++l) ok = upload_class(ctx, type, l, h);
-    if (ok) ok = hipMemcpy(ctx->d_tile_fwd, soa_f, sizeof(TileOpsSoA), hipMemcpyHostToDevice) == hipSuccess &&
-                 hipMemcpy(ctx->d_tile_inv, soa_i, sizeof(TileOpsSoA), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok = upload_tile_tabs(ctx);
     delete h;
-    if (!ctx->h_tile_fwd) { delete soa_f; delete soa_i; }
 
     if (!ok) {
         xHipCodecFree(ctx);
@@ -352,8 +351,6 @@ void xHipCodecFree(x266hip_ctx *ctx)
     for (void *q : ctx->me_retired) (void)hipFree(q);
     if (ctx->d_tile_fwd) (void)hipFree(ctx->d_tile_fwd);
     if (ctx->d_tile_inv) (void)hipFree(ctx->d_tile_inv);
-    delete ctx->h_tile_fwd;
-    delete ctx->h_tile_inv;
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
     if (ctx->d_inv) (void)hipFree(ctx->d_inv);
     if (ctx->d_inv_lds) (void)hipFree(ctx->d_inv_lds);
@@ -394,7 +391,7 @@ static const OptionDesc kOptions[] = {
     {"satd_groups_per_wave", &x266hip_ctx::satd_groups_per_wave, 1, 4096, 1},
     {"tr_tiles_per_wave", &x266hip_ctx::tr_tiles_per_wave, 1, 64, 1},
     {"tile_tiles_per_wave", &x266hip_ctx::tile_tiles_per_wave, 0, 64, 1},
-    {"tile_lds_bytes_per_wave", &x266hip_ctx::tile_lds_per_wave, 2048, 40960, 1},
+    {"tile_lds_bytes_per_wave", &x266hip_ctx::tile_lds_per_wave, 6144, 40960, 1},
     {"wg_threads", &x266hip_ctx::wg_threads, 64, 256, 64},
     {"satd_wg_threads", &x266hip_ctx::satd_wg_threads, 64, 256, 64},
     {"dct32_wg_threads", &x266hip_ctx::dct_wg_threads, 64, 256, 64},
@@ -587,8 +584,7 @@ int xTransformSetMatrix(x266hip_ctx *ctx, int slot, int size, const int8_t *m)
     for (int type = 0; type < x266hip_ctx::kTypes && ok; ++type)
         if ((transform_htype(type) == kTrDst7) == (slot == 1) || (transform_vtype(type) == kTrDst7) == (slot == 1)) ok = upload_class(ctx, type, l, h);
     delete h;
-    if (ok) ok = hipMemcpy(ctx->d_tile_fwd, ctx->h_tile_fwd, sizeof(TileOpsSoA), hipMemcpyHostToDevice) == hipSuccess &&
-                 hipMemcpy(ctx->d_tile_inv, ctx->h_tile_inv, sizeof(TileOpsSoA), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok = upload_tile_tabs(ctx);
     if (!ok) return fail(ctx, X266HIP_EDEVICE, "xTransformSetMatrix: table upload");
     return X266HIP_OK;
 }
@@ -610,7 +606,7 @@ int xTransformTilesDev(x266hip_ctx *ctx, int inverse, const int16_t *d_in, int16
     LaunchCfg cfg = cfg_for(ctx, inverse ? 1 : 0);
     cfg.wg_threads = inverse ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
     cfg.lds_bytes_per_wave = ctx->tile_lds_per_wave;                    // dependent fetches per tile (class, images, data): more waves in flight pay here
-    cfg.units_per_wave = ctx->tile_tiles_per_wave ? ctx->tile_tiles_per_wave : (inverse ? 2 : 1);   // measured optimum (profiles/r02_tiles_one_launch.txt)
+    cfg.units_per_wave = ctx->tile_tiles_per_wave ? ctx->tile_tiles_per_wave : 2;   // measured optimum (profiles/r03_tiles_one_launch.txt): the wave's table copy serves two tiles
     hipError_t e = launch_transform_tiles(inverse != 0, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class,
                                           inverse ? ctx->d_tile_inv : ctx->d_tile_fwd, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "tile transform launch", e);
