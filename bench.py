@@ -77,7 +77,68 @@ def parse_args():
                     help="seconds the node-layer legs (RCCL) may take before the JSON line is printed without them")
     ap.add_argument("--no-me", action="store_true", help="skip the motion-search legs")
     ap.add_argument("--no-transform-set", action="store_true", help="skip the transform-set / front-end / intra legs")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic (replay profiles/traffic.json instead)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # the profiled child of the live traffic passes
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------
+# roofline.traffic, live: HBM bytes of one headline launch from the PMC counters, collected as
+# MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes with --kernel-trace only
+# (never with sys / hip / hsa traces), units KB, FETCH_SIZE x2 on gfx950 (it counts the 128-byte requests of
+# 16 B-per-lane streaming reads as 64 B: the forward kernel reads exactly n * 2048 B and the counter reports half).
+# ------------------------------------------------------------------------------------------------
+def traffic_child(args):
+    """what the profiled passes run: the headline launch on the full batch, a few times, nothing else"""
+    import torch
+    import x266_amd
+    codec = x266_amd.Codec(0)
+    n = args.dct_blocks
+    x = torch.empty(n * 1024, dtype=torch.int16, device="cuda")
+    z = torch.empty_like(x)
+    stream = torch.cuda.current_stream().cuda_stream
+    codec.fill_residual_dev(x.data_ptr(), n * 1024, DCT_SEED, 0, stream)
+    for _ in range(6):
+        codec.dct32_fwd_dev(x.data_ptr(), z.data_ptr(), n, stream)
+    torch.cuda.synchronize()
+
+
+def measure_traffic_live(n_dct, budget_s=150.0):
+    """(bytes per headline launch, how it was measured) or (None, why not)"""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    t0 = time.time()
+    kb = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="x266_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            left = budget_s - (time.time() - t0)
+            if left < 20:
+                return None, "time budget of the live traffic passes exhausted"
+            subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
+                            os.path.abspath(__file__), "--traffic-child", "--dct-blocks", str(n_dct)],
+                           cwd="/tmp", env=env, timeout=left, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    name = r.get("Kernel_Name", "")
+                    if r.get("Counter_Name") == ctr and "dct32_lds_kernel<0" in name.replace(" ", "").replace("false", "0"):
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, "no %s rows for the forward kernel in rocprofv3's output" % ctr
+            kb[ctr] = sum(vals) / len(vals)
+        except Exception as e:                                            # a profiler that cannot run must not cost the bench line
+            return None, "rocprofv3 --pmc %s failed: %s" % (ctr, str(e)[:120])
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = kb["FETCH_SIZE"] * 1024.0 * 2.0 + kb["WRITE_SIZE"] * 1024.0
+    return total, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around %d launches "
+                   "of the headline kernel on this batch; KB x 1024, FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md); "
+                   "raw: FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB per launch; %.0f s" % (6, kb["FETCH_SIZE"], kb["WRITE_SIZE"], time.time() - t0))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -239,6 +300,9 @@ def cpu_baseline_dct(x_host, gpu_out_host):
 def main():
     args = parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.traffic_child:
+        traffic_child(args)
+        return
     # stdout carries exactly ONE line, the JSON: libraries that chat on stdout (RCCL prints a version banner
     # when a communicator is created) are sent to stderr for the duration of the run
     sys.stdout.flush()
@@ -373,6 +437,16 @@ def main():
             pmc_src = "replayed from %s (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command); not measured in this run" % pmc.get("_source", "profiles/traffic.json")
         except Exception:
             pmc = {}
+    if world == 1 and not args.no_live_traffic:
+        torch.cuda.synchronize()
+        live, how = measure_traffic_live(n_dct)
+        if live is not None:
+            pmc = dict(pmc, dct32_fwd_bytes_per_launch=live)
+            pmc_src = how
+        elif pmc_src:
+            pmc_src += " (live passes: %s)" % how
+        else:
+            pmc_src = "not measured: " + how
 
     result = {
         "metric": "dct32_fwd_blocks_per_s", "value": value, "unit": "blocks/s", "n_gpus": world,
