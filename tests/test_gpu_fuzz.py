@@ -187,3 +187,84 @@ def test_mixed_class_tiles_random(codec, oracle, n_tiles, seed, inverse, tpw, tp
         ttype, n = int(cls[t]) >> 2, (4, 8, 16, 32)[int(cls[t]) & 3]
         fn = oracle.transform_inv if inverse else oracle.transform_fwd
         assert np.array_equal(got[t], fn(ttype, n, x[t].reshape(-1, n * n)).ravel()), (t, ttype, n)
+
+
+@fuzz(25)
+@given(n=st.integers(1, 400), shift=st.integers(1, 15), kind=st.integers(0, 2), seed=st.integers(1, 1 << 30))
+def test_one_dimensional_pass_random(codec, oracle, n, shift, kind, seed):
+    """xDct32PassDev (round 3): random counts, every legal shift, three data mixes -- partialButterfly32 (src_tb/dct32.c:66-170)
+    block by block on a sample, and two passes at the reference's shifts = the 2-D transform on all of them."""
+    x = _data(kind, n, 1024, seed)
+    got = codec.dct32_pass(x, shift)
+    rs = np.random.RandomState(seed & 0xFFFF)
+    for b in sorted(set([0, n - 1] + [int(v) for v in rs.randint(0, n, 4)])):
+        assert np.array_equal(got[b], oracle.dct32_pass(x[b], shift)), (b, shift)
+    assert np.array_equal(codec.dct32_pass(codec.dct32_pass(x, 4), 11), oracle.dct32_fwd(x))
+
+
+@fuzz(25)
+@given(n_dct=st.integers(0, 700), n_satd=st.integers(0, 9000), kind=st.integers(0, 2), seed=st.integers(1, 1 << 30),
+       gpw=st.integers(1, 9), nt=st.sampled_from([0, 3, 11]))
+def test_frame_lanes_random(codec, oracle, n_dct, n_satd, kind, seed, gpw, nt):
+    """xDct32SatdFrameDev (round 3): both lanes of a frame in one grid, random and ragged counts on either side (zero included),
+    random SATD run length per wave -- equal to the oracle's two transforms."""
+    x, d = _data(kind, max(n_dct, 1), 1024, seed), _data(kind, max(n_satd, 1), 64, seed + 1)
+    saved = {k: codec.get_option(k) for k in ("satd_groups_per_wave", "nontemporal")}
+    try:
+        codec.set_option("satd_groups_per_wave", gpw)
+        codec.set_option("nontemporal", nt)
+        din, dout = codec.alloc(x.nbytes), codec.alloc(x.nbytes)
+        sin, sout = codec.alloc(d.nbytes), codec.alloc(max(n_satd, 4) * 4)
+        din.upload(x)
+        sin.upload(d)
+        codec.frame_lanes_dev(din.ptr, dout.ptr, n_dct, sin.ptr, sout.ptr, n_satd)
+        codec.stream_sync()
+        got_d = dout.download(np.int16, max(n_dct, 1) * 1024).reshape(-1, 1024)[:n_dct]
+        got_s = sout.download(np.uint32, max(n_satd, 1))[:n_satd]
+    finally:
+        for k, v in saved.items():
+            codec.set_option(k, v)
+    if n_dct:
+        assert np.array_equal(got_d, oracle.dct32_fwd(x[:n_dct]))
+    if n_satd:
+        assert np.array_equal(got_s, oracle.satd8x8(d[:n_satd]))
+
+
+@fuzz(15)
+@given(slot=st.integers(0, 1), size=st.sampled_from([4, 8, 16]), n_tiles=st.integers(1, 120), seed=st.integers(1, 1 << 20),
+       inverse=st.integers(0, 1), extreme=st.booleans())
+def test_installed_matrices_through_the_tile_launch(oracle, slot, size, n_tiles, seed, inverse, extreme):
+    """xTransformSetMatrix + xTransformTilesDev (round 3: the tile kernel builds its operand images from the compact matrix
+    table in LDS): a random int8 matrix in one slot, tiles of all four type codes at that size mixed with DCT-II 32 tiles --
+    every tile equal to the oracle's generic-matrix transform with the slot's matrices."""
+    cd = x266_amd.Codec(0)                                              # own context: the installed matrix must not leak into other tests
+    rs = np.random.RandomState(seed)
+    m = rs.randint(-128, 128, (size, size)).astype(np.int8)
+    if extreme:
+        m[rs.randint(0, size), :] = 127
+        m[:, rs.randint(0, size)] = -128
+    cd.set_transform_matrix(slot, size, m)
+    mats = [cd.get_transform_matrix(s, size) for s in (0, 1)]
+    l = {4: 0, 8: 1, 16: 2}[size]
+    types = rs.randint(0, 4, n_tiles)
+    cls = (types * 4 + l).astype(np.uint8)
+    big = rs.rand(n_tiles) < 0.2
+    cls[big] = 3
+    x = _data(1 if extreme else 0, n_tiles, 1024, seed)
+    if inverse:
+        x = (x >> 3).astype(np.int16)
+    din, dout, dcls = cd.alloc(n_tiles * 2048), cd.alloc(n_tiles * 2048), cd.alloc(max(n_tiles, 16))
+    din.upload(x)
+    dcls.upload(cls)
+    cd.transform_tiles_dev(inverse, din.ptr, dout.ptr, n_tiles, 0, dcls.ptr)
+    cd.stream_sync()
+    got = dout.download(np.int16, n_tiles * 1024).reshape(n_tiles, 1024)
+    for t in range(n_tiles):
+        if big[t]:
+            want = (oracle.dct32_inv if inverse else oracle.dct32_fwd)(x[t:t + 1])
+        else:
+            ty = int(types[t])
+            mh, mv = mats[1 if ty in (1, 2) else 0], mats[1 if ty in (1, 3) else 0]
+            want = oracle.transform_matrix_passes(mh, mv, x[t].reshape(-1, size * size), inverse=bool(inverse))
+        assert np.array_equal(got[t], np.asarray(want).ravel()), (t, int(cls[t]))
+    cd.close()
