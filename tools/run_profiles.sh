@@ -19,4 +19,4 @@ python bench.py --steps 20 --warmup 5 | tail -1 > gpurun_out/bench_${T}_${S}_dri
 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -2 > gpurun_out/pytest_gpu.log
 cat gpurun_out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-./host/stream8k 0 500 > gpurun_out/stream8k_${T}_$S.json 2>/dev/null; cat gpurun_out/stream8k_${T}_$S.json
+./host/stream8k 0 500 | tail -1 > gpurun_out/stream8k_${T}_$S.json 2>/dev/null; cat gpurun_out/stream8k_${T}_$S.json
