@@ -110,6 +110,9 @@ def measure_traffic_live(n_dct, budget_s=150.0):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    # already running under a profiler (someone profiles this bench run): do not nest a second one
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself being profiled (ROCPROF* / ROCP_* in the environment)"
     t0 = time.time()
     kb = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -6,7 +6,7 @@ T=${1:-r03}
 S=${2:-x}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-live-traffic"
+B="python $R/bench.py --no-cpu-baseline --no-live-traffic"   # (bench.py also refuses to nest a profiler on its own)
 # --stream8k 0: the node legs launch the same kernels on frame-sized batches, which would mix sizes into the per-kernel averages
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$S -- $B --stream8k 0 > $R/gpurun_out/prof_$S.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$S -- $B --no-me --no-transform-set --stream8k 0 --steps 5 --warmup 2 > /dev/null 2>&1
