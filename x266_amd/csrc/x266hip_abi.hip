@@ -33,7 +33,7 @@ struct x266hip_ctx {
     // the two 1-D transform slots of the set, N = 4, 8, 16: slot 0 = DCT-II sub-matrices of g_t32, slot 1 = closed-form
     // DST-VII unless the caller installed its own (xTransformSetMatrix); row k = basis function, N x N, row-major
     int8_t slot_mat[2][3][256] = {};
-    int tile_lds_per_wave = 6144;                   // mixed-class tile kernel: LDS charged per wave (resident-wave cap)
+    int tile_lds_per_wave = 8192;                   // mixed-class tile kernel: LDS charged per wave (resident-wave cap)
     int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (next tile's loads issued before this tile's arithmetic)
     // options
     int nontemporal = 11;            // see LaunchCfg: nt loads + "sc1 nt" stores in the line-dense kernels (+3-5 %), none on fragment loads
