@@ -35,10 +35,10 @@ struct TileRow {
     bool unit_live;   // the wave's (tile row, group, half) exists: false for the whole wave at once
 };
 
-__device__ __forceinline__ TileRow tile_row_of_thread(int tiles_x, int groups_x, size_t n_units)
+// A wave takes K consecutive units (template parameter), all of their loads issued before the first store.
+
+__device__ __forceinline__ TileRow tile_row_of_unit(size_t unit, int lane, int tiles_x, int groups_x, size_t n_units)
 {
-    const size_t unit = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // (ty, group, half)
-    const int lane = threadIdx.x & 63;
     TileRow r;
     r.unit_live = unit < n_units;
     r.live = r.unit_live;
@@ -55,107 +55,150 @@ __device__ __forceinline__ TileRow tile_row_of_thread(int tiles_x, int groups_x,
 }
 
 // PACK: planar -> tiles, else tiles -> planar
-template <bool PACK>
+template <bool PACK, int kUnitsPerWave>
 __global__ __launch_bounds__(256) void tile_convert_kernel(x266_ref_block_t *tiles, uint8_t *y, uint8_t *u, uint8_t *v,
                                                            long long strd_y, long long strd_c, int tiles_x, int groups_x,
                                                            size_t n_units)
 {
-    const TileRow r = tile_row_of_thread(tiles_x, groups_x, n_units);
-    if (!r.live) return;
-    const int i = r.i;
-    uint8_t *t = reinterpret_cast<uint8_t *>(tiles + r.tile);
-    uint8_t *py = y + (long long)(r.ty * 16 + i) * strd_y + r.tx * 16;
-    if (PACK) store16_sc1nt(t + i * 16, load16<true>(py));
-    else      store16_sc1nt(py, load16<true>(t + i * 16));
-    if (i < 8) {
-        uint8_t *pu = u + (long long)(r.ty * 8 + i) * strd_c + r.tx * 8;
-        uint8_t *pv = v + (long long)(r.ty * 8 + i) * strd_c + r.tx * 8;
-        uint32_t *c = reinterpret_cast<uint32_t *>(t + 256 + i * 16);
-        if (PACK) {
-            const uint2 a = *reinterpret_cast<const uint2 *>(pu), b = *reinterpret_cast<const uint2 *>(pv);
-            const v4i o = {(int)bperm(b.x, a.x, 0x05010400u),      // u0 v0 u1 v1
-                           (int)bperm(b.x, a.x, 0x07030602u),      // u2 v2 u3 v3
-                           (int)bperm(b.y, a.y, 0x05010400u), (int)bperm(b.y, a.y, 0x07030602u)};
-            store16_sc1nt(c, o);
-        } else {
-            const v4i cc = load16<true>(c);
-            const uint32_t c0 = (uint32_t)cc[0], c1 = (uint32_t)cc[1], c2 = (uint32_t)cc[2], c3 = (uint32_t)cc[3];
-            *reinterpret_cast<uint2 *>(pu) = make_uint2(bperm(c1, c0, 0x06040200u), bperm(c3, c2, 0x06040200u));
-            *reinterpret_cast<uint2 *>(pv) = make_uint2(bperm(c1, c0, 0x07050301u), bperm(c3, c2, 0x07050301u));
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    TileRow r[kUnitsPerWave];
+    v4i luma[kUnitsPerWave], cc[kUnitsPerWave];
+    uint2 ua[kUnitsPerWave], ub[kUnitsPerWave];
+#pragma unroll
+    for (int k = 0; k < kUnitsPerWave; ++k) {
+        r[k] = tile_row_of_unit(wave * kUnitsPerWave + k, lane, tiles_x, groups_x, n_units);
+        luma[k] = cc[k] = v4i{0, 0, 0, 0};
+        ua[k] = ub[k] = make_uint2(0, 0);
+        if (!r[k].live) continue;
+        const int i = r[k].i;
+        uint8_t *t = reinterpret_cast<uint8_t *>(tiles + r[k].tile);
+        uint8_t *py = y + (long long)(r[k].ty * 16 + i) * strd_y + r[k].tx * 16;
+        luma[k] = PACK ? load16<true>(py) : load16<true>(t + i * 16);
+        if (i < 8) {
+            if (PACK) {
+                ua[k] = *reinterpret_cast<const uint2 *>(u + (long long)(r[k].ty * 8 + i) * strd_c + r[k].tx * 8);
+                ub[k] = *reinterpret_cast<const uint2 *>(v + (long long)(r[k].ty * 8 + i) * strd_c + r[k].tx * 8);
+            } else {
+                cc[k] = load16<true>(t + 256 + i * 16);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kUnitsPerWave; ++k) {
+        if (!r[k].live) continue;
+        const int i = r[k].i;
+        uint8_t *t = reinterpret_cast<uint8_t *>(tiles + r[k].tile);
+        uint8_t *py = y + (long long)(r[k].ty * 16 + i) * strd_y + r[k].tx * 16;
+        if (PACK) store16_sc1nt(t + i * 16, luma[k]);
+        else      store16_sc1nt(py, luma[k]);
+        if (i < 8) {
+            uint8_t *pu = u + (long long)(r[k].ty * 8 + i) * strd_c + r[k].tx * 8;
+            uint8_t *pv = v + (long long)(r[k].ty * 8 + i) * strd_c + r[k].tx * 8;
+            uint32_t *c = reinterpret_cast<uint32_t *>(t + 256 + i * 16);
+            if (PACK) {
+                const uint2 a = ua[k], b = ub[k];
+                const v4i o = {(int)bperm(b.x, a.x, 0x05010400u),      // u0 v0 u1 v1
+                               (int)bperm(b.x, a.x, 0x07030602u),      // u2 v2 u3 v3
+                               (int)bperm(b.y, a.y, 0x05010400u), (int)bperm(b.y, a.y, 0x07030602u)};
+                store16_sc1nt(c, o);
+            } else {
+                const uint32_t c0 = (uint32_t)cc[k][0], c1 = (uint32_t)cc[k][1], c2 = (uint32_t)cc[k][2], c3 = (uint32_t)cc[k][3];
+                *reinterpret_cast<uint2 *>(pu) = make_uint2(bperm(c1, c0, 0x06040200u), bperm(c3, c2, 0x06040200u));
+                *reinterpret_cast<uint2 *>(pv) = make_uint2(bperm(c1, c0, 0x07050301u), bperm(c3, c2, 0x07050301u));
+            }
         }
     }
 }
 
 // residual[block][r][c] = cur - pred on tile luma; one thread per 16-pixel row segment.
 // LOGB = log2(block edge): 3 (8x8, the SATD blocks) or 5 (32x32, the DCT blocks)
-template <int LOGB>
+template <int LOGB, int kUnitsPerWave>
 __global__ __launch_bounds__(256) void residual_luma_kernel(const x266_ref_block_t *__restrict__ cur,
                                                             const x266_ref_block_t *__restrict__ pred,
                                                             int16_t *__restrict__ res, int tiles_x, int groups_x, size_t n_units)
 {
     constexpr int B = 1 << LOGB;
-    const TileRow r = tile_row_of_thread(tiles_x, groups_x, n_units);
-    // B = 32 stores cooperatively: lanes whose tile lies beyond the frame edge (clamped to the last tile, so
-    // their loads are valid) stay in the wave; their runs are skipped at the store
-    if (B == 32 ? !r.unit_live : !r.live) return;
-    const int i = r.i;
-    const size_t ty = r.ty, tx = r.tx;
-    const v4i a = load16<true>(reinterpret_cast<const uint8_t *>(cur + r.tile) + i * 16);
-    const v4i b = load16<true>(reinterpret_cast<const uint8_t *>(pred + r.tile) + i * 16);
-    uint32_t d[8];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[B == 32 ? 4 * 2048 : 16];
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    TileRow r[kUnitsPerWave];
+    v4i a[kUnitsPerWave], b[kUnitsPerWave];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t x = (uint32_t)a[k], z = (uint32_t)b[k];
-        const int d0 = (int)(x & 255) - (int)(z & 255), d1 = (int)((x >> 8) & 255) - (int)((z >> 8) & 255);
-        const int d2 = (int)((x >> 16) & 255) - (int)((z >> 16) & 255), d3 = (int)(x >> 24) - (int)(z >> 24);
-        d[2 * k] = ((uint32_t)d0 & 0xFFFFu) | ((uint32_t)d1 << 16);
-        d[2 * k + 1] = ((uint32_t)d2 & 0xFFFFu) | ((uint32_t)d3 << 16);
+    for (int k = 0; k < kUnitsPerWave; ++k) {
+        r[k] = tile_row_of_unit(wave * kUnitsPerWave + k, lane, tiles_x, groups_x, n_units);
+        a[k] = b[k] = v4i{0, 0, 0, 0};
+        // B = 32 stores cooperatively: lanes whose tile lies beyond the frame edge (clamped to the last tile, so
+        // their loads are valid) stay in the unit; their runs are skipped at the store
+        if (B == 32 ? !r[k].unit_live : !r[k].live) continue;
+        a[k] = load16<true>(reinterpret_cast<const uint8_t *>(cur + r[k].tile) + r[k].i * 16);
+        b[k] = load16<true>(reinterpret_cast<const uint8_t *>(pred + r[k].tile) + r[k].i * 16);
     }
-    const size_t py = ty * 16 + i, px = tx * 16;                           // pixel coordinates of this segment
     const size_t width = (size_t)tiles_x * 16;
-    if (B == 32) {
-        // A wave's 2 KiB of residual are four 512-byte runs (8 rows x 64 bytes of four 32x32 blocks), but a
-        // lane's 32 bytes are only a quarter line: written straight, every store instruction would touch half
-        // of each line.  Through a wave-private 2 KiB LDS slot the wave stores its runs with two 1 KiB-linear
-        // instructions instead.
-        __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 2048];
-        unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
-        const int lane = threadIdx.x & 63, t = lane & 7, rr = lane >> 3;
-        unsigned char *mine = slot + (t >> 1) * 512 + rr * 64 + (t & 1) * 32;
-        *reinterpret_cast<v4i *>(mine) = v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
-        *reinterpret_cast<v4i *>(mine + 16) = v4i{(int)d[4], (int)d[5], (int)d[6], (int)d[7]};
-        __builtin_amdgcn_wave_barrier();
-        const size_t tx0 = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 7) % (size_t)groups_x * 8;   // first tile of the wave's group
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = lane + 64 * j, run = c >> 5;                      // 16-byte chunk of the 2 KiB, its 512-byte run
-            const size_t bx = (tx0 >> 1) + run;                             // block column of that run
-            if (bx * 2 < (size_t)tiles_x) {
-                const size_t blk = (py >> 5) * (width >> 5) + bx;
-                char *dst = reinterpret_cast<char *>(res + blk * 1024 + ((py & 31) & ~7) * 32) + (c & 31) * 16;
-                store16_sc1nt(dst, *reinterpret_cast<const v4i *>(slot + c * 16));
-            }
+    for (int k = 0; k < kUnitsPerWave; ++k) {
+        if (B == 32 ? !r[k].unit_live : !r[k].live) continue;                // B = 32: wave-uniform
+        uint32_t d[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t x = (uint32_t)a[k][q], z = (uint32_t)b[k][q];
+            const int d0 = (int)(x & 255) - (int)(z & 255), d1 = (int)((x >> 8) & 255) - (int)((z >> 8) & 255);
+            const int d2 = (int)((x >> 16) & 255) - (int)((z >> 16) & 255), d3 = (int)(x >> 24) - (int)(z >> 24);
+            d[2 * q] = ((uint32_t)d0 & 0xFFFFu) | ((uint32_t)d1 << 16);
+            d[2 * q + 1] = ((uint32_t)d2 & 0xFFFFu) | ((uint32_t)d3 << 16);
         }
-    } else {                                                               // two 8x8 blocks side by side
-        const size_t blk = (py >> 3) * (width >> 3) + (px >> 3);
-        int16_t *dst = res + blk * 64 + (py & 7) * 8;
-        store16_sc1nt(dst, v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]});
-        store16_sc1nt(dst + 64, v4i{(int)d[4], (int)d[5], (int)d[6], (int)d[7]});
+        const size_t py = r[k].ty * 16 + r[k].i, px = r[k].tx * 16;         // pixel coordinates of this segment
+        if (B == 32) {
+            // A unit's 2 KiB of residual are four 512-byte runs (8 rows x 64 bytes of four 32x32 blocks), but a
+            // lane's 32 bytes are only a quarter line: written straight, every store instruction would touch half
+            // of each line.  Through a wave-private 2 KiB LDS slot the wave stores its runs with two 1 KiB-linear
+            // instructions instead.
+            unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+            const int t = lane & 7, rr = lane >> 3;
+            unsigned char *mine = slot + (t >> 1) * 512 + rr * 64 + (t & 1) * 32;
+            *reinterpret_cast<v4i *>(mine) = v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
+            *reinterpret_cast<v4i *>(mine + 16) = v4i{(int)d[4], (int)d[5], (int)d[6], (int)d[7]};
+            __builtin_amdgcn_wave_barrier();
+            const size_t unit = wave * kUnitsPerWave + k;
+            const size_t tx0 = (unit >> 1) % (size_t)groups_x * 8;          // first tile of the unit's group
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = lane + 64 * j, run = c >> 5;                  // 16-byte chunk of the 2 KiB, its 512-byte run
+                const size_t bx = (tx0 >> 1) + run;                         // block column of that run
+                if (bx * 2 < (size_t)tiles_x) {
+                    const size_t blk = (py >> 5) * (width >> 5) + bx;
+                    char *dst = reinterpret_cast<char *>(res + blk * 1024 + ((py & 31) & ~7) * 32) + (c & 31) * 16;
+                    store16_sc1nt(dst, *reinterpret_cast<const v4i *>(slot + c * 16));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                                // the slot is reused by the next unit
+        } else {                                                           // two 8x8 blocks side by side
+            const size_t blk = (py >> 3) * (width >> 3) + (px >> 3);
+            int16_t *dst = res + blk * 64 + (py & 7) * 8;
+            store16_sc1nt(dst, v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]});
+            store16_sc1nt(dst + 64, v4i{(int)d[4], (int)d[5], (int)d[6], (int)d[7]});
+        }
     }
 }
 
 }  // namespace
 
+// Units per wave, measured (tools/gpu_tilefmt_probe.py, 32768^2 frame): unpacking gains 13 % from two units per wave (its planar
+// stores are half lines per instruction; more of them in flight per wave), packing and the residual kernels lose 3-10 %.
+constexpr int kUnitsPack = 1, kUnitsUnpack = 2, kUnitsResidual = 1;
+
 hipError_t launch_tile_convert(bool pack, x266_ref_block_t *d_tiles, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
                                long long strd_y, long long strd_c, int width, int height, hipStream_t stream)
 {
     const int tiles_x = width / 16, groups_x = (tiles_x + 7) / 8;
-    const size_t n_units = (size_t)groups_x * (height / 16) * 2;           // one wave per (tile row, 8 tiles, half)
+    const size_t n_units = (size_t)groups_x * (height / 16) * 2;           // unit = (tile row, 8 tiles, half)
     if (n_units == 0) return hipSuccess;
-    if ((n_units + 3) / 4 > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    dim3 grid((unsigned)((n_units + 3) / 4)), block(256);
-    if (pack) hipLaunchKernelGGL((tile_convert_kernel<true>), grid, block, 0, stream, d_tiles, d_y, d_u, d_v, strd_y, strd_c, tiles_x, groups_x, n_units);
-    else      hipLaunchKernelGGL((tile_convert_kernel<false>), grid, block, 0, stream, d_tiles, d_y, d_u, d_v, strd_y, strd_c, tiles_x, groups_x, n_units);
+    const size_t K = pack ? kUnitsPack : kUnitsUnpack;
+    const size_t n_waves = (n_units + K - 1) / K;
+    if ((n_waves + 3) / 4 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
+    if (pack) hipLaunchKernelGGL((tile_convert_kernel<true, kUnitsPack>), grid, block, 0, stream, d_tiles, d_y, d_u, d_v, strd_y, strd_c, tiles_x, groups_x, n_units);
+    else      hipLaunchKernelGGL((tile_convert_kernel<false, kUnitsUnpack>), grid, block, 0, stream, d_tiles, d_y, d_u, d_v, strd_y, strd_c, tiles_x, groups_x, n_units);
     return hipGetLastError();
 }
 
@@ -165,10 +208,11 @@ hipError_t launch_residual_luma(int block_edge, const x266_ref_block_t *d_cur, c
     const int tiles_x = width / 16, groups_x = (tiles_x + 7) / 8;
     const size_t n_units = (size_t)groups_x * (height / 16) * 2;
     if (n_units == 0) return hipSuccess;
-    if ((n_units + 3) / 4 > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    dim3 grid((unsigned)((n_units + 3) / 4)), block(256);
-    if (block_edge == 32) hipLaunchKernelGGL((residual_luma_kernel<5>), grid, block, 0, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
-    else                  hipLaunchKernelGGL((residual_luma_kernel<3>), grid, block, 0, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
+    const size_t n_waves = (n_units + kUnitsResidual - 1) / kUnitsResidual;
+    if ((n_waves + 3) / 4 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
+    if (block_edge == 32) hipLaunchKernelGGL((residual_luma_kernel<5, kUnitsResidual>), grid, block, 0, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
+    else                  hipLaunchKernelGGL((residual_luma_kernel<3, kUnitsResidual>), grid, block, 0, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
     return hipGetLastError();
 }
 
