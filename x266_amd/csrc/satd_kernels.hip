@@ -228,18 +228,12 @@ __global__ __launch_bounds__(128) void frame_lanes_kernel(const int16_t *__restr
 template <bool STAGED>
 __global__ __launch_bounds__(256) void satd8x8_from_tiles_kernel(const x266_ref_block_t *__restrict__ cur,
                                                                  const x266_ref_block_t *__restrict__ pred,
-                                                                 uint32_t *__restrict__ out, int tiles_x, size_t n_tiles,
-                                                                 unsigned groups_per_wave)
+                                                                 uint32_t *__restrict__ out, int tiles_x, size_t n_tiles)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // STAGED: 4 KiB per wave
-    const size_t first_group = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * groups_per_wave;
-  for (size_t group = first_group; group < first_group + groups_per_wave && group * 8 < n_tiles; ++group) {
-    // Everything that depends on the lane -- fragment offsets, the +-1 operand images (~25 VALU) -- is rebuilt per group from a lane
-    // id the compiler cannot see through: hoisted out of the loop it takes the kernel from 62 to 92 VGPRs (five waves per SIMD, not eight)
-    int lane = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane));
-    const int n = lane & 31, half = lane >> 5;
-    const SatdOperands H = make_satd_operands(lane);
+    const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+    const size_t group = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (group * 8 >= n_tiles) return;
     size_t tile = group * 8 + (n >> 2);
     const bool live = tile < n_tiles;
     if (!live) tile = n_tiles - 1;
@@ -279,6 +273,7 @@ __global__ __launch_bounds__(256) void satd8x8_from_tiles_kernel(const x266_ref_
             b[r] = *reinterpret_cast<const uint2 *>(pb + r * 16);
         }
     }
+    const SatdOperands H = make_satd_operands(lane);
     const uint32_t S = 0x80808080u;                                     // pixels -> signed (offset cancels)
     const v4i a0 = {(int)(a[0].x ^ S), (int)(a[0].y ^ S), (int)(a[1].x ^ S), (int)(a[1].y ^ S)};
     const v4i a1 = {(int)(a[2].x ^ S), (int)(a[2].y ^ S), (int)(a[3].x ^ S), (int)(a[3].y ^ S)};
@@ -305,8 +300,6 @@ __global__ __launch_bounds__(256) void satd8x8_from_tiles_kernel(const x266_ref_
         const size_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
         out[(ty * 2 + sub_y) * (size_t)(tiles_x * 2) + tx * 2 + sub_x] = (sum + 2) >> 2;
     }
-    if (STAGED) __builtin_amdgcn_wave_barrier();                         // the slot is reused by the wave's next group
-  }
 }
 
 // ---- synthetic residual stream ---------------------------------------------
@@ -390,10 +383,8 @@ hipError_t launch_satd8x8_from_tiles(const x266_ref_block_t *d_cur, const x266_r
     if (n_tiles == 0) return hipSuccess;
     const size_t groups = (n_tiles + 7) / 8;                            // one wave per 8 tiles, one-wave workgroups
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const unsigned gpw = 2;                                             // two groups per wave (+20 % over one together with the loop-local lane state: tools/gpu_fused_probe.py)
-    const size_t waves = (groups + gpw - 1) / gpw;
-    if (cfg.lds_stage) hipLaunchKernelGGL((satd8x8_from_tiles_kernel<true>), dim3((unsigned)waves), dim3(64), (size_t)(cfg.lds_bytes_per_wave < 4096 ? 4096 : cfg.lds_bytes_per_wave), stream, d_cur, d_pred, d_out, tiles_x, n_tiles, gpw);
-    else               hipLaunchKernelGGL((satd8x8_from_tiles_kernel<false>), dim3((unsigned)waves), dim3(64), 0, stream, d_cur, d_pred, d_out, tiles_x, n_tiles, gpw);
+    if (cfg.lds_stage) hipLaunchKernelGGL((satd8x8_from_tiles_kernel<true>), dim3((unsigned)groups), dim3(64), (size_t)(cfg.lds_bytes_per_wave < 4096 ? 4096 : cfg.lds_bytes_per_wave), stream, d_cur, d_pred, d_out, tiles_x, n_tiles);
+    else               hipLaunchKernelGGL((satd8x8_from_tiles_kernel<false>), dim3((unsigned)groups), dim3(64), 0, stream, d_cur, d_pred, d_out, tiles_x, n_tiles);
     return hipGetLastError();
 }
 
