@@ -26,51 +26,33 @@ __device__ __forceinline__ uint32_t sad_chunk(const v4i &a, const v4i &b, uint32
 }
 
 // LOGC = log2(16-byte chunks per block): 0 (4x4), 2 (8x8), 4 (16x16), 6 (32x32), 8 (64x64)
-// A wave moves 4 KiB of each input whatever the block size (round 3; 1 KiB before for blocks up to 32x32: a wave that ends after two
-// loads costs more to start than to run -- 64x64, whose wave already took 4 KiB, was the fast one): kSadSteps wave-wide 1 KiB loads per
-// input, all issued before the first v_sad_u8.
-constexpr int kSadSteps = 4;
 template <int LOGC>
 __global__ __launch_bounds__(256) void sad_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
                                                   uint32_t *__restrict__ out, size_t n_blocks)
 {
     constexpr int CPB = 1 << LOGC;                          // chunks per block
-    constexpr int BPS = CPB > 64 ? 1 : 64 / CPB;            // blocks per wave-wide load
-    constexpr int SPB = CPB > 64 ? CPB / 64 : 1;            // wave-wide loads per block (64x64: 4)
-    constexpr int BPW = BPS * kSadSteps / SPB;              // blocks per wave
+    constexpr int ITER = CPB > 64 ? CPB / 64 : 1;           // wave-instructions per block (64x64: 4)
+    constexpr int BPW = CPB > 64 ? 1 : 64 / CPB;            // blocks per wave step
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t first = wave * BPW;                        // first block of this wave
     if (first >= n_blocks) return;
     const size_t total = n_blocks * (size_t)CPB * 16;
-    v4i va[kSadSteps], vb[kSadSteps];
-    bool live[kSadSteps];
+    uint32_t s = 0;
 #pragma unroll
-    for (int it = 0; it < kSadSteps; ++it) {
+    for (int it = 0; it < ITER; ++it) {
         size_t off = (first * CPB + (size_t)it * 64 + lane) * 16;
-        live[it] = off + 16 <= total;
-        if (!live[it]) off = total - 16;                    // ragged tail
-        va[it] = load16<true>(a + off);                     // line-dense, read once: streaming hint
-        vb[it] = load16<true>(b + off);
+        const bool live = off + 16 <= total;
+        if (!live) off = total - 16;                        // ragged tail
+        const v4i va = load16<true>(a + off), vb = load16<true>(b + off);      // line-dense, read once: streaming hint
+        const uint32_t part = sad_chunk(va, vb, 0);
+        s += live ? part : 0u;
     }
     constexpr int SPAN = CPB > 64 ? 64 : CPB;               // lanes that share a block
-    if (SPB > 1) {                                          // one block per wave: the steps add up
-        uint32_t s = 0;
 #pragma unroll
-        for (int it = 0; it < kSadSteps; ++it) s += live[it] ? sad_chunk(va[it], vb[it], 0) : 0u;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += (uint32_t)__shfl_xor((int)s, m);
-        if (lane == 0) out[first] = s;
-    } else {
-#pragma unroll
-        for (int it = 0; it < kSadSteps; ++it) {
-            uint32_t s = live[it] ? sad_chunk(va[it], vb[it], 0) : 0u;
-#pragma unroll
-            for (int m = SPAN >> 1; m >= 1; m >>= 1) s += (uint32_t)__shfl_xor((int)s, m);
-            const size_t blk = first + (size_t)it * BPS + (SPAN == 64 ? 0 : lane / SPAN);
-            if ((lane & (SPAN - 1)) == 0 && blk < n_blocks) out[blk] = s;
-        }
-    }
+    for (int m = SPAN >> 1; m >= 1; m >>= 1) s += (uint32_t)__shfl_xor((int)s, m);
+    const size_t blk = first + (SPAN == 64 ? 0 : lane / SPAN);
+    if ((lane & (SPAN - 1)) == 0 && blk < n_blocks) out[blk] = s;
 }
 
 }  // namespace
@@ -79,7 +61,7 @@ hipError_t launch_sad(int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t
 {
     if (n_blocks == 0) return hipSuccess;
     const int cpb = edge * edge / 16;
-    const size_t bpw = cpb > 64 ? (size_t)(64 * kSadSteps / cpb) : (size_t)(64 / cpb) * kSadSteps;   // 4 KiB of each input per wave
+    const size_t bpw = cpb > 64 ? 1 : (size_t)(64 / cpb);
     const size_t waves = (n_blocks + bpw - 1) / bpw;
     const size_t wgs = (waves + 3) / 4;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
