@@ -135,5 +135,5 @@ def test_other_baseline_config_legs_stay_above_their_floors():
     node.close()
     assert got["tiles_fwd"] >= 0.74 and got["tiles_inv"] >= 0.74, got                # 0.78-0.81 / 0.80-0.815 across boxes (profiles/r03_tiles_one_launch.txt)
     assert got["fused_fwd_inv"] >= 0.64, got                      # 0.66-0.77 across boxes: the most clock-sensitive kernel of the set
-    assert got["intra_predict_written"] >= 0.62, got
+    assert got["intra_predict_written"] >= 0.58, got               # 0.63-0.69 across boxes (write-bound: it follows the box's write rate)
     assert got["stream8k_us_per_frame"] <= 45.0, got
