@@ -5,6 +5,7 @@ Contract (one JSON line on stdout from rank 0):
   python bench.py --gpus N --steps K --warmup W
   N > 1 is launched by the driver as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  (plain `python bench.py --gpus N` without WORLD_SIZE in the environment spawns exactly that itself)
 
 Workload = BASELINE.json configs[1]: 1,048,576 synthetic 9-bit residual blocks of
 32x32 int16 per GPU, resident in HBM before the timed region (values a-b, a,b
@@ -306,6 +307,18 @@ def main():
     if args.traffic_child:
         traffic_child(args)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- the same command line the driver uses, one rank per GPU;
+        # rank 0's JSON line goes to this process's stdout, the exit status is the job's
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")))
     # stdout carries exactly ONE line, the JSON: libraries that chat on stdout (RCCL prints a version banner
     # when a communicator is created) are sent to stderr for the duration of the run
     sys.stdout.flush()
@@ -319,8 +332,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch one rank per GPU (or run without torch.distributed.run: bench.py spawns its own ranks)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libx266hip has no CPU path")
     # Test hook (never set by the driver): X266_BENCH_SHARE_GPU=1 lets several ranks share the visible

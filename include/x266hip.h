@@ -294,9 +294,23 @@ int xHipGraphLaunch(x266hip_ctx *ctx, x266hip_graph *graph, void *stream);
 void xHipGraphFree(x266hip_ctx *ctx, x266hip_graph *graph);
 /* Times `reps` back-to-back launches of one kernel with HIP events recorded on
  * `stream` itself; returns the mean milliseconds per launch in *ms_per_launch.
- * op: 0 = dct32 fwd, 1 = dct32 inv, 2 = satd8x8 (buffers as in the Dev calls). */
+ * op: 0 = dct32 fwd, 1 = dct32 inv, 2 = satd8x8 (buffers as in the Dev calls); 3 / 4 / 5 = xHipMemCeilingDev copy / read /
+ * write of n_blocks * 2048 bytes. */
 int xHipTimeKernel(x266hip_ctx *ctx, int op, const void *d_in, void *d_out,
                    size_t n_blocks, int reps, void *stream, double *ms_per_launch);
+/* What THIS box's memory system gives the launch shape of the streaming kernels, with no arithmetic -- so that a report can
+ * put "fraction of this box's copy / read rate" next to "fraction of the 8 TB/s spec" (boxes differ by 3-10 %).
+ * kind X266_MEM_COPY: d_dst[0 .. bytes) = d_src[0 .. bytes) (16 bytes per lane, nontemporal 1 KiB-linear loads, "sc1 nt"
+ * stores: the access pattern of the DCT / transform kernels); X266_MEM_READ: the same loads and nothing written but one
+ * 32-bit XOR of the words of every 2 KiB piece, d_dst[piece] as uint32 (so d_dst holds 4 * ceil(bytes / 2048) bytes: the
+ * pattern of the SATD / SAD kernels; the checksums make the stream checkable); X266_MEM_WRITE: nothing read (d_src may be
+ * NULL), every 16-byte chunk c of d_dst = {(uint32)c, 0, 0, 0} with the same stores (the pattern of the intra predictor).
+ * bytes a multiple of 16, buffers 16-byte aligned.
+ * Asynchronous on `stream`; time it with the event calls below or xHipTimeKernel's ops 3 / 4 / 5. */
+#define X266_MEM_COPY 0
+#define X266_MEM_READ 1
+#define X266_MEM_WRITE 2
+int xHipMemCeilingDev(x266hip_ctx *ctx, int kind, const void *d_src, void *d_dst, size_t bytes, void *stream);
 /* HIP events for hosts without HIP headers, so that ANY sequence of the ...Dev calls can be timed on the
  * stream it is launched on (record an event before every launch and one after the last: consecutive
  * differences are per-launch durations).  xHipEventElapsedMs waits for `stop` and returns stop - start. */

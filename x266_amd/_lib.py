@@ -93,6 +93,7 @@ def load_library():
     L.xHipStreamSync.argtypes = [_P, _P]
     L.xHipTimeKernel.argtypes = [_P, ctypes.c_int, _P, _P, _SZ, ctypes.c_int, _P,
                                  ctypes.POINTER(ctypes.c_double)]
+    L.xHipMemCeilingDev.argtypes = [_P, ctypes.c_int, _P, _P, _SZ, _P]
     L.xHipEventCreate.argtypes = [_P, ctypes.POINTER(_P)]
     L.xHipEventDestroy.argtypes = [_P, _P]
     L.xHipEventRecord.argtypes = [_P, _P, _P]
@@ -266,6 +267,10 @@ class Codec:
         self.intra32_costs_dev(d_r.ptr, d_s.ptr, d_c.ptr, d_b.ptr, n)
         self.stream_sync()
         return d_c.download(np.uint32, n * 35).reshape(n, 35), d_b.download(np.uint8, n)
+
+    def mem_ceiling_dev(self, kind, d_src, d_dst, nbytes, stream=0):
+        """kind 0 = streaming copy, 1 = read-only stream (one uint32 XOR per 2 KiB into d_dst): this box's memory ceilings"""
+        self._check(self.L.xHipMemCeilingDev(self.ctx, int(kind), d_src, d_dst, nbytes, stream), "xHipMemCeilingDev")
 
     def satd8x8_dev(self, d_in, d_out, n_blocks, stream=0):
         self._check(self.L.xSatd8x8BatchDev(self.ctx, d_in, d_out, n_blocks, stream), "xSatd8x8BatchDev")

@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t abs_sum16(const v16i &acc, uint32_t sum)
 }
 
 // One 32-block group (held as the lane's 64-byte half of its block) -> 32 costs.
-struct SatdOperands { v4i h00, h01, h10, h11; v16i dcfix; int dc0; };
+struct SatdOperands { v4i h00, h01, h10, h11; int bias0; };
 
 __device__ __forceinline__ SatdOperands make_satd_operands(int lane)
 {
@@ -64,42 +64,70 @@ __device__ __forceinline__ SatdOperands make_satd_operands(int lane)
     o.h01 = v4i{(int)(b0 ^ f4), (int)(b1 ^ f4), (int)(b2 ^ f4), (int)(b3 ^ f4)}; // tile 0, step 1: m bit 4 & step
     o.h10 = v4i{(int)(b0 ^ fh), (int)(b1 ^ fh), (int)(b2 ^ fh), (int)(b3 ^ fh)}; // tile 1, step 0: m bit 5 & s bit 5
     o.h11 = o.h01 ^ v4i{(int)fh, (int)fh, (int)fh, (int)fh};
-    // Accumulator start of the HIGH byte plane, i.e. in units of 256: 128 = the int16 bias 0x8000 that lets v_sad_u16
-    // take |.| of the truncated coefficient directly, plus (coefficient m = 0: tile 0, reg 0, half 0) 32 = the byte-plane
-    // offset fix 128 * 64.  Both ride through the "<< 8" between the planes for free.
-    o.dcfix = v16i{128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
-    o.dc0 = half == 0 ? 32 : 0;
+    // What the "<< 8" between the byte planes adds on its way (v_lshl_add, same cost as the bare shift): 0x8000 = the int16
+    // bias that lets v_sad_u16 take |.| of the truncated coefficient directly, plus -- coefficient m = 0 only: tile 0,
+    // register 0, half 0 -- the byte-plane offset fix 128 * 64 = 0x2000.
+    o.bias0 = half == 0 ? 0x8000 + 0x2000 : 0x8000;
     return o;
 }
 
 __device__ __forceinline__ uint32_t satd_group(const SatdOperands &H, const v4i &w0, const v4i &w1, const v4i &w2, const v4i &w3)
 {
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     v4i lo0, hi0, lo1, hi1;
     split_planes(w0, w1, lo0, hi0);                     // K-step 0: samples 32*half + 0..15
     split_planes(w2, w3, lo1, hi1);                     // K-step 1: samples 32*half + 16..31
     uint32_t sum = 0;
-    // x = 256 * (H * hi) + H * lo: the planes are chained through ONE accumulator -- high plane, "<< 8" (a plain 2-cycle
-    // shift; the bias and the offset fix were put into the accumulator start at 1/256 scale), low plane on top.
+    // x = 256 * (H * hi) + H * lo: the planes are chained through ONE accumulator -- high plane, "<< 8" with the bias (and, for
+    // the DC coefficient, the offset fix) added by the same v_lshl_add, low plane on top.
     {   // coefficients 0..31
-        v16i a = mfma(H.h00, hi0, H.dcfix);
+        v16i a = mfma(H.h00, hi0, zero);
         a = mfma(H.h01, hi1, a);
-        a[0] += H.dc0;
+        a[0] = (int)(((uint32_t)a[0] << 8) + (uint32_t)H.bias0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = (int)((uint32_t)a[r] << 8);
+        for (int r = 1; r < 16; ++r) a[r] = (int)(((uint32_t)a[r] << 8) + 0x8000u);
         a = mfma(H.h00, lo0, a);
         a = mfma(H.h01, lo1, a);
         sum = abs_sum16(a, sum);
     }
     {   // coefficients 32..63
-        v16i a = mfma(H.h10, hi0, H.dcfix);
+        v16i a = mfma(H.h10, hi0, zero);
         a = mfma(H.h11, hi1, a);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = (int)((uint32_t)a[r] << 8);
+        for (int r = 0; r < 16; ++r) a[r] = (int)(((uint32_t)a[r] << 8) + 0x8000u);
         a = mfma(H.h10, lo0, a);
         a = mfma(H.h11, lo1, a);
         sum = abs_sum16(a, sum);
     }
     // the other half of the coefficient rows sits in lane ^ 32
+    sum += (uint32_t)__shfl_xor((int)sum, 32);
+    return (sum + 2) >> 2;
+}
+
+// The same with the two coefficient tiles strictly one after the other (a scheduling barrier keeps the compiler from interleaving
+// the two MFMA chains, which costs a second accumulator set) and the second tile's operand images derived from the first's where
+// they are used: fits 64 VGPRs, i.e. eight resident waves per SIMD instead of five.
+__device__ __forceinline__ uint32_t satd_group_seq(const SatdOperands &H, int fh, const v4i &w0, const v4i &w1, const v4i &w2, const v4i &w3)
+{
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v4i lo0, hi0, lo1, hi1;
+    split_planes(w0, w1, lo0, hi0);
+    split_planes(w2, w3, lo1, hi1);
+    uint32_t sum = 0;
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {                          // a real loop: one accumulator set, the tiles strictly in turn
+        const int ft = t ? fh : 0;
+        const v4i f = {ft, ft, ft, ft};
+        const v4i h0 = H.h00 ^ f, h1 = H.h01 ^ f;
+        v16i a = mfma(h0, hi0, zero);
+        a = mfma(h1, hi1, a);
+        a[0] = (int)(((uint32_t)a[0] << 8) + (uint32_t)(t ? 0x8000 : H.bias0));
+#pragma unroll
+        for (int r = 1; r < 16; ++r) a[r] = (int)(((uint32_t)a[r] << 8) + 0x8000u);
+        a = mfma(h0, lo0, a);
+        a = mfma(h1, lo1, a);
+        sum = abs_sum16(a, sum);
+    }
     sum += (uint32_t)__shfl_xor((int)sum, 32);
     return (sum + 2) >> 2;
 }
@@ -136,7 +164,7 @@ __global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict_
 // order through a wave-private LDS slot.  Chunk (block n, row j) lives at
 // n*128 + ((j ^ ((n >> 1) & 7)) << 4): linear writes and fragment reads are conflict-free.
 // the body, per wave: `wave` = index of the wave in the launch, `slot` = its 4 KiB of LDS
-template <bool NT>
+template <bool NT, bool SEQ = false>
 __device__ __forceinline__ void satd8x8_lds_wave(const int16_t *__restrict__ diff, uint32_t *__restrict__ out, size_t n_blocks,
                                                  unsigned groups_per_wave, size_t wave, unsigned char *slot, int lane)
 {
@@ -170,20 +198,175 @@ __device__ __forceinline__ void satd8x8_lds_wave(const int16_t *__restrict__ dif
         const v4i w0 = *reinterpret_cast<const v4i *>(slot + frag[0]), w1 = *reinterpret_cast<const v4i *>(slot + frag[1]);
         const v4i w2 = *reinterpret_cast<const v4i *>(slot + frag[2]), w3 = *reinterpret_cast<const v4i *>(slot + frag[3]);
         __builtin_amdgcn_wave_barrier();
+        const uint32_t cost = SEQ ? satd_group_seq(H, half ? (int)0xFEFEFEFEu : 0, w0, w1, w2, w3) : satd_group(H, w0, w1, w2, w3);
+        const size_t b = g * 32 + blk;
+        if (b < n_blocks && half == 0) out[b] = cost;
+    }
+}
+
+// SHAPE 1: the same, with the next group's four loads issued before this group's arithmetic (register ping-pong, as the DCT32 kernel does)
+template <bool NT>
+__device__ __forceinline__ void satd8x8_lds_wave_prefetch(const int16_t *__restrict__ diff, uint32_t *__restrict__ out, size_t n_blocks,
+                                                          unsigned groups_per_wave, size_t wave, unsigned char *slot, int lane)
+{
+    const size_t n_groups = (n_blocks + 31) >> 5;
+    size_t g = wave * groups_per_wave;
+    const size_t end = g + groups_per_wave < n_groups ? g + groups_per_wave : n_groups;
+    if (g >= end) return;
+    const int blk = lane & 31, half = lane >> 5;
+    const size_t total_bytes = n_blocks * 128;
+    unsigned lin[4], frag[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned chunk = lane + 64 * i, n = chunk >> 3, j = chunk & 7;
+        lin[i] = n * 128 + ((j ^ ((n >> 1) & 7)) << 4);
+        frag[i] = blk * 128 + ((((unsigned)(4 * half + i)) ^ (((unsigned)blk >> 1) & 7)) << 4);
+    }
+    v4i v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        size_t off = g * 4096 + (size_t)lane * 16 + 1024 * (size_t)i;
+        if (off + 16 > total_bytes) off = total_bytes - 16;
+        v[i] = load16<NT>(reinterpret_cast<const char *>(diff) + off);
+    }
+    const SatdOperands H = make_satd_operands(lane);
+    for (; g < end; ++g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<v4i *>(slot + lin[i]) = v[i];
+        if (g + 1 < end) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                size_t off = (g + 1) * 4096 + (size_t)lane * 16 + 1024 * (size_t)i;
+                if (off + 16 > total_bytes) off = total_bytes - 16;
+                v[i] = load16<NT>(reinterpret_cast<const char *>(diff) + off);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const v4i w0 = *reinterpret_cast<const v4i *>(slot + frag[0]), w1 = *reinterpret_cast<const v4i *>(slot + frag[1]);
+        const v4i w2 = *reinterpret_cast<const v4i *>(slot + frag[2]), w3 = *reinterpret_cast<const v4i *>(slot + frag[3]);
+        __builtin_amdgcn_wave_barrier();
         const uint32_t cost = satd_group(H, w0, w1, w2, w3);
         const size_t b = g * 32 + blk;
         if (b < n_blocks && half == 0) out[b] = cost;
     }
 }
 
-template <bool NT>
-__global__ __launch_bounds__(256) void satd8x8_lds_kernel(const int16_t *__restrict__ diff,
-                                                          uint32_t *__restrict__ out, size_t n_blocks,
-                                                          unsigned groups_per_wave)
+// SHAPE 2: the groups go straight from HBM into LDS (global_load_lds_dwordx4: no staging registers), two 4 KiB slots per wave
+// in ping-pong, so that group g+1 is in flight while group g is scored.  The DMA writes lane l's 16 bytes at slot + 16 l, i.e.
+// the LDS image is linear in the order of the lanes' global addresses; the bank swizzle of the fragment reads is therefore
+// applied on the GLOBAL side -- lane l of instruction i fetches chunk (n, j ^ ((n >> 1) & 7)) of its 128-byte line, n = (l + 64 i) >> 3,
+// j = l & 7: the same whole lines per instruction, permuted inside each line.
+// `group` = the group's first byte (wave-uniform: the address is an SGPR pair + the lane's constant 32-bit offset, no vector
+// address arithmetic per group); CLAMP: the batch's last, partly filled group -- lanes past the end re-read its last 16 bytes
+template <bool NT, bool CLAMP>
+__device__ __forceinline__ void satd8x8_dma_issue(const char *__restrict__ group, size_t bytes_left, const unsigned (&goff)[4], unsigned char *slot)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 4 KiB per wave (+ occupancy padding)
-    satd8x8_lds_wave<NT>(diff, out, n_blocks, groups_per_wave, ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6,
-                         stage + (threadIdx.x >> 6) * 4096, (int)(threadIdx.x & 63));
+    if (!CLAMP) {
+        // SGPR-pair base + the lane's 32-bit offset, LDS destination through M0: the instructions themselves, because the compiler
+        // only produces the VGPR-pair address form here (a 64-bit vector add per load).  M0 is put back: the compiler owns it.
+        const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)slot;
+        unsigned keep;
+#define X266_DMA4(POLICY)                                                                                                       \
+        asm volatile("s_mov_b32 %0, m0\n\t"                                                                                     \
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5" POLICY "\n\t"                              \
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5" POLICY "\n\t"                              \
+                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5" POLICY "\n\t"                              \
+                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5" POLICY "\n\t"                              \
+                     "s_mov_b32 m0, %0"                                                                                         \
+                     : "=&s"(keep)                                                                                              \
+                     : "v"(goff[0]), "v"(goff[1]), "v"(goff[2]), "v"(goff[3]), "s"(group), "s"(lds), "s"(lds + 1024u),          \
+                       "s"(lds + 2048u), "s"(lds + 3072u)                                                                       \
+                     : "memory")
+        if (NT) X266_DMA4(" nt");
+        else    X266_DMA4("");
+#undef X266_DMA4
+        return;
+    }
+    asm volatile("; ragged last group" ::: "memory");    // keeps this (once per launch) path a branch: if-converted into the common path it costs every group vector selects
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned off = goff[i];
+        if ((size_t)off + 16 > bytes_left) off = (unsigned)(bytes_left - 16);   // those blocks are never stored
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(group + off),
+                                         (__attribute__((address_space(3))) void *)(slot + 1024 * i), 16, 0, NT ? 2 : 0);
+    }
+}
+
+template <bool NT, int DEPTH>
+__device__ __forceinline__ void satd8x8_lds_wave_dma(const int16_t *__restrict__ diff, uint32_t *__restrict__ out, size_t n_blocks,
+                                                     unsigned first, unsigned step, unsigned count, unsigned char *slots, int lane)
+{
+    // The wave scores groups first, first + step, ... (`count` of them, clipped to the batch).  Group counters are 32-bit (the
+    // launcher refuses batches of 2^37 blocks): wave-uniform compares stay on the scalar unit.
+    const unsigned n_groups = (unsigned)((n_blocks + 31) >> 5), full_groups = (unsigned)(n_blocks >> 5);
+    unsigned g = first;
+    if (g >= n_groups) return;
+    const unsigned avail = (n_groups - g + step - 1) / step;
+    const unsigned end = g + (avail < count ? avail : count) * step;          // exclusive, in steps of `step`
+    const int blk = lane & 31, half = lane >> 5;
+    const char *src = reinterpret_cast<const char *>(diff);
+    unsigned goff[4], frag[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned chunk = lane + 64 * i, n = chunk >> 3, j = chunk & 7;
+        goff[i] = n * 128 + ((j ^ ((n >> 1) & 7)) << 4);
+        frag[i] = blk * 128 + ((((unsigned)(4 * half + i)) ^ (((unsigned)blk >> 1) & 7)) << 4);
+    }
+    // DEPTH - 1 groups ahead of the one being scored; group q lives in slot q % DEPTH
+    unsigned head = 0, tail = 0;                                      // slot of the group scored next / of the group fetched next
+    unsigned fetched = g;
+    auto fetch = [&]() {
+        const char *group = src + (size_t)fetched * 4096;
+        if (fetched < full_groups) satd8x8_dma_issue<NT, false>(group, 0, goff, slots + tail * 4096);
+        else                       satd8x8_dma_issue<NT, true>(group, (n_blocks & 31) * 128, goff, slots + tail * 4096);
+        fetched += step;
+        tail = tail + 1 == (unsigned)DEPTH ? 0 : tail + 1;
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d)
+        if (fetched < end) fetch();
+    const SatdOperands H = make_satd_operands(lane);
+    for (; g < end; g += step) {
+        unsigned char *slot = slots + head * 4096;
+        if (fetched < end) fetch();
+        // group g has landed once at most `ahead` later groups' loads (4 each) are still outstanding; vmcnt counts in order
+        const unsigned ahead = fetched == g + step ? 0u : fetched == g + 2 * step ? 1u : fetched == g + 3 * step ? 2u : 3u;
+        if (DEPTH >= 4 && ahead >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (DEPTH >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead >= 1)               asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else                               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const v4i w0 = *reinterpret_cast<const v4i *>(slot + frag[0]), w1 = *reinterpret_cast<const v4i *>(slot + frag[1]);
+        const v4i w2 = *reinterpret_cast<const v4i *>(slot + frag[2]), w3 = *reinterpret_cast<const v4i *>(slot + frag[3]);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t cost = satd_group(H, w0, w1, w2, w3);
+        if (half == 0 && (g < full_groups || (unsigned)blk < (unsigned)(n_blocks & 31))) (out + (size_t)g * 32)[blk] = cost;
+        head = head + 1 == (unsigned)DEPTH ? 0 : head + 1;
+    }
+}
+
+template <bool NT, int SHAPE>
+__global__ __launch_bounds__(256, SHAPE == 3 ? 8 : 1) void satd8x8_lds_kernel(const int16_t *__restrict__ diff,
+                                                          uint32_t *__restrict__ out, size_t n_blocks,
+                                                          unsigned groups_per_wave, unsigned lds_per_wave, unsigned interleave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 4 KiB per wave (SHAPE 2: 8 KiB) + occupancy padding
+    // wave-uniform by construction; readfirstlane tells the compiler so (scalar group addresses, scalar LDS slot for M0)
+    const unsigned wave_in_wg = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+    unsigned char *slot = stage + wave_in_wg * lds_per_wave;
+    const int lane = (int)(threadIdx.x & 63);
+    if (SHAPE == 2 || SHAPE >= 4) {
+        // interleave: the workgroup's waves take turns over its groups (the workgroup advances through one contiguous piece,
+        // 4 KiB per wave and step); otherwise every wave walks its own run of consecutive groups
+        const unsigned waves_per_wg = blockDim.x >> 6;
+        if (wave > 0xFFFFFFFFu / groups_per_wave) return;
+        const unsigned first = interleave ? blockIdx.x * waves_per_wg * groups_per_wave + wave_in_wg : (unsigned)wave * groups_per_wave;
+        satd8x8_lds_wave_dma<NT, SHAPE == 2 ? 2 : SHAPE - 1>(diff, out, n_blocks, first, interleave ? waves_per_wg : 1u, groups_per_wave, slot, lane);
+    }
+    else if (SHAPE == 1) satd8x8_lds_wave_prefetch<NT>(diff, out, n_blocks, groups_per_wave, wave, slot, lane);
+    else if (SHAPE == 3) satd8x8_lds_wave<NT, true>(diff, out, n_blocks, groups_per_wave, wave, slot, lane);
+    else                 satd8x8_lds_wave<NT>(diff, out, n_blocks, groups_per_wave, wave, slot, lane);
 }
 
 // ---- the two lanes of a frame in ONE launch (BASELINE configs[4]: a 7680x4320 frame = 32 400 DCT32 blocks + 518 400
@@ -351,9 +534,13 @@ hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_block
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs), block(tpb);
     if (cfg.lds_stage) {
-        const size_t lds = waves_per_wg * (size_t)(cfg.lds_bytes_per_wave < 4096 ? 4096 : cfg.lds_bytes_per_wave) + (size_t)cfg.lds_pad_bytes;
-        if (cfg.nontemporal & 1) hipLaunchKernelGGL((satd8x8_lds_kernel<true>), grid, block, lds, stream, d_diff, d_out, n_blocks, gpw);
-        else                     hipLaunchKernelGGL((satd8x8_lds_kernel<false>), grid, block, lds, stream, d_diff, d_out, n_blocks, gpw);
+        const unsigned min_lds = cfg.shape == 2 ? 8192u : cfg.shape >= 4 ? 4096u * (unsigned)(cfg.shape - 1) : 4096u;
+        const unsigned per_wave = (unsigned)cfg.lds_bytes_per_wave < min_lds ? min_lds : (unsigned)cfg.lds_bytes_per_wave;
+        const size_t lds = waves_per_wg * (size_t)per_wave + (size_t)cfg.lds_pad_bytes;
+#define X266_SATD(NT, SHAPE) hipLaunchKernelGGL((satd8x8_lds_kernel<NT, SHAPE>), grid, block, lds, stream, d_diff, d_out, n_blocks, gpw, per_wave, (unsigned)cfg.interleave)
+        if (cfg.nontemporal & 1) { if (cfg.shape == 2) X266_SATD(true, 2); else if (cfg.shape == 1) X266_SATD(true, 1); else if (cfg.shape == 3) X266_SATD(true, 3); else if (cfg.shape == 4) X266_SATD(true, 4); else if (cfg.shape == 5) X266_SATD(true, 5); else X266_SATD(true, 0); }
+        else                     { if (cfg.shape == 2) X266_SATD(false, 2); else if (cfg.shape == 1) X266_SATD(false, 1); else if (cfg.shape == 3) X266_SATD(false, 3); else X266_SATD(false, 0); }
+#undef X266_SATD
         return hipGetLastError();
     }
     if (cfg.nontemporal & 4) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);

@@ -61,6 +61,8 @@ struct LaunchCfg {
     int lds_bytes_per_wave;   // staged kernels: LDS charged per wave (>= 2048); 160 KiB / this = resident waves per CU
     int lds_stage;       // DCT32: move tiles with linear 1 KiB instructions through a private LDS slot
     int passthrough;     // diagnostic: skip the arithmetic (timing of the memory pattern only)
+    int interleave = 0;  // A/B: SATD batch, LDS-DMA bodies: waves of a workgroup take turns over its groups
+    int shape = 0;       // A/B: kernel body variant (SATD batch: 0 load-then-score, 1 register prefetch, 2 LDS-DMA ping-pong)
 };
 
 struct DctOps;
@@ -115,6 +117,7 @@ hipError_t launch_tile_convert(bool pack, x266_ref_block_t *d_tiles, uint8_t *d_
                                long long strd_y, long long strd_c, int width, int height, hipStream_t stream);
 hipError_t launch_residual_luma(int block_edge, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_res,
                                 int width, int height, hipStream_t stream);
+hipError_t launch_mem_ceiling(int kind, const void *d_src, void *d_dst, size_t bytes, hipStream_t stream);
 hipError_t launch_fill_residual(int16_t *d_dst, size_t n_samples, uint64_t seed,
                                 uint64_t first_index, const LaunchCfg &cfg, hipStream_t stream);
 

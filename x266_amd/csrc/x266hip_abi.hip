@@ -33,6 +33,7 @@ struct x266hip_ctx {
     // the two 1-D transform slots of the set, N = 4, 8, 16: slot 0 = DCT-II sub-matrices of g_t32, slot 1 = closed-form
     // DST-VII unless the caller installed its own (xTransformSetMatrix); row k = basis function, N x N, row-major
     int8_t slot_mat[2][3][256] = {};
+    bool tr_tables_valid = true;                    // false after a matrix update whose device tables could be neither installed nor rolled back
     int tile_lds_per_wave = 8192;                   // mixed-class tile kernel: LDS charged per wave (resident-wave cap)
     int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (next tile's loads issued before this tile's arithmetic)
     // options
@@ -76,12 +77,15 @@ struct x266hip_ctx {
     int dct_wg_threads = 64, dct_inv_wg_threads = 64;
     int dct_lds_stage = 1;                          // see dct32_kernels.hip: dct32_lds_kernel
     int passthrough = 0;                            // diagnostic, see x266_device.hpp
+    int satd_interleave = 0;
+    int satd_shape = 0;                             // A/B: SATD batch kernel body (x266_device.hpp LaunchCfg::shape)
     // host-pointer staging (lazily allocated)
-    static constexpr int kSlots = 2;
-    void *d_stage_in[kSlots] = {nullptr, nullptr};
-    void *d_stage_out[kSlots] = {nullptr, nullptr};
+    static constexpr int kSlots = 3;                // chunk i+1 uploading and chunk i-1 downloading while chunk i is transformed
+    void *d_stage_in[kSlots] = {};
+    void *d_stage_out[kSlots] = {};
     size_t stage_in_bytes = 0, stage_out_bytes = 0;
-    hipStream_t stage_stream[kSlots] = {nullptr, nullptr};
+    hipStream_t stage_stream[kSlots] = {};
+    int host_register = 0;                          // env X266HIP_HOST_REGISTER=1: pin the caller's pageable buffers for the duration of a large host-pointer call
     std::string err;
 };
 
@@ -132,6 +136,8 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
     c.units_per_wave = op == 2 ? ctx->satd_groups_per_wave : (op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave);
     c.wg_threads = op == 2 ? ctx->satd_wg_threads : ctx->wg_threads;
     c.passthrough = ctx->passthrough;
+    c.shape = op == 2 ? ctx->satd_shape : 0;
+    c.interleave = op == 2 ? ctx->satd_interleave : 0;
     c.lds_stage = op == 2 ? ctx->satd_lds_stage : ctx->dct_lds_stage;
     c.lds_bytes_per_wave = op == 2 ? ctx->satd_lds_per_wave : (op == 1 ? ctx->dct_inv_lds_per_wave : ctx->dct_lds_per_wave);
     if (op != 2 && ctx->dct_lds_stage) c.wg_threads = op == 1 ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
@@ -152,6 +158,7 @@ int launch_op(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n,
         if (ctx->satd_variant == 2) e = launch_satd8x8_butterfly((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s);   // VALU comparison variant
         else e = launch_satd8x8((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s);
         break;
+    case 3: case 4: case 5: e = launch_mem_ceiling(op - 3, d_in, d_out, n * 2048, s); break;      // xHipTimeKernel only
     default: return fail(ctx, X266HIP_EINVAL, "unknown op");
     }
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "kernel launch", e);
@@ -236,12 +243,14 @@ Matrix32 block_diagonal(const int8_t *m, int n)
     return r;
 }
 
-// operand images of class (type, N = 4 << l) from the context's slot matrices: the two per-class tables (allocated on first use)
-bool upload_class(x266hip_ctx *ctx, int type, int l, DctOps *h)
+typedef int8_t SlotMatrices[2][3][256];
+
+// operand images of class (type, N = 4 << l) from a set of slot matrices: the two per-class tables (allocated on first use)
+bool upload_class(x266hip_ctx *ctx, const SlotMatrices &mat, int type, int l, DctOps *h)
 {
     const int n = 4 << l;
-    const Matrix32 mh = block_diagonal(ctx->slot_mat[transform_htype(type) == kTrDst7][l], n);
-    const Matrix32 mv = block_diagonal(ctx->slot_mat[transform_vtype(type) == kTrDst7][l], n);
+    const Matrix32 mh = block_diagonal(mat[transform_htype(type) == kTrDst7][l], n);
+    const Matrix32 mv = block_diagonal(mat[transform_vtype(type) == kTrDst7][l], n);
     build_fwd_ops_general(*h, mh, mv, transform_shift1(n), transform_shift2(n));
     if (!ctx->d_tr[type][l] && hipMalloc((void **)&ctx->d_tr[type][l], sizeof(DctOps)) != hipSuccess) return false;
     if (hipMemcpy(ctx->d_tr[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) != hipSuccess) return false;
@@ -250,14 +259,23 @@ bool upload_class(x266hip_ctx *ctx, int type, int l, DctOps *h)
     return hipMemcpy(ctx->d_tr_inv[type][l], h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
 }
 
-// the mixed-class tile kernel's compact tables from the context's slot matrices
-bool upload_tile_tabs(x266hip_ctx *ctx)
+// the mixed-class tile kernel's compact tables from a set of slot matrices
+bool upload_tile_tabs(x266hip_ctx *ctx, const SlotMatrices &mat)
 {
     TileTab t;
-    build_tile_tab(t, ctx->slot_mat, false);
+    build_tile_tab(t, mat, false);
     if (hipMemcpy(ctx->d_tile_fwd, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess) return false;
-    build_tile_tab(t, ctx->slot_mat, true);
+    build_tile_tab(t, mat, true);
     return hipMemcpy(ctx->d_tile_inv, &t, sizeof t, hipMemcpyHostToDevice) == hipSuccess;
+}
+
+// every device table that depends on (slot, N = 4 << l) of `mat`
+bool upload_slot_tables(x266hip_ctx *ctx, const SlotMatrices &mat, int slot, int l, DctOps *h)
+{
+    for (int type = 0; type < x266hip_ctx::kTypes; ++type)
+        if ((transform_htype(type) == kTrDst7) == (slot == 1) || (transform_vtype(type) == kTrDst7) == (slot == 1))
+            if (!upload_class(ctx, mat, type, l, h)) return false;
+    return upload_tile_tabs(ctx, mat);
 }
 
 }  // namespace
@@ -285,6 +303,7 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
     x266hip_ctx *ctx = new (std::nothrow) x266hip_ctx;
     if (!ctx) return X266HIP_ENOMEM;
     ctx->device = device_id;
+    if (const char *hr = std::getenv("X266HIP_HOST_REGISTER")) ctx->host_register = std::atoi(hr) != 0;
     DeviceScope dev_scope_(device_id);
     if (dev_scope_.status != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess) {
         delete ctx;
@@ -320,8 +339,8 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
              hipMalloc((void **)&ctx->d_tile_inv, sizeof(TileTab)) == hipSuccess;
     }
     for (int type = 0; type < x266hip_ctx::kTypes && ok; ++type)
-        for (int l = 0; l < 3 && ok; ++l) ok = upload_class(ctx, type, l, h);
-    if (ok) ok = upload_tile_tabs(ctx);
+        for (int l = 0; l < 3 && ok; ++l) ok = upload_class(ctx, ctx->slot_mat, type, l, h);
+    if (ok) ok = upload_tile_tabs(ctx, ctx->slot_mat);
     delete h;
 
     if (!ok) {
@@ -401,13 +420,15 @@ static const OptionDesc kOptions[] = {
     {"tr_lds_stage", &x266hip_ctx::tr_lds_stage, 0, 1, 1},
     {"dct32_lds_bytes_per_wave", &x266hip_ctx::dct_lds_per_wave, 2048, 40960, 1},
     {"dct32_inv_lds_bytes_per_wave", &x266hip_ctx::dct_inv_lds_per_wave, 2048, 40960, 1},
-    {"satd_lds_bytes_per_wave", &x266hip_ctx::satd_lds_per_wave, 2048, 40960, 1},
+    {"satd_lds_bytes_per_wave", &x266hip_ctx::satd_lds_per_wave, 2048, 163840, 1},
     {"dct32_lds_pad_bytes", &x266hip_ctx::lds_pad_dct, 0, 160 * 1024, 1},
     {"dct32_inv_lds_pad_bytes", &x266hip_ctx::lds_pad_inv, 0, 160 * 1024, 1},
     {"satd_lds_pad_bytes", &x266hip_ctx::lds_pad_satd, 0, 160 * 1024, 1},
     {"me_tile_rows", &x266hip_ctx::me_tile_rows, 0, 8, 1},
     {"intra_rounds", &x266hip_ctx::intra_rounds, 1, 16, 1},
     {"diag_passthrough", &x266hip_ctx::passthrough, 0, 1, 1},
+    {"diag_satd_shape", &x266hip_ctx::satd_shape, 0, 5, 1},
+    {"diag_satd_interleave", &x266hip_ctx::satd_interleave, 0, 1, 1},
     {"diag_tr32_simple", &x266hip_ctx::tr32_simple, 0, 1, 1},
 };
 
@@ -499,6 +520,17 @@ int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out, s
     return launch_op(ctx, 2, d_diff, d_out, n, (hipStream_t)stream);
 }
 
+int xHipMemCeilingDev(x266hip_ctx *ctx, int kind, const void *d_src, void *d_dst, size_t bytes, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (kind < X266_MEM_COPY || kind > X266_MEM_WRITE) return fail(ctx, X266HIP_EINVAL, "xHipMemCeilingDev: kind must be X266_MEM_COPY, _READ or _WRITE");
+    if ((bytes & 15u) || bad_ptrs(kind == X266_MEM_WRITE ? d_dst : d_src, d_dst, bytes)) return fail(ctx, X266HIP_EINVAL, "xHipMemCeilingDev: NULL or unaligned buffer, or bytes not a multiple of 16");
+    X_DEV(ctx);
+    const hipError_t e = launch_mem_ceiling(kind, d_src, d_dst, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "memory ceiling launch", e);
+    return X266HIP_OK;
+}
+
 int xIntra32PredictDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const uint8_t *d_modes,
                        const uint32_t *d_ref_index, uint8_t *d_pred, size_t n, void *stream)
 {
@@ -544,6 +576,7 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
         return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: size must be 4, 8, 16 (or 32 for DCT-II)");
     if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: NULL or unaligned buffer");
     if (n && ((uintptr_t)d_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: unaligned offset table");
+    if (!ctx->tr_tables_valid) return fail(ctx, X266HIP_EDEVICE, "xTransformFwdBatchDev: the transform tables of this context are invalid (a failed xTransformSetMatrix)");
     X_DEV(ctx);
     if (size == 32) {
         if (!d_offsets && !ctx->tr32_simple) return launch_op(ctx, 0, d_in, d_out, n, (hipStream_t)stream);
@@ -576,16 +609,22 @@ int xTransformSetMatrix(x266hip_ctx *ctx, int slot, int size, const int8_t *m)
     X_DEV(ctx);
     if (hipDeviceSynchronize() != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "xTransformSetMatrix: device synchronisation");   // launches in flight read the tables
     const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
-    if (m) std::memcpy(ctx->slot_mat[slot][l], m, (size_t)size * size);
-    else default_slot_matrix(slot, size, ctx->slot_mat[slot][l]);
+    // All or nothing: the device tables are built from a COPY of the slot matrices and the context's own copy changes only
+    // once every upload has succeeded; after a failed upload the old tables are put back, and if even that fails the
+    // transform set of this context is marked unusable (its calls then fail) rather than left half old, half new.
+    SlotMatrices next;
+    std::memcpy(next, ctx->slot_mat, sizeof next);
+    if (m) std::memcpy(next[slot][l], m, (size_t)size * size);
+    else default_slot_matrix(slot, size, next[slot][l]);
     DctOps *h = new (std::nothrow) DctOps;
     if (!h) return fail(ctx, X266HIP_ENOMEM, "xTransformSetMatrix");
-    bool ok = true;
-    for (int type = 0; type < x266hip_ctx::kTypes && ok; ++type)
-        if ((transform_htype(type) == kTrDst7) == (slot == 1) || (transform_vtype(type) == kTrDst7) == (slot == 1)) ok = upload_class(ctx, type, l, h);
+    const bool ok = upload_slot_tables(ctx, next, slot, l, h);
+    if (!ok) ctx->tr_tables_valid = upload_slot_tables(ctx, ctx->slot_mat, slot, l, h);
     delete h;
-    if (ok) ok = upload_tile_tabs(ctx);
-    if (!ok) return fail(ctx, X266HIP_EDEVICE, "xTransformSetMatrix: table upload");
+    if (!ok) return fail(ctx, X266HIP_EDEVICE, ctx->tr_tables_valid ? "xTransformSetMatrix: table upload failed, previous matrices kept"
+                                                                      : "xTransformSetMatrix: table upload failed and the previous tables could not be restored: transform set unusable");
+    std::memcpy(ctx->slot_mat, next, sizeof next);
+    ctx->tr_tables_valid = true;
     return X266HIP_OK;
 }
 
@@ -602,6 +641,7 @@ int xTransformTilesDev(x266hip_ctx *ctx, int inverse, const int16_t *d_in, int16
     if (!ctx) return X266HIP_EINVAL;
     if (bad_ptrs(d_in, d_out, n_tiles) || (n_tiles && !d_tile_class)) return fail(ctx, X266HIP_EINVAL, "xTransformTilesDev: NULL or unaligned buffer");
     if (n_tiles && ((uintptr_t)d_tile_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformTilesDev: unaligned offset table");
+    if (!ctx->tr_tables_valid) return fail(ctx, X266HIP_EDEVICE, "xTransformTilesDev: the transform tables of this context are invalid (a failed xTransformSetMatrix)");
     X_DEV(ctx);
     LaunchCfg cfg = cfg_for(ctx, inverse ? 1 : 0);
     cfg.wg_threads = inverse ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
@@ -709,6 +749,7 @@ int xTransformInvBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
         return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: size must be 4, 8, 16 (or 32 for DCT-II)");
     if (bad_ptrs(d_in, d_out, n)) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: NULL or unaligned buffer");
     if (n && ((uintptr_t)d_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformInvBatchDev: unaligned offset table");
+    if (!ctx->tr_tables_valid) return fail(ctx, X266HIP_EDEVICE, "xTransformInvBatchDev: the transform tables of this context are invalid (a failed xTransformSetMatrix)");
     X_DEV(ctx);
     if (size == 32 && !d_offsets) return launch_op(ctx, 1, d_in, d_out, n, (hipStream_t)stream);
     const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
@@ -773,7 +814,7 @@ int xSad8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride
 }
 
 // ---- host-pointer batch API --------------------------------------------------
-// Chunks of the batch alternate between two staging slots, each with its own
+// Chunks of the batch rotate over three staging slots, each with its own
 // stream: H2D(i+1) and D2H(i-1) overlap kernel(i).
 static int ensure_staging(x266hip_ctx *ctx, size_t in_bytes, size_t out_bytes)
 {
@@ -809,6 +850,15 @@ static int host_batch(x266hip_ctx *ctx, int op, const void *in, void *out, size_
     if (chunk > n) chunk = n;
     int rc = ensure_staging(ctx, chunk * in_unit, chunk * out_unit);
     if (rc) return rc;
+    // optional: pin the caller's pageable buffers while the call runs (the runtime otherwise stages them through its own
+    // pinned bounce buffers); only where the registration cost can pay, and never for memory that is pinned already
+    bool reg_in = false, reg_out = false;
+    if (ctx->host_register && n * in_unit >= ((size_t)64 << 20)) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, in) != hipSuccess) reg_in = hipHostRegister(const_cast<void *>(in), n * in_unit, hipHostRegisterDefault) == hipSuccess;
+        if (hipPointerGetAttributes(&attr, out) != hipSuccess) reg_out = hipHostRegister(out, n * out_unit, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();
+    }
     size_t done = 0;
     int slot = 0;
     hipError_t e = hipSuccess;
@@ -822,15 +872,17 @@ static int host_batch(x266hip_ctx *ctx, int op, const void *in, void *out, size_
         if (e == hipSuccess) rc = launch_op(ctx, op, ctx->d_stage_in[slot], ctx->d_stage_out[slot], cnt, s);
         STAGE(hipMemcpyAsync((char *)out + done * out_unit, ctx->d_stage_out[slot], cnt * out_unit, hipMemcpyDeviceToHost, s));
         done += cnt;
-        slot ^= 1;
+        slot = slot + 1 == x266hip_ctx::kSlots ? 0 : slot + 1;
     }
 #undef STAGE
-    // Drain BOTH staging streams on every path: after a failure an already enqueued D2H copy must not still be
+    // Drain EVERY staging stream on every path: after a failure an already enqueued D2H copy must not still be
     // writing the caller's `out` once this function has returned (the caller may free it).
     for (int i = 0; i < x266hip_ctx::kSlots; ++i) {
         const hipError_t es = hipStreamSynchronize(ctx->stage_stream[i]);
         if (e == hipSuccess && es != hipSuccess) { e = es; what = "hipStreamSynchronize(stage)"; }
     }
+    if (reg_in) (void)hipHostUnregister(const_cast<void *>(in));
+    if (reg_out) (void)hipHostUnregister(out);
     if (rc != X266HIP_OK) return rc;
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, what, e);
     return X266HIP_OK;
