@@ -77,6 +77,7 @@ def parse_args():
     ap.add_argument("--node-timeout", type=float, default=240.0,
                     help="seconds the node-layer legs (RCCL) may take before the JSON line is printed without them")
     ap.add_argument("--no-me", action="store_true", help="skip the motion-search legs")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-pointer leg")
     ap.add_argument("--no-transform-set", action="store_true", help="skip the transform-set / front-end / intra legs")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic (replay profiles/traffic.json instead)")
@@ -301,6 +302,134 @@ def cpu_baseline_dct(x_host, gpu_out_host):
     }, exact
 
 
+def gpu_sysfs_dir(torch):
+    """/sys/class/drm/cardN/device of cuda:0, matched by PCI address (a box shows every GPU of the host in sysfs, not only its own)"""
+    import glob
+    try:
+        p = torch.cuda.get_device_properties(0)
+        want = "%04x:%02x:%02x." % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        return None
+    for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+        if os.path.realpath(dev).split("/")[-1].startswith(want):
+            return dev
+    return None
+
+
+class SclkSampler:
+    """median shader clock (MHz) of cuda:0 while a leg runs, read from the device's hwmon freq1_input every 10 ms by a thread;
+    None where sysfs does not show it.  The VALU floors of the motion searches scale with it."""
+
+    def __init__(self, torch):
+        import glob
+        dev = gpu_sysfs_dir(torch)
+        files = glob.glob(dev + "/hwmon/hwmon*/freq1_input") if dev else []
+        self.path = files[0] if files else None
+        self.samples = []
+
+    def __enter__(self):
+        self.stop = False
+        if self.path:
+            def run():
+                while not self.stop:
+                    try:
+                        self.samples.append(int(open(self.path).read()) / 1e6)
+                    except (OSError, ValueError):
+                        pass
+                    time.sleep(0.01)
+            self.thread = threading.Thread(target=run, daemon=True)
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        if self.path:
+            self.thread.join()
+
+    def mhz(self):
+        busy = [v for v in self.samples if v > 600]                      # idle samples between launches are not the kernel's clock
+        return statistics.median(busy) if busy else None
+
+
+def pcie_link_facts(torch):
+    """negotiated generation / width of the GPU's PCIe link from sysfs (the device of cuda:0 by PCI address when torch exposes it,
+    else whatever the AMD devices agree on)"""
+    import glob
+    dev = gpu_sysfs_dir(torch)
+    if dev:
+        try:
+            return {"speed": open(dev + "/current_link_speed").read().strip(), "width": open(dev + "/current_link_width").read().strip(),
+                    "device": os.path.realpath(dev).split("/")[-1]}
+        except OSError:
+            pass
+    seen = {}
+    for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+        try:
+            if open(d + "/vendor").read().strip() != "0x1002":
+                continue
+            facts = tuple(open(d + "/" + k).read().strip() for k in ("current_link_speed", "current_link_width"))
+        except OSError:
+            continue
+        seen[facts] = seen.get(facts, 0) + 1
+    if len(seen) == 1:
+        (speed, width), cnt = next(iter(seen.items()))
+        return {"speed": speed, "width": width, "device": "all %d AMD devices in sysfs agree" % cnt}
+    return None
+
+
+def host_api_leg(codec, torch, n):
+    """xDct32FwdBatch on n blocks from pageable and from pinned host buffers, next to what the link itself gives (plain copies)"""
+    nbytes = n * 2048
+    out = {"blocks": n, "MiB_each_way": nbytes >> 20, "pcie_link": pcie_link_facts(torch)}
+
+    def best_of(fn, reps=4):
+        best = 1e9
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best
+    hp_in, hp_out = torch.empty(nbytes, dtype=torch.uint8).pin_memory(), torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    d_a, d_b = torch.empty(nbytes, dtype=torch.uint8, device="cuda"), torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def both():
+        with torch.cuda.stream(s1):
+            d_a.copy_(hp_in, non_blocking=True)
+        with torch.cuda.stream(s2):
+            hp_out.copy_(d_b, non_blocking=True)
+    out["link_GBps"] = {"h2d_alone": nbytes / best_of(lambda: d_a.copy_(hp_in, non_blocking=True)) / 1e9,
+                        "d2h_alone": nbytes / best_of(lambda: hp_out.copy_(d_b, non_blocking=True)) / 1e9,
+                        "each_way_both_directions_at_once": nbytes / best_of(both) / 1e9,
+                        "how": "one plain %d MiB copy from / to pinned memory per direction (torch)" % (nbytes >> 20)}
+    del hp_in, hp_out, d_a, d_b
+    x_dev = torch.empty(n * 1024, dtype=torch.int16, device="cuda")
+    codec.fill_residual_dev(x_dev.data_ptr(), n * 1024, DCT_SEED, 0, 0)
+    torch.cuda.synchronize()
+    xh = x_dev.cpu().numpy().reshape(n, 1024)                           # pageable, touched
+    zh = np.ones_like(xh)
+    P = ctypes.c_void_p
+
+    def call(i, o):
+        rc = codec.L.xDct32FwdBatch(codec.ctx, P(i), P(o), n)
+        if rc:
+            raise RuntimeError("xDct32FwdBatch failed: %d" % rc)
+    dt = best_of(lambda: call(xh.ctypes.data, zh.ctypes.data))
+    out["pageable"] = {"blocks_per_s": n / dt, "GBps_each_way": nbytes / dt / 1e9, "ms": dt * 1e3}
+    xp, zp = codec.host_alloc((n, 1024), np.int16), codec.host_alloc((n, 1024), np.int16)
+    xp[:] = xh
+    dt = best_of(lambda: call(xp.ctypes.data, zp.ctypes.data))
+    out["pinned"] = {"blocks_per_s": n / dt, "GBps_each_way": nbytes / dt / 1e9, "ms": dt * 1e3, "same_result_as_pageable": bool(np.array_equal(zp, zh))}
+    both_rate = out["link_GBps"]["each_way_both_directions_at_once"]
+    out["pinned"]["frac_of_link_both_directions"] = out["pinned"]["GBps_each_way"] / both_rate
+    out["pageable"]["frac_of_link_both_directions"] = out["pageable"]["GBps_each_way"] / both_rate
+    out["note"] = ("host pointers in and out, best of 4 calls: 16 MiB chunks over three staging slots, uploads + kernels issued by the calling thread, "
+                   "downloads by a helper thread (a pageable copy blocks its issuing thread); inputs are NOT resident, so this is never `value`")
+    return out
+
+
 def main():
     args = parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -382,7 +511,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return [float(v) for v in t.tolist()]
 
-    events = [codec.event_create() for _ in range(max(K, 8) + 1)]
+    events = [codec.event_create() for _ in range(max(K, 64) + 1)]
 
     def timed_leg(fn, steps=None, warmup=None):
         """fn() enqueues one step on `stream`.  Returns dict(wall_s, ms_per_step, kernel_ms_mean, kernel_ms_median)."""
@@ -420,15 +549,21 @@ def main():
         """fraction of the HBM peak from the mean launch duration of the timed launches"""
         return bytes_per_step / (leg["kernel_ms_mean"] * 1e-3) / HBM_PEAK_BYTES_PER_S
 
-    def roofline(leg, bytes_per_unit, n_units, traffic=None, traffic_source=None):
+    def roofline(leg, bytes_per_unit, n_units, traffic=None, traffic_source=None, box_kind="copy"):
         achieved = bytes_per_unit * n_units / (leg["kernel_ms_mean"] * 1e-3)
         return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": traffic, "traffic_source": traffic_source,
+                "frac": achieved / HBM_PEAK_BYTES_PER_S, "frac_of_same_box_%s" % box_kind: of_box(achieved, box_kind),
+                "traffic": traffic, "traffic_source": traffic_source,
                 "kernel_ms_per_launch": leg["kernel_ms_mean"], "kernel_ms_median": leg["kernel_ms_median"],
                 "kernel_ms_per_launch_is": "HIP events on the launching stream around the timed launches; with several ranks the slowest rank's mean",
                 "frac_by_rank": [bytes_per_unit * n_units / (m * 1e-3) / HBM_PEAK_BYTES_PER_S for m in leg["kernel_ms_mean_by_rank"]] if leg.get("kernel_ms_mean_by_rank") else None,
                 "frac_at_median": bytes_per_unit * n_units / (leg["kernel_ms_median"] * 1e-3) / HBM_PEAK_BYTES_PER_S,
                 "algorithmic_bytes_per_launch": bytes_per_unit * n_units}
+
+    def hbm2(leg, bytes_per_step, box_kind="copy"):
+        """{hbm_frac, frac_of_same_box_<kind>} of a leg"""
+        achieved = bytes_per_step / (leg["kernel_ms_mean"] * 1e-3)
+        return {"hbm_frac": achieved / HBM_PEAK_BYTES_PER_S, "frac_of_same_box_%s" % box_kind: of_box(achieved, box_kind)}
 
     def brief(leg):
         return {k: leg[k] for k in ("ms_per_step", "kernel_ms_mean", "kernel_ms_median")}
@@ -438,6 +573,23 @@ def main():
     z = torch.empty_like(x)
     codec.fill_residual_dev(x.data_ptr(), n_dct * 1024, DCT_SEED, rank * n_dct * 1024, stream)
     torch.cuda.synchronize()
+
+    # ---- what THIS box's memory system gives the streaming launch shape, with no arithmetic (xHipMemCeilingDev): the same-run
+    # reference every HBM-bound leg is also expressed in, because boxes of the pool differ by 3-10 % in what a plain stream reaches
+    ceil_bytes = n_dct * 2048
+    ceil_legs = {}
+    for kind, name, moved in ((0, "copy", 2 * ceil_bytes), (1, "read", ceil_bytes), (3, "read_probe", ceil_bytes), (2, "write", ceil_bytes)):
+        leg = timed_leg(lambda k=kind: codec.mem_ceiling_dev(k, x.data_ptr(), z.data_ptr(), ceil_bytes, stream), steps=min(K, 40), warmup=min(W, 10))
+        ceil_legs[name] = moved / (leg["kernel_ms_mean"] * 1e-3)
+    same_box = {"copy_TBps": ceil_legs["copy"] / 1e12, "read_TBps": ceil_legs["read"] / 1e12, "read_no_store_TBps": ceil_legs["read_probe"] / 1e12,
+                "write_TBps": ceil_legs["write"] / 1e12,
+                "how": "xHipMemCeilingDev on the headline input / output buffers (%d MiB), HIP-event mean of the timed launches, slowest rank: nontemporal 16 B/lane "
+                       "streams in the launch shape that measured fastest for each (copy = the transform kernels' pattern, read = one XOR checksum per 2 KiB, "
+                       "read_no_store = the same loads with nothing flowing back, write = the intra predictor's pattern)" % (ceil_bytes >> 20)}
+
+    def of_box(achieved_bytes_per_s, kind):
+        """fraction of this box's own stream of that kind"""
+        return achieved_bytes_per_s / ceil_legs[kind]
 
     head = timed_leg(lambda: codec.dct32_fwd_dev(x.data_ptr(), z.data_ptr(), n_dct, stream))
     value = rate(head, n_dct)
@@ -478,6 +630,7 @@ def main():
                              "events recorded on the launching stream around those same K launches"},
         "roofline": roofline(head, DCT_BYTES_PER_BLOCK, n_dct, pmc.get("dct32_fwd_bytes_per_launch"), pmc_src),
     }
+    result["roofline"]["same_box"] = same_box
 
     # ---- checksum of the forward output across ranks (validates the sharded run) ----------------
     csum = int(z.view(torch.int16).to(torch.int64).sum().item())
@@ -500,7 +653,7 @@ def main():
         # ---- fused forward + inverse: coefficients and reconstruction from one pass (6144 B per block)
         z2 = torch.empty_like(x)
         leg = timed_leg(lambda: codec.dct32_fwd_inv_dev(x.data_ptr(), z2.data_ptr(), r.data_ptr(), n_dct, stream))
-        also["dct32_fwd_inv_fused"] = dict(value=rate(leg, n_dct), unit="blocks/s", **brief(leg), hbm_frac=hbm(leg, 6144.0 * n_dct),
+        also["dct32_fwd_inv_fused"] = dict(value=rate(leg, n_dct), unit="blocks/s", **brief(leg), **hbm2(leg, 6144.0 * n_dct),
                                            same_bytes_as_two_kernels=bool(torch.equal(z2, z)),
                                            note="2 KiB in, 2 + 2 KiB out per block; hbm_frac from the HIP-event mean of the timed launches")
         del r, z2
@@ -510,7 +663,7 @@ def main():
         codec.fill_residual_dev(d.data_ptr(), n_satd * 64, SATD_SEED, rank * n_satd * 64, stream)
         leg = timed_leg(lambda: codec.satd8x8_dev(d.data_ptr(), s.data_ptr(), n_satd, stream))
         also["satd8x8"] = dict(value=rate(leg, n_satd), unit="blocks/s", blocks_per_gpu=n_satd, **brief(leg),
-                               roofline=roofline(leg, SATD_BYTES_PER_BLOCK, n_satd, pmc.get("satd8x8_bytes_per_launch"), pmc_src))
+                               roofline=roofline(leg, SATD_BYTES_PER_BLOCK, n_satd, pmc.get("satd8x8_bytes_per_launch"), pmc_src, box_kind="read"))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from _util import Oracle
@@ -549,28 +702,37 @@ def main():
             origin = refp.data_ptr() + pad * refp.stride(0) + pad
             ncand = nb * (2 * rng + 1) ** 2
             me_steps = max(4, K // 4)
-            leg = timed_leg(lambda: codec.satd_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream),
-                            steps=me_steps, warmup=2)
+            with SclkSampler(torch) as clk:
+                leg = timed_leg(lambda: codec.satd_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream),
+                                steps=max(me_steps, 40), warmup=2)
             mv = best.view(torch.int16).view(nb, 4)[:, :2]
             found = float(((mv[:, 0] == 5) & (mv[:, 1] == -3)).float().mean().item())
-            # VALU floor: 32 x v_sad_u16 (4 cycles per wave64 instruction, tools/alubench) per 64 candidates
-            floor_s = ncand / 64 * 32 * 4 / (4 * info_cu * 2.4e9)
+            # VALU floor: 32 x v_sad_u16 (4 cycles per wave64 instruction, tools/alubench) per 64 candidates, at the 2.4 GHz the part is
+            # specified for and -- where sysfs shows it -- at the shader clock this box sustained during the leg
+            cycles = ncand / 64 * 32 * 4 / (4 * info_cu)
+            floor_s = cycles / 2.4e9
+            sclk = clk.mhz()
             also["satd8x8_me_search"] = dict(
                 value=rate(leg, ncand), unit="SATD/s", ms_per_frame=leg["ms_per_step"], **brief(leg),
                 frame="%dx%d luma, 8x8 blocks, window +-%d (%d candidates per block)" % (w, h, rng, (2 * rng + 1) ** 2),
                 bound="VALU issue (v_sad_u16), not HBM: ~18 MB of compulsory traffic per frame",
                 frac_of_v_sad_u16_floor=floor_s / (leg["kernel_ms_mean"] * 1e-3),
+                sclk_mhz=sclk, frac_of_v_sad_u16_floor_at_sclk=(cycles / (sclk * 1e6) / (leg["kernel_ms_mean"] * 1e-3)) if sclk else None,
                 frac_of_v_sad_u16_floor_wallclock=floor_s / (leg["ms_per_step"] * 1e-3),
                 planted_mv_found_fraction=found,
                 parity="per-candidate cost pinned by satd8x8 (src_tb/satd.c); harness (order, tie-break, padding) unpinned")
             # the same search with the SAD metric
-            leg = timed_leg(lambda: codec.sad_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream),
-                            steps=me_steps, warmup=2)
+            with SclkSampler(torch) as clk:
+                leg = timed_leg(lambda: codec.sad_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream),
+                                steps=max(me_steps, 60), warmup=2)
             mv = best.view(torch.int16).view(nb, 4)[:, :2]
-            floor_sad = ncand / 64 * 16 * 4 / (4 * info_cu * 2.4e9)
+            cycles_sad = ncand / 64 * 16 * 4 / (4 * info_cu)
+            floor_sad = cycles_sad / 2.4e9
+            sclk = clk.mhz()
             also["sad8x8_me_search"] = dict(
                 value=rate(leg, ncand), unit="SAD/s", ms_per_frame=leg["ms_per_step"], **brief(leg),
                 frac_of_v_sad_u8_floor=floor_sad / (leg["kernel_ms_mean"] * 1e-3),
+                sclk_mhz=sclk, frac_of_v_sad_u8_floor_at_sclk=(cycles_sad / (sclk * 1e6) / (leg["kernel_ms_mean"] * 1e-3)) if sclk else None,
                 planted_mv_found_fraction=float(((mv[:, 0] == 5) & (mv[:, 1] == -3)).float().mean().item()),
                 parity="metric = sad() of riscv/programs/benchmarks/sad/sad.c at n = 8; harness unpinned, as for the SATD search")
             del big, sm
@@ -588,7 +750,7 @@ def main():
                     else:
                         fn = lambda tt=ttype, nn=n, cnt=nblk: codec.transform_fwd_dev(tt, nn, x.data_ptr(), zt.data_ptr(), cnt, 0, stream)
                     leg = timed_leg(fn, steps=short, warmup=3)
-                    ts["%s_%dx%d" % (tname, n, n)] = dict(value=rate(leg, nblk), unit="blocks/s", hbm_frac=hbm(leg, 4.0 * n * n * nblk), **brief(leg))
+                    ts["%s_%dx%d" % (tname, n, n)] = dict(value=rate(leg, nblk), unit="blocks/s", **hbm2(leg, 4.0 * n * n * nblk), **brief(leg))
             # per-CTU mixed batch: every 64x64 CTU's 32x32 quadrants cycle through the seven (type, size) classes
             n_ctu = (n_dct * 1024) // 4096
             q = torch.arange(n_ctu * 4, device="cuda", dtype=torch.int64)
@@ -601,7 +763,7 @@ def main():
             for inv_flag, name in ((0, "per_ctu_one_launch"), (1, "per_ctu_one_launch_inverse")):
                 leg = timed_leg(lambda f=inv_flag: codec.transform_tiles_dev(f, x.data_ptr(), zt.data_ptr(), n_ctu * 4, 0, tile_cls.data_ptr(), stream),
                                 steps=short, warmup=3)
-                per_ctu[name] = dict(value=rate(leg, n_ctu), unit="CTUs/s", hbm_frac=hbm(leg, 4.0 * n_ctu * 4096), **brief(leg))
+                per_ctu[name] = dict(value=rate(leg, n_ctu), unit="CTUs/s", **hbm2(leg, 4.0 * n_ctu * 4096), **brief(leg))
             # comparison only: the same buffer as seven per-class calls over offset tables
             mixed = []
             for kind, (tt, n) in enumerate(((0, 32), (0, 16), (1, 16), (0, 8), (1, 8), (0, 4), (1, 4))):
@@ -614,7 +776,7 @@ def main():
                 for tt, nn, o in mixed:
                     codec.transform_fwd_dev(tt, nn, x.data_ptr(), zt.data_ptr(), o.numel(), o.data_ptr(), stream)
             leg = timed_leg(ctu_pass, steps=short, warmup=3)
-            per_ctu["seven_calls_over_offset_tables"] = dict(value=rate(leg, n_ctu), unit="CTUs/s", hbm_frac=hbm(leg, 4.0 * n_ctu * 4096),
+            per_ctu["seven_calls_over_offset_tables"] = dict(value=rate(leg, n_ctu), unit="CTUs/s", **hbm2(leg, 4.0 * n_ctu * 4096),
                                                              note="comparison only; the one-launch form above is the configs[3] path", **brief(leg))
             del zt, mixed, q, qbase, qkind, tile_cls
             also["transform_set"] = {"classes": ts, "per_ctu_mixed": per_ctu, "parity": "unpinned upstream except DCT-II 32; bit-exact vs this repo's oracle",
@@ -648,7 +810,7 @@ def main():
                 leg = timed_leg(fn, steps=short, warmup=3)
                 fused[name] = dict(value=rate(leg, units), unit="blocks/s", **brief(leg))
                 if bytes_per_unit:
-                    fused[name]["hbm_frac"] = hbm(leg, bytes_per_unit * units)
+                    fused[name].update(hbm2(leg, bytes_per_unit * units, "read" if name.startswith("satd") else "copy"))
             fused["note"] = ("%dx%d tiled frame pair (x266.cpp ref_block_t); fused kernels are bit-identical to the two-kernel paths "
                              "listed next to them (tests/test_gpu_tiles.py)" % (fw, fh))
             also["fused_from_tiles"] = fused
@@ -675,7 +837,7 @@ def main():
                     ("sad_16x16", 2.0 * npx + 4.0 * (npx // 256), lambda: codec.sad_dev(16, ypl.data_ptr(), t_b.data_ptr(), sad_o.data_ptr(), npx // 256, stream)),
                     ("sad_64x64", 2.0 * npx + 4.0 * (npx // 4096), lambda: codec.sad_dev(64, ypl.data_ptr(), t_b.data_ptr(), sad_o.data_ptr(), npx // 4096, stream))):
                 leg = timed_leg(fn, steps=short, warmup=3)
-                front[name] = dict(GBps=world * nbytes * leg["steps"] / leg["wall_s"] / 1e9, hbm_frac=hbm(leg, nbytes),
+                front[name] = dict(GBps=world * nbytes * leg["steps"] / leg["wall_s"] / 1e9, **hbm2(leg, nbytes, "read" if name.startswith("sad") else "copy"),
                                    samples_per_s=world * npx * leg["steps"] / leg["wall_s"], **brief(leg))
             front["note"] = ("%dx%d frame; bytes = planes read + tile bytes written (conv), luma of both tile frames + int16 residual "
                              "(residual), both blocks + 4-byte result (sad)" % (fw2, fh2))
@@ -697,7 +859,8 @@ def main():
             intra = {}
             leg = timed_leg(lambda: codec.intra32_predict_dev(refs_t.data_ptr(), modes_t.data_ptr(), index_t.data_ptr(), pred_t.data_ptr(), n_sets * 35, stream),
                             steps=short, warmup=3)
-            intra["predict"] = dict(value=rate(leg, n_sets * 35), unit="predictions/s", written_hbm_frac=hbm(leg, 1024.0 * n_sets * 35), **brief(leg))
+            intra["predict"] = dict(value=rate(leg, n_sets * 35), unit="predictions/s", written_hbm_frac=hbm(leg, 1024.0 * n_sets * 35),
+                                    frac_of_same_box_write=of_box(1024.0 * n_sets * 35 / (leg["kernel_ms_mean"] * 1e-3), "write"), **brief(leg))
             leg = timed_leg(lambda: codec.intra32_costs_dev(refs_t.data_ptr(), src_t.data_ptr(), cost_t.data_ptr(), bestm_t.data_ptr(), n_dec, stream),
                             steps=short, warmup=3)
             intra["decide_35_modes"] = dict(value=rate(leg, n_dec), unit="blocks/s", satd8x8_per_s=rate(leg, n_dec) * 35 * 16, **brief(leg))
@@ -705,13 +868,19 @@ def main():
             also["intra32"] = intra
             del refs_t, modes_t, index_t, pred_t, src_t, cost_t, bestm_t
 
+        # ---- the literal drop-in path: host pointers in, host pointers out (xDct32FwdBatch, what INTEGRATION.md section 2 tells an
+        # x266.cpp maintainer to call, src/x266.cpp:526-555), PCIe-inclusive -- never `value`
+        if rank == 0 and world == 1 and not args.no_host_api:
+            also["host_api"] = host_api_leg(codec, torch, min(n_dct, 1 << 17))
+
         # ---- the node layer of the C ABI: BASELINE configs[4] and the other end-to-end scatter/gather figures.
         # These legs are the only ones that talk RCCL from this library; a communication hang must not cost the whole
         # line, so they run under a watchdog: past --node-timeout seconds rank 0 prints the JSON with what it has
         # (the legs marked as timed out) and every rank leaves.
         result["also"] = also
         result["secondary"] = {"metric": "satd8x8_blocks_per_s", "value": also["satd8x8"]["value"], "unit": "blocks/s",
-                               "roofline_frac": also["satd8x8"]["roofline"]["frac"]}
+                               "roofline_frac": also["satd8x8"]["roofline"]["frac"],
+                               "frac_of_same_box_read": also["satd8x8"]["roofline"]["frac_of_same_box_read"]}
         if (ctrl == "cuda" or os.environ.get("X266HIP_RCCL_LIB")) and args.stream8k > 0:
             def node_timed_out():
                 also["node_layer_error"] = "node-layer legs did not finish within %.0f s (RCCL hang?); line printed without them" % args.node_timeout
@@ -739,7 +908,7 @@ def main():
                 also["rccl_by_rank"] = infos                                # which library each rank's node layer talks to (torch's bundled one or ROCm's)
                 fw8, fh8 = 7680, 4320
                 nd8, ns8 = (fw8 // 32) * (fh8 // 32), (fw8 // 8) * (fh8 // 8)
-                IN_RING, OUT_RING = 4, 5
+                IN_RING, OUT_RING = 4, 5                                  # X266_STREAM_IN_RING / X266_STREAM_OUT_RING (include/x266hip.h)
                 fin = fout = None
                 if rank == 0:
                     fin = [(torch.empty(nd8 * 1024, dtype=torch.int16, device="cuda"), torch.empty(ns8 * 64, dtype=torch.int16, device="cuda")) for _ in range(IN_RING)]

@@ -21,8 +21,8 @@
 
 #include "../include/x266hip.h"
 
-#define IN_RING 4
-#define OUT_RING 5
+#define IN_RING X266_STREAM_IN_RING
+#define OUT_RING X266_STREAM_OUT_RING
 
 #define CHECK(call) do { int rc_ = (call); if (rc_ != X266HIP_OK) { fprintf(stderr, "%s failed: %d (%s | %s)\n", #call, rc_, \
     node ? xHipNodeLastError(node) : "", hip ? xHipLastError(hip) : ""); return 1; } } while (0)

@@ -20,8 +20,8 @@
 
 #include "../include/x266hip.h"
 
-#define IN_RING 4
-#define OUT_RING 5
+#define IN_RING X266_STREAM_IN_RING
+#define OUT_RING X266_STREAM_OUT_RING
 #define N_VAL (OUT_RING + 2)
 #define MAX_RANKS 64
 

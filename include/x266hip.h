@@ -155,6 +155,20 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
  * not to be called concurrently with other calls on the context.  The 32-point DCT-II cannot be replaced. */
 int xTransformSetMatrix(x266hip_ctx *ctx, int slot, int size, const int8_t *m);
 int xTransformGetMatrix(const x266hip_ctx *ctx, int slot, int size, int8_t *m);
+/* Named contents of slot 1 at all three sizes at once (slot 0 stays the DCT-II), through the same mechanism and with the
+ * same all-or-nothing behaviour as xTransformSetMatrix:
+ *   X266_PRESET_CLOSED_FORM  the built-in closed-form DST-VII (what a fresh context has)
+ *   X266_PRESET_VTM_DST7     H.266's DST-VII integers as recalled from the VTM sources (DEFINE_DST7_P8/P16_MATRIX; N = 4 is the
+ *                            closed form) -- marked "as recalled, unverified offline": the build environment holds neither the
+ *                            standard nor VTM; a host that has the normative tables should install them with xTransformSetMatrix
+ *   X266_PRESET_VTM_DCT8     DCT-VIII, H.266's third MTS kernel, as the flipped, sign-alternated DST-VII of the preset above:
+ *                            T8[k][n] = (-1)^k T7[k][N-1-n]; with it the type codes X266_TR_DST7* mean DCT-VIII
+ * xTransformPreset returns the preset slot 1 holds, or -1 after xTransformSetMatrix on slot 1. */
+#define X266_PRESET_CLOSED_FORM 0
+#define X266_PRESET_VTM_DST7    1
+#define X266_PRESET_VTM_DCT8    2
+int xTransformUsePreset(x266hip_ctx *ctx, int preset);
+int xTransformPreset(const x266hip_ctx *ctx);
 /* Inverse transforms of the same set (no upstream counterpart): columns first, shifts 7 and 12
  * (8-bit video), int16 clipping after each pass; (DCT-II, 32) contiguous is xDct32InvBatchDev.
  * d_offsets as in the forward call. */
@@ -266,6 +280,10 @@ int xFillResidualDev(x266hip_ctx *ctx, int16_t *d_dst, size_t n_samples,
 /* internal device buffers in chunks, H2D / kernel / D2H overlapped).         */
 /* Synchronous: results are in `out` on return.                               */
 /* ------------------------------------------------------------------------ */
+/* Rates over a PCIe 5.0 x16 link that gives 57 GB/s one way and 48.5 GB/s each way when both directions run: 43 GB/s each way
+ * from PINNED host buffers (xHipHostAlloc below, hipHostMalloc, or memory the host registered), 27 GB/s each way from pageable ones
+ * -- the runtime stages pageable copies through the calling thread, so uploads and downloads take turns
+ * (profiles/r04_hostpipe.txt).  A host that re-uses its buffers should allocate them pinned. */
 int xDct32FwdBatch(x266hip_ctx *ctx, const int16_t *in, int16_t *out, size_t n_blocks);
 int xDct32InvBatch(x266hip_ctx *ctx, const int16_t *in, int16_t *out, size_t n_blocks);
 int xSatd8x8Batch(x266hip_ctx *ctx, const int16_t *diff, uint32_t *out, size_t n_blocks);
@@ -274,6 +292,9 @@ int xSatd8x8Batch(x266hip_ctx *ctx, const int16_t *diff, uint32_t *out, size_t n
 /* device memory / stream helpers for hosts without HIP headers               */
 /* ------------------------------------------------------------------------ */
 int xHipMalloc(x266hip_ctx *ctx, void **d_ptr, size_t bytes);
+/* Page-locked host memory (hipHostMalloc) for the host-pointer batch calls and xHipMemcpy*: copies from / to it are true DMA. */
+int xHipHostAlloc(x266hip_ctx *ctx, void **h_ptr, size_t bytes);
+int xHipHostFree(x266hip_ctx *ctx, void *h_ptr);
 int xHipFree(x266hip_ctx *ctx, void *d_ptr);
 int xHipMemcpyH2D(x266hip_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 int xHipMemcpyD2H(x266hip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
@@ -294,8 +315,8 @@ int xHipGraphLaunch(x266hip_ctx *ctx, x266hip_graph *graph, void *stream);
 void xHipGraphFree(x266hip_ctx *ctx, x266hip_graph *graph);
 /* Times `reps` back-to-back launches of one kernel with HIP events recorded on
  * `stream` itself; returns the mean milliseconds per launch in *ms_per_launch.
- * op: 0 = dct32 fwd, 1 = dct32 inv, 2 = satd8x8 (buffers as in the Dev calls); 3 / 4 / 5 = xHipMemCeilingDev copy / read /
- * write of n_blocks * 2048 bytes. */
+ * op: 0 = dct32 fwd, 1 = dct32 inv, 2 = satd8x8 (buffers as in the Dev calls); 3 .. 6 = xHipMemCeilingDev copy / read /
+ * write / read probe of n_blocks * 2048 bytes. */
 int xHipTimeKernel(x266hip_ctx *ctx, int op, const void *d_in, void *d_out,
                    size_t n_blocks, int reps, void *stream, double *ms_per_launch);
 /* What THIS box's memory system gives the launch shape of the streaming kernels, with no arithmetic -- so that a report can
@@ -305,11 +326,15 @@ int xHipTimeKernel(x266hip_ctx *ctx, int op, const void *d_in, void *d_out,
  * 32-bit XOR of the words of every 2 KiB piece, d_dst[piece] as uint32 (so d_dst holds 4 * ceil(bytes / 2048) bytes: the
  * pattern of the SATD / SAD kernels; the checksums make the stream checkable); X266_MEM_WRITE: nothing read (d_src may be
  * NULL), every 16-byte chunk c of d_dst = {(uint32)c, 0, 0, 0} with the same stores (the pattern of the intra predictor).
+ * X266_MEM_READ_PROBE: X266_MEM_READ that stores a piece's XOR only where it equals X266_MEM_PROBE_MAGIC, i.e. practically
+ * never: the rate of loads with nothing flowing back (a host that wants to see the loads happen plants a piece with that XOR).
  * bytes a multiple of 16, buffers 16-byte aligned.
- * Asynchronous on `stream`; time it with the event calls below or xHipTimeKernel's ops 3 / 4 / 5. */
+ * Asynchronous on `stream`; time it with the event calls below or xHipTimeKernel's ops 3 / 4 / 5 / 6. */
 #define X266_MEM_COPY 0
 #define X266_MEM_READ 1
 #define X266_MEM_WRITE 2
+#define X266_MEM_READ_PROBE 3
+#define X266_MEM_PROBE_MAGIC 0x12345678u
 int xHipMemCeilingDev(x266hip_ctx *ctx, int kind, const void *d_src, void *d_dst, size_t bytes, void *stream);
 /* HIP events for hosts without HIP headers, so that ANY sequence of the ...Dev calls can be timed on the
  * stream it is launched on (record an event before every launch and one after the last: consecutive
@@ -398,7 +423,12 @@ void xNodeStreamFree(x266hip_nstream *s);
  * overwritten once THREE later steps have been issued (or its ticket has been waited for): until then its buffers belong
  * to the stream -- the kernels of three consecutive frames run on three streams and may overlap (only a third frame in
  * flight covers the ramp and tail of ~30 us kernels), so frames t, t+1 and t+2 must not share buffers: input rings of four,
- * output rings of five or more.  *ticket (may be NULL) receives t. */
+ * output rings of five or more (X266_STREAM_IN_RING / X266_STREAM_OUT_RING; they grew by one when the stream went from two to three
+ * frames in flight, so a host sizes its rings by the constants, not by a number).  Input buffers may be SHARED between frames (they
+ * are only read); an output buffer that overlaps the output of one of the previous X266_STREAM_OUT_RING - 1 frames of this stream
+ * -- frames not yet flushed -- is refused with X266HIP_EINVAL: two frames in flight would write it.  *ticket (may be NULL) receives t. */
+#define X266_STREAM_IN_RING  4
+#define X266_STREAM_OUT_RING 5
 int  xNodeStreamPush(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units,
                      void *producer_stream, long *ticket);
 /* The root-device stream on which the NEXT pushed frame's kernels will run (NULL on processes that do not drive the

@@ -21,24 +21,16 @@ def fuzz(n):
                     suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow, HealthCheck.data_too_large])
 
 OPTIONS = {
-    "nontemporal": st.sampled_from([0, 1, 2, 3, 8, 10, 11]),
     "adaptive_per_wave": st.integers(0, 1),
-    "dct32_lds_stage": st.integers(0, 1),
-    "satd_lds_stage": st.integers(0, 1),
-    "tr_lds_stage": st.integers(0, 1),
     "dct32_variant": st.sampled_from([0, 2]),
-    "satd_variant": st.sampled_from([0, 2]),
+    "satd_variant": st.sampled_from([0, 1, 2, 3]),
     "dct32_blocks_per_wave": st.integers(1, 9),
     "dct32_inv_blocks_per_wave": st.integers(1, 9),
     "dct32_fwdinv_blocks_per_wave": st.integers(1, 9),
-    "satd_groups_per_wave": st.integers(1, 9),
-    "tr_tiles_per_wave": st.integers(1, 5),
-    "wg_threads": st.sampled_from([64, 128, 192, 256]),
+    "satd_groups_per_wave": st.integers(0, 9),
     "dct32_wg_threads": st.sampled_from([64, 128, 192, 256]),
-    "dct32_inv_wg_threads": st.sampled_from([64, 128, 192, 256]),
-    "satd_wg_threads": st.sampled_from([64, 128, 192, 256]),
-    "dct32_lds_bytes_per_wave": st.sampled_from([2048, 4096, 8192, 12288]),
-    "satd_lds_bytes_per_wave": st.sampled_from([4096, 6144, 8192]),
+    "satd_wg_threads": st.sampled_from([0, 64, 128, 192, 256]),
+    "satd_lds_bytes_per_wave": st.sampled_from([0, 4096, 6144, 9216, 16384]),
 }
 
 
@@ -81,12 +73,12 @@ def test_dct_and_satd_random_sizes_and_options(codec, oracle, n, kind, seed, opt
 
 @fuzz(25)
 @given(ttype=st.integers(0, 1), size=st.sampled_from([4, 8, 16]), n=st.integers(1, 3000), kind=st.integers(0, 1), seed=st.integers(1, 1 << 30),
-       stage=st.integers(0, 1), tpw=st.integers(1, 4))
-def test_transform_set_random(codec, oracle, ttype, size, n, kind, seed, stage, tpw):
-    saved = {k: codec.get_option(k) for k in ("tr_lds_stage", "tr_tiles_per_wave", "adaptive_per_wave")}
+       tpb=st.sampled_from([64, 128, 192, 256]), per_wave=st.integers(1, 4))
+def test_transform_set_random(codec, oracle, ttype, size, n, kind, seed, tpb, per_wave):
+    saved = {k: codec.get_option(k) for k in ("dct32_wg_threads", "dct32_inv_blocks_per_wave", "adaptive_per_wave")}
     try:
-        codec.set_option("tr_lds_stage", stage)
-        codec.set_option("tr_tiles_per_wave", tpw)
+        codec.set_option("dct32_wg_threads", tpb)
+        codec.set_option("dct32_inv_blocks_per_wave", per_wave)          # tiles per wave of the inverse family
         codec.set_option("adaptive_per_wave", seed & 1)
         x = _data(kind, n, size * size, seed)
         fwd = oracle.transform_fwd(ttype, size, x)
@@ -169,11 +161,10 @@ def test_mixed_class_tiles_random(codec, oracle, n_tiles, seed, inverse, tpw, tp
     x = _data(kind, n_tiles, 1024, seed)
     if inverse and kind != 0:
         x = (x >> 2).astype(np.int16)                                    # keep coefficients in a sane range (clipping is still exercised by kind 2)
-    saved = {k: codec.get_option(k) for k in ("tile_tiles_per_wave", "dct32_wg_threads", "dct32_inv_wg_threads")}
+    saved = {k: codec.get_option(k) for k in ("tile_tiles_per_wave", "dct32_wg_threads")}
     try:
         codec.set_option("tile_tiles_per_wave", tpw)
         codec.set_option("dct32_wg_threads", tpb)
-        codec.set_option("dct32_inv_wg_threads", tpb)
         din, dout, dcls = codec.alloc(n_tiles * 2048), codec.alloc(n_tiles * 2048), codec.alloc(max(n_tiles, 16))
         din.upload(x)
         dcls.upload(cls)
@@ -204,15 +195,14 @@ def test_one_dimensional_pass_random(codec, oracle, n, shift, kind, seed):
 
 @fuzz(25)
 @given(n_dct=st.integers(0, 700), n_satd=st.integers(0, 9000), kind=st.integers(0, 2), seed=st.integers(1, 1 << 30),
-       gpw=st.integers(1, 9), nt=st.sampled_from([0, 3, 11]))
-def test_frame_lanes_random(codec, oracle, n_dct, n_satd, kind, seed, gpw, nt):
+       gpw=st.integers(0, 9))
+def test_frame_lanes_random(codec, oracle, n_dct, n_satd, kind, seed, gpw):
     """xDct32SatdFrameDev (round 3): both lanes of a frame in one grid, random and ragged counts on either side (zero included),
     random SATD run length per wave -- equal to the oracle's two transforms."""
     x, d = _data(kind, max(n_dct, 1), 1024, seed), _data(kind, max(n_satd, 1), 64, seed + 1)
-    saved = {k: codec.get_option(k) for k in ("satd_groups_per_wave", "nontemporal")}
+    saved = {k: codec.get_option(k) for k in ("satd_groups_per_wave",)}
     try:
         codec.set_option("satd_groups_per_wave", gpw)
-        codec.set_option("nontemporal", nt)
         din, dout = codec.alloc(x.nbytes), codec.alloc(x.nbytes)
         sin, sout = codec.alloc(d.nbytes), codec.alloc(max(n_satd, 4) * 4)
         din.upload(x)

@@ -27,6 +27,20 @@ def test_streams_move_every_byte(codec, nbytes):
     padded[: src.size] = src
     want = np.bitwise_xor.reduce(padded.reshape(pieces, 512), axis=1)
     assert np.array_equal(d_sum.download(np.uint32, pieces), want)
+    # the probe reads the same bytes and stores nothing -- unless a piece's XOR is the magic: plant it in the last whole piece
+    d_sum.upload(np.zeros(pieces + 4, np.uint32))
+    codec.mem_ceiling_dev(3, d_src.ptr, d_sum.ptr, nbytes)
+    codec.stream_sync()
+    assert not d_sum.download(np.uint32, pieces).any()
+    if nbytes >= 2048:
+        hit = nbytes // 2048 - 1
+        src2 = src.copy()
+        src2[hit * 512] ^= want[hit] ^ np.uint32(0x12345678)
+        d_src.upload(src2)
+        codec.mem_ceiling_dev(3, d_src.ptr, d_sum.ptr, nbytes)
+        codec.stream_sync()
+        got3 = d_sum.download(np.uint32, pieces)
+        assert got3[hit] == 0x12345678 and not np.delete(got3, hit).any()
     codec.mem_ceiling_dev(2, 0, d_dst.ptr, nbytes)
     codec.stream_sync()
     got = d_dst.download(np.uint32, nbytes // 4 + 4)
@@ -37,6 +51,6 @@ def test_streams_move_every_byte(codec, nbytes):
 
 def test_bad_arguments_are_refused(codec):
     d = codec.alloc(4096)
-    for kind, src, dst, n in ((3, d.ptr, d.ptr, 64), (0, d.ptr + 4, d.ptr + 2048, 64), (0, d.ptr, d.ptr + 2048, 24), (1, 0, d.ptr, 64)):
+    for kind, src, dst, n in ((4, d.ptr, d.ptr, 64), (0, d.ptr + 4, d.ptr + 2048, 64), (0, d.ptr, d.ptr + 2048, 24), (1, 0, d.ptr, 64)):
         with pytest.raises(x266_amd.X266Error):
             codec.mem_ceiling_dev(kind, src, dst, n)

@@ -71,6 +71,33 @@ def test_frame_stream_is_bit_exact(node, oracle, w, h, n_frames):
     st.close()
 
 
+def test_output_buffer_of_a_frame_in_flight_is_refused(node, oracle):
+    """buffer ownership is checked, not only documented -- an output buffer that overlaps the output of one of the previous
+    X266_STREAM_OUT_RING - 1 frames still in flight is EINVAL (inputs may be shared: they are only read); a flush or a waited ticket
+    gives the buffers back."""
+    dev = torch.device("cuda", 0)
+    st = node.stream([OP_DCT32_FWD], [8])
+    x = torch.from_numpy(oracle.fill_residual(8 * 1024, 3)).to(dev)
+    outs = [torch.zeros(8 * 1024, dtype=torch.int16, device=dev) for _ in range(5)]
+    torch.cuda.synchronize()
+    t0 = st.push([x.data_ptr()], [outs[0].data_ptr()])
+    for back in (1, 2, 3, 4):                                            # frame `back` steps later, same output: refused every time
+        with pytest.raises(x266_amd.X266Error, match="in flight"):
+            st.push([x.data_ptr()], [outs[0].data_ptr() + 2048 * 3], [5])   # a partial overlap counts
+        st.push([x.data_ptr()], [outs[back].data_ptr()])                 # the same INPUT is fine
+    st.push([x.data_ptr()], [outs[0].data_ptr()])                        # five frames later: legal
+    st.wait(t0 + 3)
+    st.push([x.data_ptr()], [outs[1].data_ptr()])                        # frames <= t0 + 3 are complete: their outputs may be reused at once
+    st.flush()
+    want = oracle.dct32_fwd(x.cpu().numpy()).ravel()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), want)
+    st.push([x.data_ptr()], [outs[0].data_ptr()])                        # after a flush nothing is in flight
+    st.push([x.data_ptr()], [outs[1].data_ptr()])
+    st.flush()
+    st.close()
+
+
 def test_stream_takes_ragged_unit_counts_and_inverse_lane(node, oracle):
     dev = torch.device("cuda", 0)
     st = node.stream([OP_DCT32_INV, OP_SATD8X8, OP_DCT32_FWD], [40, 1000, 40])
@@ -320,3 +347,165 @@ def test_plain_c_host_with_one_process_per_rank(n_ranks, size):
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["processes"] == n_ranks and d["bit_exact_vs_single_device"] is True and d["frames"] == 12
+
+
+# ---- the real thing: two or more devices (BASELINE configs[4]) ---------------------------------------------------------
+# Engages on any box that shows >= 2 gfx950 devices and reports as skipped (with the reason) on the one-GPU boxes: single-process
+# node over REAL RCCL between distinct HBMs (transport 0 -- no peer-copy fallback, no model), the process-per-rank twin from plain
+# C, bench.py --gpus N without torchrun on the command line, and a deliberately slow peer with the input ring overwritten at the
+# documented distance.  Everything is compared bit for bit with the single-device calls.
+def _device_count():
+    return int(x266_amd.load_library().xHipDeviceCount())
+
+
+@pytest.fixture(scope="module")
+def real_node():
+    n = _device_count()
+    if n < 2:
+        pytest.skip("multi-device tier: this box shows %d HIP device(s); it engages from 2" % n)
+    assert "X266HIP_RCCL_LIB" not in os.environ, "the multi-device tier must talk to the real RCCL"
+    node = Node.single_process(list(range(n)))
+    node.set_option("transport", 0)                   # fails if RCCL did not initialise (the library would have fallen back to peer copies)
+    ver, path = Node.rccl_info()
+    assert ver > 0 and "rccl_model" not in path, (ver, path)
+    yield node
+    node.close()
+
+
+def test_multi_device_self_test_and_world(real_node):
+    n = _device_count()
+    assert real_node.world == n and real_node.local_ranks == list(range(n)) and real_node.drives_root
+    real_node.self_test()                             # ring send/recv between distinct devices + all-reduce, checked word by word
+
+
+@pytest.mark.parametrize("w,h,n_frames", [(96, 160, 9), (7680, 4320, 7)])
+def test_multi_device_frame_stream_over_rccl(real_node, codec, oracle, w, h, n_frames):
+    """The configs[4] stream at its own size over real xGMI: every frame of every lane equals the single-device calls (and the
+    first frame the oracle), tickets waited two steps later as documented."""
+    n_d, n_s = (w // 32) * (h // 32), (w // 8) * (h // 8)
+    dev = torch.device("cuda", 0)
+    st = real_node.frame_stream(w, h)
+    xin = [(torch.from_numpy(_frame(oracle, n_d * 1024, 0x266, f)).to(dev), torch.from_numpy(_frame(oracle, n_s * 64, 0x267, f)).to(dev)) for f in range(n_frames)]
+    want = []
+    for a, b in xin:
+        c, e = torch.empty_like(a), torch.empty(n_s, dtype=torch.int32, device=dev)
+        codec.dct32_fwd_dev(a.data_ptr(), c.data_ptr(), n_d)
+        codec.satd8x8_dev(b.data_ptr(), e.data_ptr(), n_s)
+        want.append((c, e))
+    torch.cuda.synchronize()
+    assert np.array_equal(want[0][0].cpu().numpy(), oracle.dct32_fwd(xin[0][0].cpu().numpy(), threads=32).ravel())
+    assert np.array_equal(want[0][1].cpu().numpy(), oracle.satd8x8(xin[0][1].cpu().numpy(), threads=32).astype(np.int32))
+    out = [(torch.zeros(n_d * 1024, dtype=torch.int16, device=dev), torch.zeros(n_s, dtype=torch.int32, device=dev)) for _ in range(n_frames)]
+    torch.cuda.synchronize()
+    tickets = []
+    for f in range(n_frames):
+        tickets.append(st.push([xin[f][0].data_ptr(), xin[f][1].data_ptr()], [out[f][0].data_ptr(), out[f][1].data_ptr()]))
+        if f >= 2:
+            st.wait(tickets[f - 2])
+            assert torch.equal(out[f - 2][0], want[f - 2][0]) and torch.equal(out[f - 2][1], want[f - 2][1]), f - 2
+    st.flush()
+    for f in range(n_frames):
+        assert torch.equal(out[f][0], want[f][0]) and torch.equal(out[f][1], want[f][1]), f
+    st.close()
+
+
+def test_multi_device_batch_scatter_gather_and_sharded_search(real_node, codec, oracle):
+    dev = torch.device("cuda", 0)
+    for op, n, chunk in ((OP_DCT32_FWD, 100003, 0), (OP_SATD8X8, 2000001, 0), (OP_DCT32_INV, 4099, 1000)):
+        unit = 64 if op == OP_SATD8X8 else 1024
+        tin = torch.empty(n * unit, dtype=torch.int16, device=dev)
+        codec.fill_residual_dev(tin.data_ptr(), tin.numel(), 0x300 + op)
+        tout = torch.zeros(n if op == OP_SATD8X8 else n * 1024, dtype=torch.int32 if op == OP_SATD8X8 else torch.int16, device=dev)
+        ref = torch.empty_like(tout)
+        {OP_DCT32_FWD: codec.dct32_fwd_dev, OP_DCT32_INV: codec.dct32_inv_dev, OP_SATD8X8: codec.satd8x8_dev}[op](tin.data_ptr(), ref.data_ptr(), n)
+        torch.cuda.synchronize()
+        real_node.batch_scatter_gather(op, tin.data_ptr(), tout.data_ptr(), n, chunk)
+        assert torch.equal(tout, ref), op
+    w, h, rng = 1920, 1088, 32
+    cur, refp = me_frames(w, h, rng, 0x53, mv=(4, -1))
+    tc, tr = torch.from_numpy(cur).to(dev), torch.from_numpy(refp).to(dev)
+    nb = (h // 8) * (w // 8)
+    origin = tr.data_ptr() + rng * tr.stride(0) + rng
+    single = torch.zeros(nb * 2, dtype=torch.int32, device=dev)
+    codec.satd_search_dev(tc.data_ptr(), tc.stride(0), origin, tr.stride(0), w, h, rng, single.data_ptr())
+    torch.cuda.synchronize()
+    for n_stripes in (0, real_node.world + 3, 1):
+        best = torch.zeros(nb * 2, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        real_node.satd_search(tc.data_ptr(), tc.stride(0), origin, tr.stride(0), w, h, rng, n_stripes, best.data_ptr())
+        assert torch.equal(best, single), n_stripes
+
+
+def test_multi_device_slow_peer_and_input_ring_reuse(real_node, codec):
+    """The run-ahead hazard on real hardware: the last rank's device is kept busy with full-frame motion searches (its frame kernels
+    lag by milliseconds) while the root pushes 7680x4320 frames from an input ring of X266_STREAM_IN_RING buffers that are REFILLED
+    with the next frame's content as early as the header allows (once three later steps have been issued) and an output ring of
+    X266_STREAM_OUT_RING.  Every frame must still equal the single-device result."""
+    IN_RING, OUT_RING, n_frames = 4, 5, 40
+    w, h = 7680, 4320
+    n_d, n_s = (w // 32) * (h // 32), (w // 8) * (h // 8)
+    dev = torch.device("cuda", 0)
+    peer_index = real_node.world - 1
+    peer = real_node.rank_codec(peer_index)
+    pdev = torch.device("cuda", peer_index)
+    sw, sh, srng = 3840, 2160, 64
+    pc = torch.randint(0, 256, (sh, sw), device=pdev, dtype=torch.int32).to(torch.uint8)
+    pr = torch.randint(0, 256, (sh + 2 * srng, sw + 2 * srng), device=pdev, dtype=torch.int32).to(torch.uint8)
+    pbest = torch.empty((sh // 8) * (sw // 8) * 2, dtype=torch.int32, device=pdev)
+    pstream = peer.stream_create()
+    torch.cuda.synchronize(pdev)
+
+    def frame_input(f, a, b, stream):
+        codec.fill_residual_dev(a.data_ptr(), a.numel(), 0x266, f * 100000007, stream)
+        codec.fill_residual_dev(b.data_ptr(), b.numel(), 0x267, f * 100000007, stream)
+
+    fin = [(torch.empty(n_d * 1024, dtype=torch.int16, device=dev), torch.empty(n_s * 64, dtype=torch.int16, device=dev)) for _ in range(IN_RING)]
+    fout = [(torch.zeros(n_d * 1024, dtype=torch.int16, device=dev), torch.zeros(n_s, dtype=torch.int32, device=dev)) for _ in range(OUT_RING)]
+    producer = codec.stream_create()
+    st = real_node.frame_stream(w, h)
+    got = []
+    tickets = []
+    for f in range(n_frames):
+        if f % 4 == 0:                                  # ~2.3 ms of search per call on the peer's device: it stays behind for the whole run
+            for _ in range(6):
+                peer.satd_search_dev(pc.data_ptr(), pc.stride(0), pr.data_ptr() + srng * pr.stride(0) + srng, pr.stride(0), sw, sh, srng, pbest.data_ptr(), 0, pstream)
+        a, b = fin[f % IN_RING]
+        frame_input(f, a, b, producer)                  # overwrites frame f - IN_RING's input: exactly three later steps (f-3, f-2, f-1) have been issued
+        c, e = fout[f % OUT_RING]
+        tickets.append(st.push([a.data_ptr(), b.data_ptr()], [c.data_ptr(), e.data_ptr()], producer_stream=producer))
+        if f >= 2:
+            st.wait(tickets[f - 2])
+            c2, e2 = fout[(f - 2) % OUT_RING]
+            got.append((c2.clone(), e2.clone()))
+    st.flush()
+    for f in (n_frames - 2, n_frames - 1):
+        c2, e2 = fout[f % OUT_RING]
+        got.append((c2.clone(), e2.clone()))
+    torch.cuda.synchronize()
+    peer.stream_sync(pstream)
+    st.close()
+    a, b = fin[0]
+    c1, e1 = torch.empty_like(fout[0][0]), torch.empty_like(fout[0][1])
+    for f in range(n_frames):
+        frame_input(f, a, b, 0)
+        codec.dct32_fwd_dev(a.data_ptr(), c1.data_ptr(), n_d)
+        codec.satd8x8_dev(b.data_ptr(), e1.data_ptr(), n_s)
+        torch.cuda.synchronize()
+        assert torch.equal(got[f][0], c1) and torch.equal(got[f][1], e1), f
+    codec.stream_destroy(producer)
+    peer.stream_destroy(pstream)
+
+
+def test_multi_device_process_per_rank_from_plain_c():
+    """host/stream8k_ranks: one process per visible device, real RCCL (ncclCommInitRank over the id rank 0 hands out), 7680x4320."""
+    n = _device_count()
+    if n < 2:
+        pytest.skip("multi-device tier: this box shows %d HIP device(s); it engages from 2" % n)
+    exe = os.path.join(ROOT, "host", "stream8k_ranks")
+    assert os.path.exists(exe), "host/stream8k_ranks is not built (make -C host)"
+    env = {k: v for k, v in os.environ.items() if k != "X266HIP_RCCL_LIB"}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([exe, "0", "60", "7680", "4320"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["processes"] == n and d["bit_exact_vs_single_device"] is True and d["frames"] == 60

@@ -145,11 +145,11 @@ def test_dct32_roundtrip_on_device(codec):
 def test_dct32_fused_fwd_inv(codec, oracle, n, per_wave, tpb, with_coef):
     """xDct32FwdInvBatchDev == forward then inverse, bit for bit (coefficients and reconstruction),
     on realistic residuals and on full-range int16 (the inverse's clipping paths)."""
-    saved = {k: codec.get_option(k) for k in ("dct32_fwdinv_blocks_per_wave", "dct32_inv_wg_threads", "adaptive_per_wave")}
+    saved = {k: codec.get_option(k) for k in ("dct32_fwdinv_blocks_per_wave", "dct32_wg_threads", "adaptive_per_wave")}
     try:
         codec.set_option("adaptive_per_wave", 0)                                    # small batches: keep the multi-block loop
         codec.set_option("dct32_fwdinv_blocks_per_wave", per_wave)
-        codec.set_option("dct32_inv_wg_threads", tpb)
+        codec.set_option("dct32_wg_threads", tpb)
         for x in (_mixed(n, 1024, 900 + n), dct_edge_blocks()[0]):
             m = x.shape[0]
             din, dco, dre = codec.alloc(m * 2048), codec.alloc(m * 2048), codec.alloc(m * 2048)
@@ -236,35 +236,55 @@ def test_argument_errors(codec):
     assert L.xDct32FwdBatchDev(codec.ctx, buf.ptr + 2, buf.ptr, 1, None) < 0        # misaligned
     assert L.xSatd8x8Batch(codec.ctx, None, None, 3) < 0
     assert L.xHipSetOption(codec.ctx, b"no_such_option", 1) < 0
-    for key, bad in ((b"dct32_wg_threads", 96), (b"dct32_wg_threads", 512), (b"dct32_blocks_per_wave", 0), (b"nontemporal", 16),
-                     (b"dct32_lds_bytes_per_wave", 1024), (b"me_tile_rows", 9)):
+    for key, bad in ((b"dct32_wg_threads", 96), (b"dct32_wg_threads", 512), (b"dct32_blocks_per_wave", 0), (b"satd_variant", 4),
+                     (b"satd_lds_bytes_per_wave", 1 << 20), (b"me_tile_rows", 9), (b"nontemporal", 11), (b"dct32_lds_stage", 0)):   # the last two: keys of rounds 1-3, gone
         assert L.xHipSetOption(codec.ctx, key, bad) < 0, key                     # out of range: rejected, value unchanged
     assert codec.get_option("dct32_wg_threads") == 64
     assert b"" != L.xHipLastError(codec.ctx)
 
 
-@pytest.mark.parametrize("nt,tpb,per_wave,stage", [
-    (0, 64, 1, 0), (4, 256, 3, 0), (3, 128, 16, 0), (11, 192, 7, 0), (7, 64, 1, 0),
-    (0, 64, 1, 1), (3, 256, 3, 1), (1, 128, 16, 1), (2, 192, 7, 1), (11, 64, 5, 1), (0, 256, 2, 1)])
-def test_launch_geometry_options_do_not_change_results(codec, oracle, nt, tpb, per_wave, stage):
+@pytest.mark.parametrize("tpb,per_wave,satd_variant,satd_lds", [
+    (64, 1, 0, 0), (256, 3, 1, 4096), (128, 16, 3, 9216), (192, 7, 3, 16384), (64, 5, 1, 12288), (256, 2, 3, 0), (128, 8, 0, 0)])
+def test_launch_geometry_options_do_not_change_results(codec, oracle, tpb, per_wave, satd_variant, satd_lds):
+    """Every launch option is an A/B knob: workgroup sizes, units per wave, the LDS charge and which of the two SATD batch kernels runs
+    (satd_variant 1 = staged, 3 = LDS-DMA, 0 = by batch size) never change a result."""
     x = residual_np(3001 * 1024, 0x266).reshape(-1, 1024)
     d = x.reshape(-1, 64)[:100003]
-    keys = ("adaptive_per_wave", "nontemporal", "wg_threads", "satd_wg_threads", "dct32_wg_threads", "dct32_inv_wg_threads", "dct32_lds_stage", "satd_lds_stage", "dct32_blocks_per_wave",
-            "dct32_inv_blocks_per_wave", "satd_groups_per_wave")
+    keys = ("adaptive_per_wave", "satd_wg_threads", "dct32_wg_threads", "dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "satd_groups_per_wave",
+            "satd_variant", "satd_lds_bytes_per_wave")
     saved = {k: codec.get_option(k) for k in keys}
     try:
-        codec.set_option("nontemporal", nt)
         codec.set_option("adaptive_per_wave", 0)
-        for k in ("wg_threads", "satd_wg_threads", "dct32_wg_threads", "dct32_inv_wg_threads"):
+        for k in ("satd_wg_threads", "dct32_wg_threads"):
             codec.set_option(k, tpb)
-        codec.set_option("dct32_lds_stage", stage)
-        codec.set_option("satd_lds_stage", stage)
         for k in ("dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "satd_groups_per_wave"):
             codec.set_option(k, per_wave)
+        codec.set_option("satd_variant", satd_variant)
+        codec.set_option("satd_lds_bytes_per_wave", satd_lds)
         z = oracle.dct32_fwd(x, threads=8)
         assert np.array_equal(codec.dct32_fwd(x), z)
         assert np.array_equal(codec.dct32_inv(z), oracle.dct32_inv(z, threads=8))
         assert np.array_equal(codec.satd8x8(d), oracle.satd8x8(d, threads=8))
+    finally:
+        for k, v in saved.items():
+            codec.set_option(k, v)
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 1000, 4097, 65537])
+def test_both_satd_batch_kernels_on_ragged_full_range_batches(codec, oracle, variant, n):
+    """The staged kernel (small and medium batches) and the LDS-DMA kernel (from 3 Mi blocks on) forced onto the same ragged batches
+    of full-range int16 (wraparound included), with 1, 3, 8 and 9 groups per wave: the DMA kernel's last partly filled group, its
+    eight-group cost store and its two-slot pipeline all have their own edges."""
+    d = fullrange_np(n * 64, 7000 + n).reshape(-1, 64)
+    want = oracle.satd8x8(d)
+    saved = {k: codec.get_option(k) for k in ("satd_variant", "satd_groups_per_wave", "adaptive_per_wave")}
+    try:
+        codec.set_option("satd_variant", variant)
+        for adaptive, gpw in ((0, 1), (0, 3), (0, 8), (0, 9), (1, 0)):
+            codec.set_option("adaptive_per_wave", adaptive)
+            codec.set_option("satd_groups_per_wave", gpw)
+            assert np.array_equal(codec.satd8x8(d), want), (variant, n, adaptive, gpw)
     finally:
         for k, v in saved.items():
             codec.set_option(k, v)

@@ -93,6 +93,32 @@ def test_recalled_h266_dst7(fresh, oracle, n):
     check_everywhere(fresh, oracle, n, fresh.get_transform_matrix(0, n).astype(np.int16), m.astype(np.int16))
 
 
+@pytest.mark.parametrize("n", [4, 8, 16])
+def test_named_presets(fresh, oracle, n):
+    """xTransformUsePreset: the recalled VTM DST-VII and the DCT-VIII derived from it (T8[k][c] = (-1)^k T7[k][N-1-c]) in slot 1 at
+    all sizes at once; every entry point of the set then equals the oracle's passes with the same matrices; preset 0 restores."""
+    assert fresh.transform_preset() == 0
+    closed = fresh.get_transform_matrix(1, n).copy()
+    dct2 = fresh.get_transform_matrix(0, n).astype(np.int16)
+    t7 = recalled_dst7(fresh, n) if n > 4 else closed                              # N = 4: the closed form is the standard's table
+    fresh.use_transform_preset(1)
+    assert fresh.transform_preset() == 1 and np.array_equal(fresh.get_transform_matrix(1, n), t7)
+    assert np.array_equal(fresh.get_transform_matrix(0, n).astype(np.int16), dct2)   # slot 0 untouched
+    check_everywhere(fresh, oracle, n, dct2, t7.astype(np.int16))
+    fresh.use_transform_preset(2)
+    t8 = (t7[:, ::-1].astype(np.int16) * ((-1) ** np.arange(n))[:, None]).astype(np.int8)
+    assert fresh.transform_preset() == 2 and np.array_equal(fresh.get_transform_matrix(1, n), t8)
+    g = t8.astype(np.int32) @ t8.astype(np.int32).T                                  # a near-orthogonal basis of norm ~ 64 sqrt(N) like the others
+    assert abs(g - np.diag(np.diag(g))).max() < 0.05 * g.diagonal().min()
+    check_everywhere(fresh, oracle, n, dct2, t8.astype(np.int16))
+    fresh.set_transform_matrix(1, n, t7)
+    assert fresh.transform_preset() == -1                                            # a caller's own matrix is not a preset
+    fresh.use_transform_preset(0)
+    assert fresh.transform_preset() == 0 and np.array_equal(fresh.get_transform_matrix(1, n), closed)
+    with pytest.raises(x266_amd.X266Error):
+        fresh.use_transform_preset(3)
+
+
 def test_defaults_and_restore(fresh, oracle, codec):
     """Built-ins = the oracle's tables; NULL restores them; other contexts are not affected; bad arguments are rejected."""
     for n in (4, 8, 16):

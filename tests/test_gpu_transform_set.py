@@ -13,15 +13,8 @@ CLASSES = [(0, 4), (0, 8), (0, 16), (0, 32), (1, 4), (1, 8), (1, 16)]
 MIXED = [(2, 4), (2, 8), (2, 16), (3, 4), (3, 8), (3, 16)]
 
 
-@pytest.fixture(params=[1, 0], ids=["staged", "direct"])
-def staging(request, codec):
-    codec.set_option("tr_lds_stage", request.param)
-    yield request.param
-    codec.set_option("tr_lds_stage", 1)
-
-
 @pytest.mark.parametrize("ttype,n", CLASSES + MIXED)
-def test_contiguous_batches(codec, oracle, ttype, n, staging):
+def test_contiguous_batches(codec, oracle, ttype, n):
     per = n * n
     x = np.concatenate([residual_np(3001 * per, 50 + n), fullrange_np(2000 * per, 51 + n),
                         extremes_np(500 * per, 52 + n)]).reshape(-1, per)
@@ -30,7 +23,7 @@ def test_contiguous_batches(codec, oracle, ttype, n, staging):
 
 @pytest.mark.parametrize("ttype,n", [c for c in CLASSES + MIXED if c[1] < 32])
 @pytest.mark.parametrize("count", [1, 2, 3, 5, 15, 16, 17, 63, 64, 65, 127, 129])
-def test_ragged_counts(codec, oracle, ttype, n, count, staging):
+def test_ragged_counts(codec, oracle, ttype, n, count):
     x = fullrange_np(count * n * n, 900 + count + n).reshape(count, n * n)
     assert np.array_equal(codec.transform_fwd(ttype, n, x), oracle.transform_fwd(ttype, n, x))
 

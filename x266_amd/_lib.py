@@ -11,6 +11,7 @@ _SZ = ctypes.c_size_t
 _U64 = ctypes.c_uint64
 
 OP_DCT32_FWD, OP_DCT32_INV, OP_SATD8X8 = 0, 1, 2
+PRESET_CLOSED_FORM, PRESET_VTM_DST7, PRESET_VTM_DCT8 = 0, 1, 2
 
 
 class X266Error(RuntimeError):
@@ -49,6 +50,7 @@ def load_library():
     L.xHipCodecInit.argtypes = [ctypes.POINTER(_P), ctypes.c_int]
     L.xHipCodecFree.argtypes = [_P]
     L.xHipCodecFree.restype = None
+    L.xHipDeviceCount.restype = ctypes.c_int
     L.xHipDeviceInfo.argtypes = [_P, ctypes.c_char_p, _SZ, ctypes.POINTER(ctypes.c_int),
                                  ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_SZ)]
     L.xHipSetOption.argtypes = [_P, ctypes.c_char_p, ctypes.c_int]
@@ -79,6 +81,8 @@ def load_library():
     L.xDct32SatdFrameDev.argtypes = [_P, _P, _P, _SZ, _P, _P, _SZ, _P]
     L.xTransformSetMatrix.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P]
     L.xTransformGetMatrix.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P]
+    L.xTransformUsePreset.argtypes = [_P, ctypes.c_int]
+    L.xTransformPreset.argtypes = [_P]
     L.xHipMeScratchReserve.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int]
     L.xSatd8x8SearchDev.argtypes = [_P, _P, ctypes.c_ssize_t, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, _P, _P, _P]
@@ -88,6 +92,8 @@ def load_library():
         getattr(L, name).argtypes = [_P, _P, _P, _SZ]
     L.xHipMalloc.argtypes = [_P, ctypes.POINTER(_P), _SZ]
     L.xHipFree.argtypes = [_P, _P]
+    L.xHipHostAlloc.argtypes = [_P, ctypes.POINTER(_P), _SZ]
+    L.xHipHostFree.argtypes = [_P, _P]
     L.xHipMemcpyH2D.argtypes = [_P, _P, _P, _SZ]
     L.xHipMemcpyD2H.argtypes = [_P, _P, _P, _SZ]
     L.xHipStreamSync.argtypes = [_P, _P]
@@ -168,9 +174,19 @@ class Codec:
                             "libx266hip has no CPU path" % (device, rc))
         self.ctx = ctx
 
+    @classmethod
+    def borrowed(cls, ctx_ptr):
+        """A view of a context somebody else owns (xHipNodeCtx: a node rank's context, freed with the node)."""
+        self = cls.__new__(cls)
+        self.L = load_library()
+        self.ctx = _P(ctx_ptr)
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "ctx", None):
-            self.L.xHipCodecFree(self.ctx)
+            if not getattr(self, "_borrowed", False):
+                self.L.xHipCodecFree(self.ctx)
             self.ctx = None
 
     def __del__(self):
@@ -353,6 +369,13 @@ class Codec:
         assert m.shape == (size, size)
         self._check(self.L.xTransformSetMatrix(self.ctx, slot, size, m.ctypes.data), "xTransformSetMatrix")
 
+    def use_transform_preset(self, preset):
+        """0 closed-form DST-VII (built-in), 1 H.266 DST-VII as recalled from VTM, 2 DCT-VIII derived from it -- slot 1, all sizes"""
+        self._check(self.L.xTransformUsePreset(self.ctx, int(preset)), "xTransformUsePreset")
+
+    def transform_preset(self):
+        return self.L.xTransformPreset(self.ctx)
+
     def get_transform_matrix(self, slot, size):
         m = np.empty((size, size), np.int8)
         self._check(self.L.xTransformGetMatrix(self.ctx, slot, size, m.ctypes.data), "xTransformGetMatrix")
@@ -456,3 +479,35 @@ class Codec:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def host_alloc(self, shape, dtype):
+        """A numpy array in page-locked host memory (xHipHostAlloc): the host-pointer batch calls move it by DMA (43 GB/s each way
+        instead of 27 from pageable memory).  The array owns the allocation through its base object."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = _P()
+        self._check(self.L.xHipHostAlloc(self.ctx, ctypes.byref(p), max(n * dtype.itemsize, 1)), "xHipHostAlloc")
+        owner = _PinnedBlock(self, p.value, (ctypes.c_char * max(n * dtype.itemsize, 1)).from_address(p.value))
+        arr = np.frombuffer(owner.buf, dtype=dtype, count=n).reshape(shape)
+        owner.keep(arr)
+        return arr
+
+
+class _PinnedBlock:
+    """Frees a pinned allocation when the last numpy view of it is gone."""
+    _live = {}
+
+    def __init__(self, codec, ptr, buf):
+        self.codec, self.ptr, self.buf = codec, ptr, buf
+
+    def keep(self, arr):
+        import weakref
+        _PinnedBlock._live[self.ptr] = self
+        weakref.finalize(arr, _PinnedBlock._release, self.ptr)
+
+    @staticmethod
+    def _release(ptr):
+        blk = _PinnedBlock._live.pop(ptr, None)
+        if blk is not None and getattr(blk.codec, "ctx", None):
+            blk.buf = None
+            blk.codec.L.xHipHostFree(blk.codec.ctx, ptr)

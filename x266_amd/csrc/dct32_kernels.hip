@@ -31,9 +31,11 @@
 //    each lane finishes with 16 consecutive coefficients of one output row:
 //    two 16-byte stores per lane, same address pattern as the loads.
 //
-// Kernels in this file: dct32_lds_kernel (default: LDS-staged line-dense traffic, forward / inverse),
+// Kernels in this file: dct32_lds_kernel (LDS-staged line-dense traffic, forward / inverse),
 // dct32_fwdinv_lds_kernel (coefficients + reconstruction in one pass), dct32_from_tiles_kernel
-// (residual formation fused in), dct32_kernel (direct fragment loads: A/B only).
+// (residual formation fused in), dct32_pass_kernel (the 1-D pass by itself, for checking).  The direct
+// fragment-load forms and the variants without cache-policy hints of rounds 1-3 are gone: every A/B they
+// served is frozen in profiles/r01_*.txt (line-dense traffic +9 %, "nt" loads / "sc1 nt" stores +3-5 %).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -48,87 +50,14 @@ namespace {
 // ---- inverse ---------------------------------------------------------------
 // T[u][y] = clip16((sum_v g[v][y] Z[v][u] + 64)   >> 7)      (columns first)
 // R[y][x] = clip16((sum_u g[u][x] T[u][y] + 2048) >> 12)
-// The first contraction runs over the ROW index of the loaded block, which a
-// row-per-lane fragment cannot feed; the block is first transposed on the
-// matrix core (data x permuted identity: Dt[v][c] = Z[v][kappa(c)]), one MFMA
-// per byte plane, whose accumulators are again input-operand shaped.
-// row-per-lane input (no LDS): transpose both planes on the matrix core first
-__device__ __forceinline__ void inv_block(const v4i &w0, const v4i &w1, const LaneConsts &k,
-                                          const v16i &c2r, v4i &o0, v4i &o1)
-{
-    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    v4i lo, hi;
-    split_planes(w0, w1, lo, hi);
-    // values stay single bytes: no carries between planes
-    const v16i thi = mfma(hi, k.tr, zero);
-    const v16i tlo = mfma(lo, k.tr, zero);
-    inv_passes(pack_bytes(tlo), pack_bytes(thi), k, c2r, o0, o1);
-}
+// The first contraction runs over the ROW index of the loaded block, which a row-per-lane fragment cannot
+// feed: with the tile staged in LDS each lane reads its COLUMN instead (see dct32_lds_kernel).
 
-// ---- kernel ----------------------------------------------------------------
+// ---- kernels ---------------------------------------------------------------
 // Each wave transforms blocks_per_wave consecutive blocks, one wave per chunk, a grid as large as
 // the batch: the hardware dispatcher then walks the batch in address order,
 // which is what HBM likes best (a plain one-element-per-thread copy is ~15 % faster on this chip than
-// any persistent grid-stride copy; the persistent launch of rounds 1-2 is gone for that reason).
-// The next block's loads are issued before the current block's arithmetic
-// (two register sets in ping-pong).
-// MODE 0 forward, 1 inverse, 2 pass-through (diagnostic only: same loads, stores and loop,
-// no arithmetic -- measures what the memory system gives this launch shape)
-template <int MODE, bool NT>
-__global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ in,
-                                                    int16_t *__restrict__ out, size_t n_blocks,
-                                                    const DctOps *__restrict__ ops,
-                                                    unsigned blocks_per_wave)
-{
-    const int lane = threadIdx.x & 63;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    size_t b = wave * blocks_per_wave;
-    const size_t stride = 1;
-    const size_t end = b + blocks_per_wave < n_blocks ? b + blocks_per_wave : n_blocks;
-    if (b >= end) return;
-
-    const size_t lane_off = (size_t)(lane & 31) * 64 + (size_t)(lane >> 5) * 32;   // bytes
-    const char *src = reinterpret_cast<const char *>(in) + lane_off;
-    char *dst = reinterpret_cast<char *>(out) + lane_off;
-
-    // first block's loads go out before the operand images are fetched
-    v4i a0 = load16<NT>(src + b * 2048), a1 = load16<NT>(src + b * 2048 + 16);
-
-    const LaneConsts k = load_consts(ops, lane);
-    v16i c2r;
-    constexpr bool INVERSE = MODE == 1;
-    if (INVERSE) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c2r[r] = ops->c2r[lane][r];
-    }
-    v4i b0 = a0, b1 = a1, o0, o1;
-    while (true) {
-        size_t nb = b + stride;
-        if (nb < end) {
-            b0 = load16<NT>(src + nb * 2048);
-            b1 = load16<NT>(src + nb * 2048 + 16);
-        }
-        if (MODE == 1)      inv_block(a0, a1, k, c2r, o0, o1);
-        else if (MODE == 0) fwd_block<4, 11>(a0, a1, k, o0, o1);
-        else                { o0 = a0 ^ k.p1; o1 = a1 ^ k.p2; }
-        store16<NT>(dst + b * 2048, o0);
-        store16<NT>(dst + b * 2048 + 16, o1);
-        if (nb >= end) break;
-        b = nb;
-        nb = b + stride;
-        if (nb < end) {
-            a0 = load16<NT>(src + nb * 2048);
-            a1 = load16<NT>(src + nb * 2048 + 16);
-        }
-        if (MODE == 1)      inv_block(b0, b1, k, c2r, o0, o1);
-        else if (MODE == 0) fwd_block<4, 11>(b0, b1, k, o0, o1);
-        else                { o0 = b0 ^ k.p1; o1 = b1 ^ k.p2; }
-        store16<NT>(dst + b * 2048, o0);
-        store16<NT>(dst + b * 2048 + 16, o1);
-        if (nb >= end) break;
-        b = nb;
-    }
-}
+// any persistent grid-stride copy).  The next block's loads are issued before the current block's arithmetic.
 
 // ---- LDS-staged variant -------------------------------------------------------
 // Same arithmetic; the difference is what the memory system sees.  A row-per-lane
@@ -144,7 +73,7 @@ __global__ __launch_bounds__(256) void dct32_kernel(const int16_t *__restrict__ 
 // no barrier, only the in-order LDS queue of the wave itself.
 // (lds_slot itself lives in x266_mfma_blocks.hpp: the fused frame kernel of satd_kernels.hip stages DCT32 tiles the same way)
 
-template <int MODE, int NT = 0>
+template <bool INVERSE>
 __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restrict__ in,
                                                         int16_t *__restrict__ out, size_t n_blocks,
                                                         const DctOps *__restrict__ ops,
@@ -174,10 +103,10 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
     const char *src = reinterpret_cast<const char *>(in) + lane * 16;
     char *dst = reinterpret_cast<char *>(out) + lane * 16;
 
-    v4i g0 = load16<(NT & 1) != 0>(src + b * 2048), g1 = load16<(NT & 1) != 0>(src + b * 2048 + 1024);
+    v4i g0 = load16<true>(src + b * 2048), g1 = load16<true>(src + b * 2048 + 1024);
     const LaneConsts k = load_consts(ops, lane);
     v16i c2r;
-    if (MODE == 1) {
+    if (INVERSE) {
         // the pass-B constants depend on (half, register) only: two scalar loads (wave-uniform
         // addresses) and a per-lane select instead of 64 bytes of vector loads per lane and wave
         const int *__restrict__ s0 = ops->c2r[0], *__restrict__ s1 = ops->c2r[32];
@@ -189,15 +118,14 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
         *reinterpret_cast<v4i *>(slot + lin0) = g0;
         *reinterpret_cast<v4i *>(slot + lin1) = g1;
         if (nb < end) {                                        // next tile's loads fly under this tile's arithmetic
-            g0 = load16<(NT & 1) != 0>(src + nb * 2048);
-            g1 = load16<(NT & 1) != 0>(src + nb * 2048 + 1024);
+            g0 = load16<true>(src + nb * 2048);
+            g1 = load16<true>(src + nb * 2048 + 1024);
         }
         __builtin_amdgcn_wave_barrier();
         v4i o0, o1;
-        if (MODE == 1) {
+        if (INVERSE) {
             // The inverse contracts over the block's ROW index first: with the tile in LDS the lane
-            // simply reads its COLUMN (16 x ds_read_u16) -- the matrix-core transpose of the direct
-            // kernel (2 MFMA + 24 v_perm) is not needed.  Lane (c, h): column kappa(c), rows 16h..16h+15.
+            // simply reads its COLUMN (16 x ds_read_u16).  Lane (c, h): column kappa(c), rows 16h..16h+15.
             uint32_t w[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
@@ -211,8 +139,7 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
         } else {
             const v4i a0 = *reinterpret_cast<const v4i *>(slot + frag0);
             const v4i a1 = *reinterpret_cast<const v4i *>(slot + frag1);
-            if (MODE == 0) fwd_block<4, 11>(a0, a1, k, o0, o1);
-            else           { o0 = a0 ^ k.p1; o1 = a1 ^ k.p2; }
+            fwd_block<4, 11>(a0, a1, k, o0, o1);
         }
         __builtin_amdgcn_wave_barrier();
         *reinterpret_cast<v4i *>(slot + frag0) = o0;
@@ -221,8 +148,8 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
         __builtin_amdgcn_wave_barrier();
-        store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst + b * 2048, s0);
-        store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst + b * 2048 + 1024, s1);
+        store16_sc1nt(dst + b * 2048, s0);
+        store16_sc1nt(dst + b * 2048 + 1024, s1);
         if (nb >= end) break;
         b = nb;
     }
@@ -233,7 +160,6 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
 // algorithmic bytes) instead of 4 + 4 KiB for the two kernels back to back.  After the
 // forward passes the coefficient tile sits in the wave's LDS slot for its line-dense store anyway;
 // the inverse reads its columns from there, as the staged inverse does from a loaded tile.
-template <int NT>
 __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__restrict__ in,
                                                                int16_t *__restrict__ coef_out,
                                                                int16_t *__restrict__ recon_out, size_t n_blocks,
@@ -261,7 +187,7 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__
     const char *src = reinterpret_cast<const char *>(in) + lane * 16;
     const size_t lane_off = (size_t)lane * 16;
 
-    v4i g0 = load16<(NT & 1) != 0>(src + b * 2048), g1 = load16<(NT & 1) != 0>(src + b * 2048 + 1024);
+    v4i g0 = load16<true>(src + b * 2048), g1 = load16<true>(src + b * 2048 + 1024);
     const LaneConsts kf = load_consts(fwd_ops, lane);
     const LaneConsts ki = load_consts(inv_ops, lane);
     v16i c2r;
@@ -275,8 +201,8 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__
         *reinterpret_cast<v4i *>(slot + lin0) = g0;
         *reinterpret_cast<v4i *>(slot + lin1) = g1;
         if (nb < end) {
-            g0 = load16<(NT & 1) != 0>(src + nb * 2048);
-            g1 = load16<(NT & 1) != 0>(src + nb * 2048 + 1024);
+            g0 = load16<true>(src + nb * 2048);
+            g1 = load16<true>(src + nb * 2048 + 1024);
         }
         __builtin_amdgcn_wave_barrier();
         v4i o0, o1;
@@ -293,8 +219,8 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__
             const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
             const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
             char *dst = reinterpret_cast<char *>(coef_out) + b * 2048 + lane_off;
-            store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst, s0);
-            store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst + 1024, s1);
+            store16_sc1nt(dst, s0);
+            store16_sc1nt(dst + 1024, s1);
         }
         {
             uint32_t w[8];
@@ -317,8 +243,8 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__
             const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
             __builtin_amdgcn_wave_barrier();
             char *dst = reinterpret_cast<char *>(recon_out) + b * 2048 + lane_off;
-            store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst, s0);
-            store16m<(NT & 8) ? 2 : ((NT & 2) ? 1 : 0)>(dst + 1024, s1);
+            store16_sc1nt(dst, s0);
+            store16_sc1nt(dst + 1024, s1);
         }
         if (nb >= end) break;
         b = nb;
@@ -335,7 +261,6 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__
 // inline C operand.  A lane's fragment (row c, columns 16h..16h+15 of the 32x32 block) is exactly
 // one 16-byte luma row of one tile, so fragment loads are line-dense as they are; only the stores
 // go through the LDS slot (section "LDS-staged variant").
-template <bool NT>
 __global__ __launch_bounds__(256) void dct32_from_tiles_kernel(const x266_ref_block_t *__restrict__ cur,
                                                                const x266_ref_block_t *__restrict__ pred,
                                                                int16_t *__restrict__ out, int blocks_x, int tiles_x,
@@ -350,8 +275,8 @@ __global__ __launch_bounds__(256) void dct32_from_tiles_kernel(const x266_ref_bl
     const size_t by = blk / blocks_x, bx = blk - by * blocks_x;
     const size_t tile = (by * 2 + (c >> 4)) * (size_t)tiles_x + bx * 2 + h;
     // each instruction reads the whole 256-byte luma part of four tiles: line-dense, so streaming hints pay
-    const v4i a = load16<NT>(reinterpret_cast<const unsigned char *>(cur + tile) + (c & 15) * 16);
-    const v4i b = load16<NT>(reinterpret_cast<const unsigned char *>(pred + tile) + (c & 15) * 16);
+    const v4i a = load16<true>(reinterpret_cast<const unsigned char *>(cur + tile) + (c & 15) * 16);
+    const v4i b = load16<true>(reinterpret_cast<const unsigned char *>(pred + tile) + (c & 15) * 16);
     const LaneConsts k = load_consts(ops, lane);
     const v4i bias = {(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
     const v16i round1 = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};
@@ -365,8 +290,8 @@ __global__ __launch_bounds__(256) void dct32_from_tiles_kernel(const x266_ref_bl
     const v4i s0 = *reinterpret_cast<const v4i *>(slot + lds_slot(lane >> 2, lane & 3));
     const v4i s1 = *reinterpret_cast<const v4i *>(slot + lds_slot(16 + (lane >> 2), lane & 3));
     char *dst = reinterpret_cast<char *>(out) + blk * 2048 + lane * 16;
-    store16m<NT ? 2 : 0>(dst, s0);
-    store16m<NT ? 2 : 0>(dst + 1024, s1);
+    store16_sc1nt(dst, s0);
+    store16_sc1nt(dst + 1024, s1);
 }
 
 
@@ -406,7 +331,7 @@ __global__ __launch_bounds__(256) void dct32_pass_kernel(const int16_t *__restri
 
 // ---- launchers ---------------------------------------------------------------
 hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_blocks,
-                        const DctOps *d_ops, const DctOps *d_ops_lds_inv, const LaunchCfg &cfg, hipStream_t stream)
+                        const DctOps *d_ops, const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
     const unsigned tpb = cfg.wg_threads;                       // 64 .. 256, multiple of 64
@@ -415,26 +340,9 @@ hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_
     const size_t waves = (n_blocks + bpw - 1) / bpw;
     const size_t wgs = (waves + waves_per_wg - 1) / waves_per_wg;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    dim3 grid((unsigned)wgs), block(tpb);
-    const int mode = cfg.passthrough ? 2 : (inverse ? 1 : 0);
-    if (cfg.lds_stage) {                                       // line-dense global traffic through a private LDS slot
-        const size_t per_wave = cfg.lds_bytes_per_wave < 2048 ? 2048 : (size_t)cfg.lds_bytes_per_wave;
-        const size_t lds = waves_per_wg * per_wave + (size_t)cfg.lds_pad_bytes;
-        if (mode == 0 && (cfg.nontemporal & 11) == 11) hipLaunchKernelGGL((dct32_lds_kernel<0, 11>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
-        else if (mode == 1 && (cfg.nontemporal & 11) == 11) hipLaunchKernelGGL((dct32_lds_kernel<1, 11>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops_lds_inv, bpw);
-        else if (mode == 0 && (cfg.nontemporal & 3) == 1) hipLaunchKernelGGL((dct32_lds_kernel<0, 1>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
-        else if (mode == 0 && (cfg.nontemporal & 3) == 2) hipLaunchKernelGGL((dct32_lds_kernel<0, 2>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
-        else if (mode == 0 && (cfg.nontemporal & 3) == 3) hipLaunchKernelGGL((dct32_lds_kernel<0, 3>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
-        else if (mode == 0) hipLaunchKernelGGL((dct32_lds_kernel<0>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
-        else if (mode == 1 && (cfg.nontemporal & 3)) hipLaunchKernelGGL((dct32_lds_kernel<1, 3>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops_lds_inv, bpw);
-        else if (mode == 1) hipLaunchKernelGGL((dct32_lds_kernel<1>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops_lds_inv, bpw);
-        else                hipLaunchKernelGGL((dct32_lds_kernel<2>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
-        return hipGetLastError();
-    }
-#define X266_LAUNCH(MODE, NT) hipLaunchKernelGGL((dct32_kernel<MODE, NT>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_in, d_out, n_blocks, d_ops, bpw)
-    if (cfg.nontemporal & 4) { if (mode == 0) X266_LAUNCH(0, true); else if (mode == 1) X266_LAUNCH(1, true); else X266_LAUNCH(2, true); }
-    else                 { if (mode == 0) X266_LAUNCH(0, false); else if (mode == 1) X266_LAUNCH(1, false); else X266_LAUNCH(2, false); }
-#undef X266_LAUNCH
+    const size_t lds = waves_per_wg * (size_t)cfg.lds_bytes_per_wave;   // 2 KiB used per wave; the rest caps the resident waves per CU
+    if (inverse) hipLaunchKernelGGL(dct32_lds_kernel<true>, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
+    else         hipLaunchKernelGGL(dct32_lds_kernel<false>, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_out, n_blocks, d_ops, bpw);
     return hipGetLastError();
 }
 
@@ -455,10 +363,8 @@ hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_
     const unsigned bpw = units_per_wave_for(cfg, n_blocks);
     const size_t wpw = tpb / 64, waves = (n_blocks + bpw - 1) / bpw, wgs = (waves + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
-    if ((cfg.nontemporal & 11) == 11) hipLaunchKernelGGL((dct32_fwdinv_lds_kernel<11>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
-    else if (cfg.nontemporal & 3)     hipLaunchKernelGGL((dct32_fwdinv_lds_kernel<3>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
-    else                              hipLaunchKernelGGL((dct32_fwdinv_lds_kernel<0>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
+    const size_t lds = wpw * (size_t)cfg.lds_bytes_per_wave;
+    hipLaunchKernelGGL(dct32_fwdinv_lds_kernel, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
     return hipGetLastError();
 }
 
@@ -471,9 +377,8 @@ hipError_t launch_dct32_from_tiles(const x266_ref_block_t *d_cur, const x266_ref
     const unsigned tpb = (unsigned)cfg.wg_threads;
     const size_t wpw = tpb / 64, wgs = (n_blocks + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
-    if (cfg.nontemporal & 2) hipLaunchKernelGGL((dct32_from_tiles_kernel<true>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_cur, d_pred, d_out, blocks_x, width / 16, n_blocks, d_fwd_ops);
-    else                     hipLaunchKernelGGL((dct32_from_tiles_kernel<false>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_cur, d_pred, d_out, blocks_x, width / 16, n_blocks, d_fwd_ops);
+    const size_t lds = wpw * (size_t)cfg.lds_bytes_per_wave;
+    hipLaunchKernelGGL(dct32_from_tiles_kernel, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_cur, d_pred, d_out, blocks_x, width / 16, n_blocks, d_fwd_ops);
     return hipGetLastError();
 }
 

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void satd8x8_butterfly_kernel(const int16_t *_
 hipError_t launch_satd8x8_butterfly(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks, const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
-    const unsigned tpb = (unsigned)cfg.wg_threads;
+    const unsigned tpb = cfg.wg_threads > 0 ? (unsigned)cfg.wg_threads : 128u;
     const size_t wpw = tpb / 64, waves = (n_blocks + 63) / 64, wgs = (waves + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t per_wave = cfg.lds_bytes_per_wave < 8192 ? 8192 : (size_t)cfg.lds_bytes_per_wave;

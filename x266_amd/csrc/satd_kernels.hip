@@ -104,67 +104,11 @@ __device__ __forceinline__ uint32_t satd_group(const SatdOperands &H, const v4i 
     return (sum + 2) >> 2;
 }
 
-// The same with the two coefficient tiles strictly one after the other (a scheduling barrier keeps the compiler from interleaving
-// the two MFMA chains, which costs a second accumulator set) and the second tile's operand images derived from the first's where
-// they are used: fits 64 VGPRs, i.e. eight resident waves per SIMD instead of five.
-__device__ __forceinline__ uint32_t satd_group_seq(const SatdOperands &H, int fh, const v4i &w0, const v4i &w1, const v4i &w2, const v4i &w3)
-{
-    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    v4i lo0, hi0, lo1, hi1;
-    split_planes(w0, w1, lo0, hi0);
-    split_planes(w2, w3, lo1, hi1);
-    uint32_t sum = 0;
-#pragma unroll 1
-    for (int t = 0; t < 2; ++t) {                          // a real loop: one accumulator set, the tiles strictly in turn
-        const int ft = t ? fh : 0;
-        const v4i f = {ft, ft, ft, ft};
-        const v4i h0 = H.h00 ^ f, h1 = H.h01 ^ f;
-        v16i a = mfma(h0, hi0, zero);
-        a = mfma(h1, hi1, a);
-        a[0] = (int)(((uint32_t)a[0] << 8) + (uint32_t)(t ? 0x8000 : H.bias0));
-#pragma unroll
-        for (int r = 1; r < 16; ++r) a[r] = (int)(((uint32_t)a[r] << 8) + 0x8000u);
-        a = mfma(h0, lo0, a);
-        a = mfma(h1, lo1, a);
-        sum = abs_sum16(a, sum);
-    }
-    sum += (uint32_t)__shfl_xor((int)sum, 32);
-    return (sum + 2) >> 2;
-}
-
-template <bool NT>
-__global__ __launch_bounds__(256) void satd8x8_kernel(const int16_t *__restrict__ diff,
-                                                      uint32_t *__restrict__ out, size_t n_blocks,
-                                                      unsigned groups_per_wave)
-{
-    const int lane = threadIdx.x & 63;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const size_t n_groups = (n_blocks + 31) >> 5;           // 32 blocks per wave-iteration
-    size_t g = wave * groups_per_wave;                      // streaming launch (see dct32_kernels.hip)
-    const size_t stride = 1;
-    const size_t end = g + groups_per_wave < n_groups ? g + groups_per_wave : n_groups;
-    if (g >= end) return;
-    const int blk = lane & 31, half = lane >> 5;
-    const SatdOperands H = make_satd_operands(lane);
-
-    for (; g < end; g += stride) {
-        size_t b = g * 32 + blk;
-        const bool live = b < n_blocks;
-        if (!live) b = n_blocks - 1;                        // ragged tail: re-read the last block
-        const char *p = reinterpret_cast<const char *>(diff) + b * 128 + (size_t)half * 64;
-        const v4i w0 = load16<NT>(p), w1 = load16<NT>(p + 16);
-        const v4i w2 = load16<NT>(p + 32), w3 = load16<NT>(p + 48);
-        const uint32_t cost = satd_group(H, w0, w1, w2, w3);
-        if (live && half == 0) out[b] = cost;
-    }
-}
-
 // LDS-staged variant: the group's 4 KiB are fetched with four fully linear 1 KiB instructions
 // (whole 128-byte lines per instruction, see dct32_kernels.hip) and turned into block-per-lane
 // order through a wave-private LDS slot.  Chunk (block n, row j) lives at
 // n*128 + ((j ^ ((n >> 1) & 7)) << 4): linear writes and fragment reads are conflict-free.
 // the body, per wave: `wave` = index of the wave in the launch, `slot` = its 4 KiB of LDS
-template <bool NT, bool SEQ = false>
 __device__ __forceinline__ void satd8x8_lds_wave(const int16_t *__restrict__ diff, uint32_t *__restrict__ out, size_t n_blocks,
                                                  unsigned groups_per_wave, size_t wave, unsigned char *slot, int lane)
 {
@@ -190,57 +134,10 @@ __device__ __forceinline__ void satd8x8_lds_wave(const int16_t *__restrict__ dif
         for (int i = 0; i < 4; ++i) {
             size_t off = base + (size_t)lane * 16 + 1024 * (size_t)i;
             if (off + 16 > total_bytes) off = total_bytes - 16;       // ragged tail: stay inside the buffer
-            v[i] = load16<NT>(reinterpret_cast<const char *>(diff) + off);
+            v[i] = load16<true>(reinterpret_cast<const char *>(diff) + off);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<v4i *>(slot + lin[i]) = v[i];
-        __builtin_amdgcn_wave_barrier();
-        const v4i w0 = *reinterpret_cast<const v4i *>(slot + frag[0]), w1 = *reinterpret_cast<const v4i *>(slot + frag[1]);
-        const v4i w2 = *reinterpret_cast<const v4i *>(slot + frag[2]), w3 = *reinterpret_cast<const v4i *>(slot + frag[3]);
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t cost = SEQ ? satd_group_seq(H, half ? (int)0xFEFEFEFEu : 0, w0, w1, w2, w3) : satd_group(H, w0, w1, w2, w3);
-        const size_t b = g * 32 + blk;
-        if (b < n_blocks && half == 0) out[b] = cost;
-    }
-}
-
-// SHAPE 1: the same, with the next group's four loads issued before this group's arithmetic (register ping-pong, as the DCT32 kernel does)
-template <bool NT>
-__device__ __forceinline__ void satd8x8_lds_wave_prefetch(const int16_t *__restrict__ diff, uint32_t *__restrict__ out, size_t n_blocks,
-                                                          unsigned groups_per_wave, size_t wave, unsigned char *slot, int lane)
-{
-    const size_t n_groups = (n_blocks + 31) >> 5;
-    size_t g = wave * groups_per_wave;
-    const size_t end = g + groups_per_wave < n_groups ? g + groups_per_wave : n_groups;
-    if (g >= end) return;
-    const int blk = lane & 31, half = lane >> 5;
-    const size_t total_bytes = n_blocks * 128;
-    unsigned lin[4], frag[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned chunk = lane + 64 * i, n = chunk >> 3, j = chunk & 7;
-        lin[i] = n * 128 + ((j ^ ((n >> 1) & 7)) << 4);
-        frag[i] = blk * 128 + ((((unsigned)(4 * half + i)) ^ (((unsigned)blk >> 1) & 7)) << 4);
-    }
-    v4i v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        size_t off = g * 4096 + (size_t)lane * 16 + 1024 * (size_t)i;
-        if (off + 16 > total_bytes) off = total_bytes - 16;
-        v[i] = load16<NT>(reinterpret_cast<const char *>(diff) + off);
-    }
-    const SatdOperands H = make_satd_operands(lane);
-    for (; g < end; ++g) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<v4i *>(slot + lin[i]) = v[i];
-        if (g + 1 < end) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                size_t off = (g + 1) * 4096 + (size_t)lane * 16 + 1024 * (size_t)i;
-                if (off + 16 > total_bytes) off = total_bytes - 16;
-                v[i] = load16<NT>(reinterpret_cast<const char *>(diff) + off);
-            }
-        }
         __builtin_amdgcn_wave_barrier();
         const v4i w0 = *reinterpret_cast<const v4i *>(slot + frag[0]), w1 = *reinterpret_cast<const v4i *>(slot + frag[1]);
         const v4i w2 = *reinterpret_cast<const v4i *>(slot + frag[2]), w3 = *reinterpret_cast<const v4i *>(slot + frag[3]);
@@ -251,35 +148,31 @@ __device__ __forceinline__ void satd8x8_lds_wave_prefetch(const int16_t *__restr
     }
 }
 
-// SHAPE 2: the groups go straight from HBM into LDS (global_load_lds_dwordx4: no staging registers), two 4 KiB slots per wave
-// in ping-pong, so that group g+1 is in flight while group g is scored.  The DMA writes lane l's 16 bytes at slot + 16 l, i.e.
-// the LDS image is linear in the order of the lanes' global addresses; the bank swizzle of the fragment reads is therefore
-// applied on the GLOBAL side -- lane l of instruction i fetches chunk (n, j ^ ((n >> 1) & 7)) of its 128-byte line, n = (l + 64 i) >> 3,
-// j = l & 7: the same whole lines per instruction, permuted inside each line.
-// `group` = the group's first byte (wave-uniform: the address is an SGPR pair + the lane's constant 32-bit offset, no vector
-// address arithmetic per group); CLAMP: the batch's last, partly filled group -- lanes past the end re-read its last 16 bytes
-template <bool NT, bool CLAMP>
+// ---- large batches: the groups go straight from HBM into LDS -------------------------------------------------------------
+// global_load_lds_dwordx4 (LDS-DMA: no staging registers), two 4 KiB slots per wave in ping-pong.  The DMA writes lane l's 16
+// bytes at slot + 16 l, i.e. the LDS image is linear in the order of the lanes' global addresses; the bank swizzle of the fragment
+// reads is therefore applied on the GLOBAL side -- lane l of instruction i fetches chunk (n, j ^ ((n >> 1) & 7)) of its 128-byte
+// line, n = (l + 64 i) >> 3, j = l & 7: the same whole lines per instruction, permuted inside each line.
+// `group` = the group's first byte, wave-uniform: the address is an SGPR pair + the lane's constant 32-bit offset, no vector
+// address arithmetic per group.  CLAMP: the batch's last, partly filled group -- lanes past the end re-read its last 16 bytes.
+template <bool CLAMP>
 __device__ __forceinline__ void satd8x8_dma_issue(const char *__restrict__ group, size_t bytes_left, const unsigned (&goff)[4], unsigned char *slot)
 {
     if (!CLAMP) {
-        // SGPR-pair base + the lane's 32-bit offset, LDS destination through M0: the instructions themselves, because the compiler
-        // only produces the VGPR-pair address form here (a 64-bit vector add per load).  M0 is put back: the compiler owns it.
+        // the instructions themselves, because the compiler only produces the VGPR-pair address form here (a 64-bit vector add
+        // per load).  M0 (the LDS destination) is put back: the compiler owns it.
         const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)slot;
         unsigned keep;
-#define X266_DMA4(POLICY)                                                                                                       \
-        asm volatile("s_mov_b32 %0, m0\n\t"                                                                                     \
-                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5" POLICY "\n\t"                              \
-                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5" POLICY "\n\t"                              \
-                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5" POLICY "\n\t"                              \
-                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5" POLICY "\n\t"                              \
-                     "s_mov_b32 m0, %0"                                                                                         \
-                     : "=&s"(keep)                                                                                              \
-                     : "v"(goff[0]), "v"(goff[1]), "v"(goff[2]), "v"(goff[3]), "s"(group), "s"(lds), "s"(lds + 1024u),          \
-                       "s"(lds + 2048u), "s"(lds + 3072u)                                                                       \
-                     : "memory")
-        if (NT) X266_DMA4(" nt");
-        else    X266_DMA4("");
-#undef X266_DMA4
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5 nt\n\t"
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5 nt\n\t"
+                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5 nt\n\t"
+                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5 nt\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(goff[0]), "v"(goff[1]), "v"(goff[2]), "v"(goff[3]), "s"(group), "s"(lds), "s"(lds + 1024u),
+                       "s"(lds + 2048u), "s"(lds + 3072u)
+                     : "memory");
         return;
     }
     asm volatile("; ragged last group" ::: "memory");    // keeps this (once per launch) path a branch: if-converted into the common path it costs every group vector selects
@@ -288,21 +181,24 @@ __device__ __forceinline__ void satd8x8_dma_issue(const char *__restrict__ group
         unsigned off = goff[i];
         if ((size_t)off + 16 > bytes_left) off = (unsigned)(bytes_left - 16);   // those blocks are never stored
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(group + off),
-                                         (__attribute__((address_space(3))) void *)(slot + 1024 * i), 16, 0, NT ? 2 : 0);
+                                         (__attribute__((address_space(3))) void *)(slot + 1024 * i), 16, 0, 2 /* nt */);
     }
 }
 
-template <bool NT, int DEPTH>
-__device__ __forceinline__ void satd8x8_lds_wave_dma(const int16_t *__restrict__ diff, uint32_t *__restrict__ out, size_t n_blocks,
-                                                     unsigned first, unsigned step, unsigned count, unsigned char *slots, int lane)
+// The wave scores groups first .. first + count - 1 (clipped to the batch).  Per group: wait for its DMA, read the fragments,
+// REFILL THE SLOT AT ONCE -- before the group is scored -- so that two groups are in flight all the time, not one while the
+// wave computes; score; park the 32 costs in LDS.  The costs of up to eight groups leave as one line-dense 1 KiB store: a store
+// just before the loop's s_waitcnt vmcnt(4) would be counted by it, i.e. every iteration would wait for the previous group's
+// store to be acknowledged.  Group counters are 32-bit (the launcher refuses batches of 2^37 blocks): wave-uniform compares stay
+// on the scalar unit.  `slots`: 2 x 4 KiB of DMA slots + 1 KiB of costs.
+typedef int v4i_unaligned __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ void satd8x8_dma_wave(const int16_t *__restrict__ diff, uint32_t *__restrict__ out, size_t n_blocks,
+                                                 unsigned first, unsigned count, unsigned char *slots, int lane)
 {
-    // The wave scores groups first, first + step, ... (`count` of them, clipped to the batch).  Group counters are 32-bit (the
-    // launcher refuses batches of 2^37 blocks): wave-uniform compares stay on the scalar unit.
     const unsigned n_groups = (unsigned)((n_blocks + 31) >> 5), full_groups = (unsigned)(n_blocks >> 5);
-    unsigned g = first;
-    if (g >= n_groups) return;
-    const unsigned avail = (n_groups - g + step - 1) / step;
-    const unsigned end = g + (avail < count ? avail : count) * step;          // exclusive, in steps of `step`
+    if (first >= n_groups) return;
+    const unsigned end = n_groups - first > count ? first + count : n_groups;
     const int blk = lane & 31, half = lane >> 5;
     const char *src = reinterpret_cast<const char *>(diff);
     unsigned goff[4], frag[4];
@@ -312,61 +208,64 @@ __device__ __forceinline__ void satd8x8_lds_wave_dma(const int16_t *__restrict__
         goff[i] = n * 128 + ((j ^ ((n >> 1) & 7)) << 4);
         frag[i] = blk * 128 + ((((unsigned)(4 * half + i)) ^ (((unsigned)blk >> 1) & 7)) << 4);
     }
-    // DEPTH - 1 groups ahead of the one being scored; group q lives in slot q % DEPTH
-    unsigned head = 0, tail = 0;                                      // slot of the group scored next / of the group fetched next
-    unsigned fetched = g;
-    auto fetch = [&]() {
-        const char *group = src + (size_t)fetched * 4096;
-        if (fetched < full_groups) satd8x8_dma_issue<NT, false>(group, 0, goff, slots + tail * 4096);
-        else                       satd8x8_dma_issue<NT, true>(group, (n_blocks & 31) * 128, goff, slots + tail * 4096);
-        fetched += step;
-        tail = tail + 1 == (unsigned)DEPTH ? 0 : tail + 1;
+    uint32_t *costs = reinterpret_cast<uint32_t *>(slots + 8192);        // 8 groups x 32 costs
+    auto fetch = [&](unsigned q, unsigned char *slot) {
+        const char *group = src + (size_t)q * 4096;
+        if (q < full_groups) satd8x8_dma_issue<false>(group, 0, goff, slot);
+        else                 satd8x8_dma_issue<true>(group, (n_blocks & 31) * 128, goff, slot);
     };
-#pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d)
-        if (fetched < end) fetch();
+    unsigned g = first;
+    fetch(g, slots);
+    if (g + 1 < end) fetch(g + 1, slots + 4096);
     const SatdOperands H = make_satd_operands(lane);
-    for (; g < end; g += step) {
-        unsigned char *slot = slots + head * 4096;
-        if (fetched < end) fetch();
-        // group g has landed once at most `ahead` later groups' loads (4 each) are still outstanding; vmcnt counts in order
-        const unsigned ahead = fetched == g + step ? 0u : fetched == g + 2 * step ? 1u : fetched == g + 3 * step ? 2u : 3u;
-        if (DEPTH >= 4 && ahead >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (DEPTH >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead >= 1)               asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else                               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (unsigned i = 0; g < end; ++g, ++i) {
+        unsigned char *slot = slots + (i & 1) * 4096;
+        if (g + 1 < end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // group g has landed, group g+1 stays in flight
+        else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         const v4i w0 = *reinterpret_cast<const v4i *>(slot + frag[0]), w1 = *reinterpret_cast<const v4i *>(slot + frag[1]);
         const v4i w2 = *reinterpret_cast<const v4i *>(slot + frag[2]), w3 = *reinterpret_cast<const v4i *>(slot + frag[3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the fragments are in registers: the slot may be refilled
         __builtin_amdgcn_wave_barrier();
+        if (g + 2 < end) fetch(g + 2, slot);
         const uint32_t cost = satd_group(H, w0, w1, w2, w3);
-        if (half == 0 && (g < full_groups || (unsigned)blk < (unsigned)(n_blocks & 31))) (out + (size_t)g * 32)[blk] = cost;
-        head = head + 1 == (unsigned)DEPTH ? 0 : head + 1;
+        if (half == 0) costs[(i & 7) * 32 + blk] = cost;
+        if ((i & 7) == 7 || g + 1 == end) {                             // up to 8 x 32 costs: 16 bytes per lane, one 1 KiB-linear store
+            const size_t b0 = (size_t)(g - (i & 7)) * 32;
+            const size_t have = (size_t)((i & 7) + 1) * 32 < n_blocks - b0 ? (size_t)((i & 7) + 1) * 32 : n_blocks - b0;
+            __builtin_amdgcn_wave_barrier();
+            const v4i c = *reinterpret_cast<const v4i *>(costs + lane * 4);
+            __builtin_amdgcn_wave_barrier();
+            uint32_t *dst = out + b0 + lane * 4;
+            if ((size_t)lane * 4 + 4 <= have) __builtin_nontemporal_store(c, reinterpret_cast<v4i_unaligned *>(dst));
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((size_t)lane * 4 + k < have) dst[k] = (uint32_t)c[k];
+            }
+        }
     }
 }
 
-template <bool NT, int SHAPE>
-__global__ __launch_bounds__(256, SHAPE == 3 ? 8 : 1) void satd8x8_lds_kernel(const int16_t *__restrict__ diff,
-                                                          uint32_t *__restrict__ out, size_t n_blocks,
-                                                          unsigned groups_per_wave, unsigned lds_per_wave, unsigned interleave)
+// small and medium batches (and the SATD lane of the frame kernel below): the staged body, one 4 KiB LDS slot per wave
+__global__ __launch_bounds__(256) void satd8x8_lds_kernel(const int16_t *__restrict__ diff, uint32_t *__restrict__ out, size_t n_blocks,
+                                                          unsigned groups_per_wave, unsigned lds_per_wave)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 4 KiB per wave (SHAPE 2: 8 KiB) + occupancy padding
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 4 KiB per wave + occupancy padding
+    satd8x8_lds_wave(diff, out, n_blocks, groups_per_wave, ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6,
+                     stage + (threadIdx.x >> 6) * lds_per_wave, (int)(threadIdx.x & 63));
+}
+
+// large batches: the LDS-DMA body, 9 KiB of LDS per wave + occupancy padding
+__global__ __launch_bounds__(256) void satd8x8_dma_kernel(const int16_t *__restrict__ diff, uint32_t *__restrict__ out, size_t n_blocks,
+                                                          unsigned groups_per_wave, unsigned lds_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
     // wave-uniform by construction; readfirstlane tells the compiler so (scalar group addresses, scalar LDS slot for M0)
     const unsigned wave_in_wg = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
-    unsigned char *slot = stage + wave_in_wg * lds_per_wave;
-    const int lane = (int)(threadIdx.x & 63);
-    if (SHAPE == 2 || SHAPE >= 4) {
-        // interleave: the workgroup's waves take turns over its groups (the workgroup advances through one contiguous piece,
-        // 4 KiB per wave and step); otherwise every wave walks its own run of consecutive groups
-        const unsigned waves_per_wg = blockDim.x >> 6;
-        if (wave > 0xFFFFFFFFu / groups_per_wave) return;
-        const unsigned first = interleave ? blockIdx.x * waves_per_wg * groups_per_wave + wave_in_wg : (unsigned)wave * groups_per_wave;
-        satd8x8_lds_wave_dma<NT, SHAPE == 2 ? 2 : SHAPE - 1>(diff, out, n_blocks, first, interleave ? waves_per_wg : 1u, groups_per_wave, slot, lane);
-    }
-    else if (SHAPE == 1) satd8x8_lds_wave_prefetch<NT>(diff, out, n_blocks, groups_per_wave, wave, slot, lane);
-    else if (SHAPE == 3) satd8x8_lds_wave<NT, true>(diff, out, n_blocks, groups_per_wave, wave, slot, lane);
-    else                 satd8x8_lds_wave<NT>(diff, out, n_blocks, groups_per_wave, wave, slot, lane);
+    if (wave > 0xFFFFFFFFu / groups_per_wave) return;
+    satd8x8_dma_wave(diff, out, n_blocks, (unsigned)wave * groups_per_wave, groups_per_wave, stage + wave_in_wg * lds_per_wave, (int)(threadIdx.x & 63));
 }
 
 // ---- the two lanes of a frame in ONE launch (BASELINE configs[4]: a 7680x4320 frame = 32 400 DCT32 blocks + 518 400
@@ -396,7 +295,7 @@ __global__ __launch_bounds__(128) void frame_lanes_kernel(const int16_t *__restr
         store16m<2>(dst, s0);
         store16m<2>(dst + 1024, s1);
     } else {
-        satd8x8_lds_wave<true>(diff, satd_out, n_satd, groups_per_wave, (size_t)(blockIdx.x - dct_wgs) * 2 + wave_in_wg, slot, lane);
+        satd8x8_lds_wave(diff, satd_out, n_satd, groups_per_wave, (size_t)(blockIdx.x - dct_wgs) * 2 + wave_in_wg, slot, lane);
     }
 }
 
@@ -408,12 +307,11 @@ __global__ __launch_bounds__(128) void frame_lanes_kernel(const int16_t *__restr
 // of the signed-offset trick cancels, and negating a +-1 operand byte is an XOR with 0xFE.
 // One wave takes 8 consecutive tiles = 32 blocks (lane n: tile n/4, block n%4 of the tile), so a
 // tile's 256 luma bytes are consumed whole by one wave; costs are stored in raster order of blocks.
-template <bool STAGED>
 __global__ __launch_bounds__(256) void satd8x8_from_tiles_kernel(const x266_ref_block_t *__restrict__ cur,
                                                                  const x266_ref_block_t *__restrict__ pred,
                                                                  uint32_t *__restrict__ out, int tiles_x, size_t n_tiles)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // STAGED: 4 KiB per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 4 KiB per wave
     const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
     const size_t group = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (group * 8 >= n_tiles) return;
@@ -422,39 +320,28 @@ __global__ __launch_bounds__(256) void satd8x8_from_tiles_kernel(const x266_ref_
     if (!live) tile = n_tiles - 1;
     const int sub_y = (n >> 1) & 1, sub_x = n & 1;                      // block inside the tile
     uint2 a[4], b[4];
-    if (STAGED) {
-        // Line-dense loads: one instruction reads the whole 256-byte luma part of four tiles (16 lanes
-        // x 16 B each), nontemporal; a wave-private LDS slot turns that into block-per-lane order.
-        // Row r of tile t (both 0-based inside the wave's group) lives at t*256 + ((r & 8) | ((r & 7) ^ t))*16:
-        // the b128 writes and the b64 fragment reads are both bank-conflict-free.
-        unsigned char *slot = stage + (threadIdx.x >> 6) * 4096;
-        const int lt = lane >> 4, lr = lane & 15;
+    // Line-dense loads: one instruction reads the whole 256-byte luma part of four tiles (16 lanes
+    // x 16 B each), nontemporal; a wave-private LDS slot turns that into block-per-lane order.
+    // Row r of tile t (both 0-based inside the wave's group) lives at t*256 + ((r & 8) | ((r & 7) ^ t))*16:
+    // the b128 writes and the b64 fragment reads are both bank-conflict-free.
+    unsigned char *slot = stage + (threadIdx.x >> 6) * 4096;
+    const int lt = lane >> 4, lr = lane & 15;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            size_t t = group * 8 + 4 * k + lt;
-            if (t >= n_tiles) t = n_tiles - 1;                          // ragged tail: stay inside the frame
-            const unsigned dst = (unsigned)((4 * k + lt) * 256 + ((lr & 8) | ((lr & 7) ^ (4 * k + lt))) * 16);
-            *reinterpret_cast<v4i *>(slot + dst) = load16<true>(reinterpret_cast<const unsigned char *>(cur + t) + lr * 16);
-            *reinterpret_cast<v4i *>(slot + 2048 + dst) = load16<true>(reinterpret_cast<const unsigned char *>(pred + t) + lr * 16);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int lt8 = n >> 2;
+    for (int k = 0; k < 2; ++k) {
+        size_t t = group * 8 + 4 * k + lt;
+        if (t >= n_tiles) t = n_tiles - 1;                          // ragged tail: stay inside the frame
+        const unsigned dst = (unsigned)((4 * k + lt) * 256 + ((lr & 8) | ((lr & 7) ^ (4 * k + lt))) * 16);
+        *reinterpret_cast<v4i *>(slot + dst) = load16<true>(reinterpret_cast<const unsigned char *>(cur + t) + lr * 16);
+        *reinterpret_cast<v4i *>(slot + 2048 + dst) = load16<true>(reinterpret_cast<const unsigned char *>(pred + t) + lr * 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int lt8 = n >> 2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = sub_y * 8 + 4 * half + r;
-            const unsigned src = (unsigned)(lt8 * 256 + ((row & 8) | ((row & 7) ^ lt8)) * 16 + sub_x * 8);
-            a[r] = *reinterpret_cast<const uint2 *>(slot + src);
-            b[r] = *reinterpret_cast<const uint2 *>(slot + 2048 + src);
-        }
-    } else {
-        const unsigned off = (unsigned)((sub_y * 8 + 4 * half) * 16 + sub_x * 8);
-        const unsigned char *pa = reinterpret_cast<const unsigned char *>(cur + tile) + off;
-        const unsigned char *pb = reinterpret_cast<const unsigned char *>(pred + tile) + off;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            a[r] = *reinterpret_cast<const uint2 *>(pa + r * 16);
-            b[r] = *reinterpret_cast<const uint2 *>(pb + r * 16);
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int row = sub_y * 8 + 4 * half + r;
+        const unsigned src = (unsigned)(lt8 * 256 + ((row & 8) | ((row & 7) ^ lt8)) * 16 + sub_x * 8);
+        a[r] = *reinterpret_cast<const uint2 *>(slot + src);
+        b[r] = *reinterpret_cast<const uint2 *>(slot + 2048 + src);
     }
     const SatdOperands H = make_satd_operands(lane);
     const uint32_t S = 0x80808080u;                                     // pixels -> signed (offset cancels)
@@ -521,30 +408,30 @@ __global__ __launch_bounds__(256) void fill_residual_kernel(int16_t *__restrict_
 
 }  // namespace
 
-hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks,
-                          const LaunchCfg &cfg, hipStream_t stream)
+// Batches from kSatdDmaMinBlocks on run the LDS-DMA kernel (four-wave workgroups, four groups per wave, 16 KiB of LDS charged per wave
+// = eight resident waves per CU), smaller ones the staged kernel (two-wave workgroups, two groups per wave, 6 KiB charged): measured
+// crossover, profiles/r04_satd_batch.txt -- +4-5 % at 2^24 blocks on every box, -7 % at the 8K frame's 518 400.
+hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks, const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
     const size_t groups = (n_blocks + 31) / 32;
-    const unsigned tpb = cfg.wg_threads;
+    if (groups > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const bool dma = cfg.shape == 3 || (cfg.shape == 0 && n_blocks >= kSatdDmaMinBlocks);
+    LaunchCfg c = cfg;
+    if (c.units_per_wave <= 0) c.units_per_wave = dma ? 4 : 2;
+    const unsigned tpb = cfg.wg_threads > 0 ? (unsigned)cfg.wg_threads : (dma ? 256u : 128u);
+    const unsigned min_lds = dma ? 9216u : 4096u;
+    unsigned per_wave = cfg.lds_bytes_per_wave > 0 ? (unsigned)cfg.lds_bytes_per_wave : (dma ? 16384u : 6144u);
+    if (per_wave < min_lds) per_wave = min_lds;
     const size_t waves_per_wg = tpb / 64;
-    const unsigned gpw = units_per_wave_for(cfg, groups);
+    const unsigned gpw = units_per_wave_for(c, groups);
     const size_t waves = (groups + gpw - 1) / gpw;
     const size_t wgs = (waves + waves_per_wg - 1) / waves_per_wg;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    dim3 grid((unsigned)wgs), block(tpb);
-    if (cfg.lds_stage) {
-        const unsigned min_lds = cfg.shape == 2 ? 8192u : cfg.shape >= 4 ? 4096u * (unsigned)(cfg.shape - 1) : 4096u;
-        const unsigned per_wave = (unsigned)cfg.lds_bytes_per_wave < min_lds ? min_lds : (unsigned)cfg.lds_bytes_per_wave;
-        const size_t lds = waves_per_wg * (size_t)per_wave + (size_t)cfg.lds_pad_bytes;
-#define X266_SATD(NT, SHAPE) hipLaunchKernelGGL((satd8x8_lds_kernel<NT, SHAPE>), grid, block, lds, stream, d_diff, d_out, n_blocks, gpw, per_wave, (unsigned)cfg.interleave)
-        if (cfg.nontemporal & 1) { if (cfg.shape == 2) X266_SATD(true, 2); else if (cfg.shape == 1) X266_SATD(true, 1); else if (cfg.shape == 3) X266_SATD(true, 3); else if (cfg.shape == 4) X266_SATD(true, 4); else if (cfg.shape == 5) X266_SATD(true, 5); else X266_SATD(true, 0); }
-        else                     { if (cfg.shape == 2) X266_SATD(false, 2); else if (cfg.shape == 1) X266_SATD(false, 1); else if (cfg.shape == 3) X266_SATD(false, 3); else X266_SATD(false, 0); }
-#undef X266_SATD
-        return hipGetLastError();
-    }
-    if (cfg.nontemporal & 4) hipLaunchKernelGGL((satd8x8_kernel<true>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
-    else                 hipLaunchKernelGGL((satd8x8_kernel<false>), grid, block, (size_t)cfg.lds_pad_bytes, stream, d_diff, d_out, n_blocks, gpw);
+    const size_t lds = waves_per_wg * (size_t)per_wave;
+    if (lds > 65536) return hipErrorInvalidValue;
+    if (dma) hipLaunchKernelGGL(satd8x8_dma_kernel, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_diff, d_out, n_blocks, gpw, per_wave);
+    else     hipLaunchKernelGGL(satd8x8_lds_kernel, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_diff, d_out, n_blocks, gpw, per_wave);
     return hipGetLastError();
 }
 
@@ -554,7 +441,9 @@ hipError_t launch_frame_lanes(const int16_t *d_dct_in, int16_t *d_dct_out, size_
     if (n_dct == 0 && n_satd == 0) return hipSuccess;
     const size_t dct_wgs = (n_dct + 1) / 2;
     const size_t groups = (n_satd + 31) / 32;
-    const unsigned gpw = groups ? units_per_wave_for(satd_cfg, groups) : 1u;
+    LaunchCfg c = satd_cfg;
+    if (c.units_per_wave <= 0) c.units_per_wave = 2;                  // the staged body's default
+    const unsigned gpw = groups ? units_per_wave_for(c, groups) : 1u;
     const size_t satd_wgs = ((groups + gpw - 1) / gpw + 1) / 2;
     if (dct_wgs + satd_wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(frame_lanes_kernel, dim3((unsigned)(dct_wgs + satd_wgs)), dim3(128), (size_t)(2 * 8192), stream,
@@ -563,15 +452,14 @@ hipError_t launch_frame_lanes(const int16_t *d_dct_in, int16_t *d_dct_out, size_
 }
 
 hipError_t launch_satd8x8_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, uint32_t *d_out,
-                                     int width, int height, const LaunchCfg &cfg, hipStream_t stream)
+                                     int width, int height, hipStream_t stream)
 {
     const int tiles_x = width / 16;
     const size_t n_tiles = (size_t)tiles_x * (size_t)(height / 16);
     if (n_tiles == 0) return hipSuccess;
     const size_t groups = (n_tiles + 7) / 8;                            // one wave per 8 tiles, one-wave workgroups
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (cfg.lds_stage) hipLaunchKernelGGL((satd8x8_from_tiles_kernel<true>), dim3((unsigned)groups), dim3(64), (size_t)(cfg.lds_bytes_per_wave < 4096 ? 4096 : cfg.lds_bytes_per_wave), stream, d_cur, d_pred, d_out, tiles_x, n_tiles);
-    else               hipLaunchKernelGGL((satd8x8_from_tiles_kernel<false>), dim3((unsigned)groups), dim3(64), 0, stream, d_cur, d_pred, d_out, tiles_x, n_tiles);
+    hipLaunchKernelGGL(satd8x8_from_tiles_kernel, dim3((unsigned)groups), dim3(64), (size_t)6144, stream, d_cur, d_pred, d_out, tiles_x, n_tiles);
     return hipGetLastError();
 }
 

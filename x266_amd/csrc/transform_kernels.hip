@@ -26,70 +26,6 @@
 namespace x266 {
 namespace {
 
-template <int LOGN, bool INDEXED>
-__global__ __launch_bounds__(256) void tr_fwd_small_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
-                                                           size_t n_blocks, const DctOps *__restrict__ ops,
-                                                           const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
-{
-    constexpr int N = 1 << LOGN;
-    constexpr int PER = 32 / N;                 // small blocks per tile edge
-    constexpr int PIECES = N >= 16 ? 1 : 16 / N;   // small-block rows per lane (a lane holds 16 samples of a tile row)
-    constexpr int NSB = PER * PER;              // small blocks per tile
-    constexpr int S1 = LOGN - 1, S2 = LOGN + 6;
-
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const size_t n_tiles = (n_blocks + NSB - 1) / NSB;
-    size_t t = wave * tiles_per_wave;
-    const size_t t_end = t + tiles_per_wave < n_tiles ? t + tiles_per_wave : n_tiles;
-    if (t >= t_end) return;
-    const LaneConsts k = load_consts(ops, lane);
-    const int row = c & (N - 1), tile_row = c >> LOGN;
-
-    for (; t < t_end; ++t) {
-        const size_t first = N == 32 ? t : t * NSB + (size_t)tile_row * PER + (size_t)h * PIECES;
-        uint32_t w[8];
-        size_t off[PIECES];
-        bool live[PIECES];
-#pragma unroll
-        for (int q = 0; q < PIECES; ++q) {
-            size_t blk = first + q;
-            live[q] = blk < n_blocks;
-            if (!live[q]) blk = n_blocks - 1;                              // ragged tail: re-read the last block
-            const size_t base = INDEXED ? (size_t)offsets[blk] : blk * (size_t)(N * N);
-            off[q] = (base + (size_t)row * N + (N == 32 ? 16 * h : 0)) * 2;   // bytes
-            const char *p = reinterpret_cast<const char *>(in) + off[q];
-            if (N >= 16) {
-                const v4i a = *reinterpret_cast<const v4i *>(p), b = *reinterpret_cast<const v4i *>(p + 16);
-                w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = b[0]; w[5] = b[1]; w[6] = b[2]; w[7] = b[3];
-            } else if (N == 8) {
-                const v4i a = *reinterpret_cast<const v4i *>(p);
-                w[4 * q] = a[0]; w[4 * q + 1] = a[1]; w[4 * q + 2] = a[2]; w[4 * q + 3] = a[3];
-            } else {
-                const uint2 a = *reinterpret_cast<const uint2 *>(p);
-                w[2 * q] = a.x; w[2 * q + 1] = a.y;
-            }
-        }
-        v4i o0, o1;
-        fwd_block<S1, S2>(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, k, o0, o1);
-        const uint32_t z[8] = {(uint32_t)o0[0], (uint32_t)o0[1], (uint32_t)o0[2], (uint32_t)o0[3],
-                               (uint32_t)o1[0], (uint32_t)o1[1], (uint32_t)o1[2], (uint32_t)o1[3]};
-#pragma unroll
-        for (int q = 0; q < PIECES; ++q) {
-            if (!live[q]) continue;
-            char *p = reinterpret_cast<char *>(out) + off[q];
-            if (N >= 16) {
-                *reinterpret_cast<v4i *>(p) = o0;
-                *reinterpret_cast<v4i *>(p + 16) = o1;
-            } else if (N == 8) {
-                *reinterpret_cast<v4i *>(p) = v4i{(int)z[4 * q], (int)z[4 * q + 1], (int)z[4 * q + 2], (int)z[4 * q + 3]};
-            } else {
-                *reinterpret_cast<uint2 *>(p) = make_uint2(z[2 * q], z[2 * q + 1]);
-            }
-        }
-    }
-}
-
 // One 32x32 tile of (32/N)^2 small blocks, block-major, sitting in a wave-private 2 KiB LDS slot: read the
 // lane's fragment pieces, run the two MFMA passes with the class's operand images, write the results back
 // in place.  Shared by the per-class kernels and the mixed-class tile kernel.
@@ -140,11 +76,11 @@ __device__ __forceinline__ void fwd_tile_in_slot(unsigned char *slot, int lane, 
     }
 }
 
-// LDS-staged variant for contiguous batches: a tile's (32/N)^2 blocks are 2 KiB of consecutive
-// memory, moved with linear 1 KiB instructions (whole 128-byte lines per instruction, see
+// A tile's (32/N)^2 blocks are 2 KiB of consecutive memory (contiguous batches) or (32/N)^2 pieces placed by the
+// offset table, moved with linear 1 KiB instructions (whole 128-byte lines per instruction, see
 // dct32_kernels.hip section "LDS-staged variant") and re-read from a wave-private LDS slot in
-// fragment order.  N = 8 does not need it: its fragment loads are line-dense already.
-template <int LOGN, bool NT, bool INDEXED>
+// fragment order.  Streaming cache hints only for contiguous batches: scattered blocks may share lines across instructions.
+template <int LOGN, bool INDEXED>
 __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
                                                                size_t n_blocks, const DctOps *__restrict__ ops,
                                                                const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
@@ -185,8 +121,8 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
             if (!live0) o0 = total_bytes - 16;                           // ragged tail: stay inside the buffer
             if (!live1) o1 = total_bytes - 16;
         }
-        const v4i g0 = load16<NT>(reinterpret_cast<const char *>(in) + o0);
-        const v4i g1 = load16<NT>(reinterpret_cast<const char *>(in) + o1);
+        const v4i g0 = load16<!INDEXED>(reinterpret_cast<const char *>(in) + o0);   // streaming hints for contiguous batches only
+        const v4i g1 = load16<!INDEXED>(reinterpret_cast<const char *>(in) + o1);
         *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
         *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
         __builtin_amdgcn_wave_barrier();
@@ -195,8 +131,8 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
         __builtin_amdgcn_wave_barrier();
-        if (live0) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o0, s0);   // NT: "sc1 nt" (x266_device.hpp)
-        if (live1) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o1, s1);
+        if (live0) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o0, s0);   // contiguous: "sc1 nt" (x266_device.hpp)
+        if (live1) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o1, s1);
     }
 }
 
@@ -266,7 +202,7 @@ __device__ __forceinline__ v16i load_c2r(const DctOps *__restrict__ ops, int h)
 // after each pass -- DESIGN.md section 10), contiguous batches, same block-diagonal tile idea.  The
 // first contraction runs over the tile's ROW index, so each lane reads its COLUMN out of the staged
 // tile (16 x ds_read_u16), exactly as the staged DCT32 inverse does.
-template <int LOGN, bool NT, bool INDEXED>
+template <int LOGN, bool INDEXED>
 __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
                                                                size_t n_blocks, const DctOps *__restrict__ ops,
                                                                const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
@@ -306,8 +242,8 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
             if (!live0) o0 = total_bytes - 16;
             if (!live1) o1 = total_bytes - 16;
         }
-        const v4i g0 = load16<NT>(reinterpret_cast<const char *>(in) + o0);
-        const v4i g1 = load16<NT>(reinterpret_cast<const char *>(in) + o1);
+        const v4i g0 = load16<!INDEXED>(reinterpret_cast<const char *>(in) + o0);   // streaming hints for contiguous batches only
+        const v4i g1 = load16<!INDEXED>(reinterpret_cast<const char *>(in) + o1);
         *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
         *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
         __builtin_amdgcn_wave_barrier();
@@ -316,8 +252,8 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
         __builtin_amdgcn_wave_barrier();
-        if (live0) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o0, s0);   // NT: "sc1 nt" (x266_device.hpp)
-        if (live1) store16m<NT ? 2 : 0>(reinterpret_cast<char *>(out) + o1, s1);
+        if (live0) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o0, s0);   // contiguous: "sc1 nt" (x266_device.hpp)
+        if (live1) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o1, s1);
     }
 }
 
@@ -528,35 +464,19 @@ hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out
     const size_t tiles = (n_blocks + per_tile - 1) / per_tile;
     const unsigned tpw = units_per_wave_for(cfg, tiles);
     const size_t waves = (tiles + tpw - 1) / tpw;
-    if (cfg.lds_stage) {                                         // line-dense traffic through LDS (contiguous or placed by the offset table)
-        const unsigned tpb = (unsigned)cfg.wg_threads;            // same launch shape as the staged DCT32 kernel
-        const size_t wpw = tpb / 64, swgs = (waves + wpw - 1) / wpw;
-        if (swgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-        const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
-        dim3 sgrid((unsigned)swgs), sblock(tpb);
-        // streaming cache hints only for contiguous batches: scattered blocks may share lines across instructions
-#define X266_TRL(L) do { if (d_offsets)                hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, false, true>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
-                         else if (cfg.nontemporal & 3) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, true, false>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
-                         else                          hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, false, false>), sgrid, sblock, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
-        if (log2n == 2) X266_TRL(2); else if (log2n == 3) X266_TRL(3); else if (log2n == 4) X266_TRL(4); else if (log2n == 5) X266_TRL(5);
-        else return hipErrorInvalidValue;
-#undef X266_TRL
-        return hipGetLastError();
-    }
-    const size_t wgs = (waves + 3) / 4;
+    const unsigned tpb = (unsigned)cfg.wg_threads;                // same launch shape as the staged DCT32 kernel
+    const size_t wpw = tpb / 64, wgs = (waves + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    dim3 grid((unsigned)wgs), block(256);
-#define X266_TR(L) do { if (d_offsets) hipLaunchKernelGGL((tr_fwd_small_kernel<L, true>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
-                        else           hipLaunchKernelGGL((tr_fwd_small_kernel<L, false>), grid, block, 0, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
-    if (log2n == 2) X266_TR(2); else if (log2n == 3) X266_TR(3); else if (log2n == 4) X266_TR(4); else if (log2n == 5) X266_TR(5);
+    const size_t lds = wpw * (size_t)cfg.lds_bytes_per_wave;
+    dim3 grid((unsigned)wgs), block(tpb);
+#define X266_TRL(L) do { if (d_offsets) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
+                         else           hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, false>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
+    if (log2n == 2) X266_TRL(2); else if (log2n == 3) X266_TRL(3); else if (log2n == 4) X266_TRL(4);
+    else if (log2n == 5 && d_offsets) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<5, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw);   // contiguous 32x32 batches are the DCT32 kernel's
     else return hipErrorInvalidValue;
-#undef X266_TR
+#undef X266_TRL
     return hipGetLastError();
 }
-
-}  // namespace x266
-
-namespace x266 {
 
 hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
                                       const uint32_t *d_offsets, const LaunchCfg &cfg, hipStream_t stream)
@@ -569,20 +489,16 @@ hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d
     const unsigned tpb = (unsigned)cfg.wg_threads;
     const size_t wpw = tpb / 64, wgs = (waves + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const size_t lds = wpw * (size_t)(cfg.lds_bytes_per_wave < 2048 ? 2048 : cfg.lds_bytes_per_wave);
+    const size_t lds = wpw * (size_t)cfg.lds_bytes_per_wave;
     dim3 grid((unsigned)wgs), block(tpb);
-#define X266_TRI(L) do { if (d_offsets)                hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, false, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
-                         else if (cfg.nontemporal & 3) hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, true, false>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
-                         else                          hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, false, false>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
-    if (log2n == 2) X266_TRI(2); else if (log2n == 3) X266_TRI(3); else if (log2n == 4) X266_TRI(4); else if (log2n == 5) X266_TRI(5);
+#define X266_TRI(L) do { if (d_offsets) hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
+                         else           hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, false>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
+    if (log2n == 2) X266_TRI(2); else if (log2n == 3) X266_TRI(3); else if (log2n == 4) X266_TRI(4);
+    else if (log2n == 5 && d_offsets) hipLaunchKernelGGL((tr_inv_small_lds_kernel<5, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw);
     else return hipErrorInvalidValue;
 #undef X266_TRI
     return hipGetLastError();
 }
-
-}  // namespace x266
-
-namespace x266 {
 
 hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_tiles, const uint32_t *d_tile_offsets,
                                   const uint8_t *d_tile_class, const TileTab *d_tab, const LaunchCfg &cfg, hipStream_t stream)
@@ -596,7 +512,9 @@ hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_
     const unsigned per_wave = (unsigned)(cfg.lds_bytes_per_wave < 6144 ? 6144 : (cfg.lds_bytes_per_wave + 15) & ~15);   // table + two tiles, then padding
     const size_t lds = wpw * (size_t)per_wave;
     dim3 grid((unsigned)wgs), block(tpb);
-    const bool nt = !d_tile_offsets && (cfg.nontemporal & 3);           // streaming hints only when the tiles are the whole buffer in order
+    // streaming hints only when the tiles are the whole buffer in order.  (The cache policy as a run-time, wave-uniform choice inside one
+    // kernel costs 1-3.6 % same-box -- profiles/r04_kernel_prune.txt -- so these stay compile-time variants.)
+    const bool nt = !d_tile_offsets;
 #define X266_TT(INV, NTV) hipLaunchKernelGGL((tr_tiles_kernel<INV, NTV>), grid, block, lds, stream, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, d_tab, tpw, per_wave)
     if (inverse) { if (nt) X266_TT(true, true); else X266_TT(true, false); }
     else         { if (nt) X266_TT(false, true); else X266_TT(false, false); }

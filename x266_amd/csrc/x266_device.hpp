@@ -50,20 +50,16 @@ __device__ __forceinline__ void store16m(void *p, const v4i &v)
 }
 
 struct LaunchCfg {
-    int cu_count;        // compute units of the device
-    int adaptive;        // shrink units_per_wave on small batches so the grid still fills the chip
-    int nontemporal;     // bit 0: nontemporal loads, bit 1: nontemporal stores in the line-dense (LDS-staged)
-                         // kernels; bit 2: the same hints in the direct fragment-pattern kernels (harmful there);
-                         // bit 3: line-dense stores use "sc1 nt" instead of "nt"
-    int units_per_wave;  // streaming launch: consecutive units (DCT blocks / 32-block SATD groups) per wave
-    int wg_threads;      // workgroup size, multiple of 64
-    int lds_pad_bytes;   // unused dynamic LDS per workgroup: caps resident waves per CU (fewer bytes in flight)
-    int lds_bytes_per_wave;   // staged kernels: LDS charged per wave (>= 2048); 160 KiB / this = resident waves per CU
-    int lds_stage;       // DCT32: move tiles with linear 1 KiB instructions through a private LDS slot
-    int passthrough;     // diagnostic: skip the arithmetic (timing of the memory pattern only)
-    int interleave = 0;  // A/B: SATD batch, LDS-DMA bodies: waves of a workgroup take turns over its groups
-    int shape = 0;       // A/B: kernel body variant (SATD batch: 0 load-then-score, 1 register prefetch, 2 LDS-DMA ping-pong)
+    int cu_count;             // compute units of the device
+    int adaptive;             // shrink units_per_wave on small batches so the grid still fills the chip
+    int units_per_wave;       // streaming launch: consecutive units (DCT blocks / 32-block SATD groups / tiles) per wave; SATD batch: 0 = the kernel's own default
+    int wg_threads;           // workgroup size, multiple of 64; SATD batch: 0 = the kernel's own default
+    int lds_bytes_per_wave;   // LDS charged per wave (what the kernel uses + padding): 160 KiB / this = cap on resident waves per CU; SATD batch: 0 = default
+    int shape;                // SATD batch only: 0 kernel by batch size, 1 staged kernel, 3 LDS-DMA kernel
 };
+
+// SATD batch: from this many blocks on the LDS-DMA kernel runs (satd_kernels.hip, launch_satd8x8)
+constexpr size_t kSatdDmaMinBlocks = (size_t)3 << 20;
 
 struct DctOps;
 struct TileTab;
@@ -93,7 +89,7 @@ hipError_t launch_dct32_pass(const int16_t *d_in, int16_t *d_out, size_t n_block
 hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,
                                const DctOps *d_fwd_ops, const DctOps *d_inv_lds_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_blocks,
-                        const DctOps *d_ops, const DctOps *d_ops_lds_inv, const LaunchCfg &cfg, hipStream_t stream);
+                        const DctOps *d_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
                                   const uint32_t *d_offsets, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_dct32_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_out,
@@ -101,7 +97,7 @@ hipError_t launch_dct32_from_tiles(const x266_ref_block_t *d_cur, const x266_ref
 hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
                                       const uint32_t *d_offsets, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_satd8x8_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, uint32_t *d_out,
-                                     int width, int height, const LaunchCfg &cfg, hipStream_t stream);
+                                     int width, int height, hipStream_t stream);
 hipError_t launch_frame_lanes(const int16_t *d_dct_in, int16_t *d_dct_out, size_t n_dct, const DctOps *d_fwd_ops,
                               const int16_t *d_diff, uint32_t *d_satd_out, size_t n_satd, const LaunchCfg &satd_cfg, hipStream_t stream);
 hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks,

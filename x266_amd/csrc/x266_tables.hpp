@@ -196,6 +196,31 @@ constexpr int8_t kDst7_16[256] = {
      17, -33,  48, -62,  73, -81,  87, -89,  88, -84,  77, -67,  55, -41,  25,  -8,
 };
 
+// Presets of slot 1 (xTransformUsePreset).  The H.266 DST-VII integers for N = 8 / 16 AS RECALLED from the VTM sources
+// (DEFINE_DST7_P8_MATRIX / DEFINE_DST7_P16_MATRIX) -- UNVERIFIED OFFLINE: no copy of the standard or of VTM exists in the build
+// environment.  They have the closed form's sign / index pattern with hand-tuned magnitudes, so they are stated as the
+// magnitude substitution closed form -> recalled; N = 4 needs none (the closed form IS the standard's {29, 55, 74, 84} table).
+constexpr int8_t kVtmDst7Mag8[2][8] = {{16, 32, 46, 59, 70, 79, 84, 87}, {17, 32, 46, 60, 71, 78, 85, 86}};
+constexpr int8_t kVtmDst7Mag16[2][16] = {{8, 17, 25, 33, 41, 48, 55, 62, 67, 73, 77, 81, 84, 87, 88, 89},
+                                         {8, 17, 25, 33, 40, 48, 55, 62, 68, 73, 77, 81, 85, 87, 88, 88}};
+
+// m[k*n + c] = the recalled VTM DST-VII (dct8 = false) or the DCT-VIII derived from it, T8[k][c] = (-1)^k T7[k][n-1-c]
+// (H.266's third MTS kernel is the flipped, sign-alternated DST-VII); n in {4, 8, 16}
+inline void vtm_slot1_matrix(int n, bool dct8, int8_t *m)
+{
+    const int8_t *closed = n == 4 ? kDst7_4 : (n == 8 ? kDst7_8 : kDst7_16);
+    int8_t t7[256];
+    for (int i = 0; i < n * n; ++i) {
+        int v = closed[i];
+        const int mag = v < 0 ? -v : v;
+        if (n == 8) { for (int j = 0; j < 8; ++j) if (kVtmDst7Mag8[0][j] == mag) { v = v < 0 ? -kVtmDst7Mag8[1][j] : kVtmDst7Mag8[1][j]; break; } }
+        if (n == 16) { for (int j = 0; j < 16; ++j) if (kVtmDst7Mag16[0][j] == mag) { v = v < 0 ? -kVtmDst7Mag16[1][j] : kVtmDst7Mag16[1][j]; break; } }
+        t7[i] = (int8_t)v;
+    }
+    for (int k = 0; k < n; ++k)
+        for (int c = 0; c < n; ++c) m[k * n + c] = dct8 ? (int8_t)((k & 1) ? -t7[k * n + (n - 1 - c)] : t7[k * n + (n - 1 - c)]) : t7[k * n + c];
+}
+
 enum TransformType { kTrDct2 = 0, kTrDst7 = 1 };
 
 struct Matrix32 { int8_t v[32][32]; };

@@ -9,9 +9,12 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/x266hip.h"
@@ -24,7 +27,6 @@ struct x266hip_ctx {
     int device = 0;
     hipDeviceProp_t prop{};
     DctOps *d_fwd = nullptr;
-    DctOps *d_inv = nullptr;
     DctOps *d_inv_lds = nullptr;                    // inverse operand images for the LDS-staged kernel (column reads)
     static constexpr int kTypes = 4;                // DCT-II, DST-VII, and the two mixed horizontal / vertical pairs
     DctOps *d_tr[kTypes][3] = {};                   // [type][log2N - 2], N = 4, 8, 16
@@ -33,21 +35,21 @@ struct x266hip_ctx {
     // the two 1-D transform slots of the set, N = 4, 8, 16: slot 0 = DCT-II sub-matrices of g_t32, slot 1 = closed-form
     // DST-VII unless the caller installed its own (xTransformSetMatrix); row k = basis function, N x N, row-major
     int8_t slot_mat[2][3][256] = {};
+    int slot1_preset = X266_PRESET_CLOSED_FORM;     // -1 once the caller installed a matrix of its own in slot 1
     bool tr_tables_valid = true;                    // false after a matrix update whose device tables could be neither installed nor rolled back
-    int tile_lds_per_wave = 8192;                   // mixed-class tile kernel: LDS charged per wave (resident-wave cap)
-    int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (next tile's loads issued before this tile's arithmetic)
-    // options
-    int nontemporal = 11;            // see LaunchCfg: nt loads + "sc1 nt" stores in the line-dense kernels (+3-5 %), none on fragment loads
-    int dct_variant = 0, satd_variant = 0;          // 0 = matrix-core kernels, 2 = VALU butterfly (comparison only; 1, the persistent launch of rounds 1-2, is gone)
-    // streaming launch: consecutive units per wave (measured optimum on MI355X, profiles/r01_sweep.txt)
-    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, satd_groups_per_wave = 2;
-    int dct_fwdinv_blocks_per_wave = 4;
-    int adaptive_per_wave = 1;
-    int wg_threads = 256;
-    int satd_wg_threads = 128;                      // SATD batch (staged): two-wave workgroups, 2 groups per wave (profiles/r01_satd_staged_nt.txt)
-    int lds_pad_dct = 0, lds_pad_inv = 0, lds_pad_satd = 0;
+    // Launch options (xHipSetOption): A/B knobs, results never depend on them.  Defaults = the measured optimum.
+    int dct_variant = 0;                            // 0 = matrix-core kernel, 2 = VALU butterfly (the comparison variant north_star asks for)
+    int satd_variant = 0;                           // 0 = by batch size (staged kernel below 3 Mi blocks, LDS-DMA kernel from there), 1 = staged, 2 = VALU butterfly, 3 = LDS-DMA
+    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, dct_fwdinv_blocks_per_wave = 4;   // consecutive blocks one wave loops over (profiles/r01_launch_sweep.txt)
+    int satd_groups_per_wave = 0, satd_wg_threads = 0, satd_lds_per_wave = 0;                   // 0 = the chosen SATD kernel's own default (satd_kernels.hip, launch_satd8x8)
+    int adaptive_per_wave = 1;                      // shrink the per-wave run on small batches
+    int dct_wg_threads = 64;                        // workgroup size of the DCT32 / transform-set kernels: one-wave workgroups stream best (profiles/r01_wg_occupancy.txt)
+    int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (0 = 2: the wave's table copy serves two tiles)
     int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (SATD search: 8, 4 or 2; SAD search: 2), else 2, 4, 8 (8: SATD search only; 1 is served by 2)
-    int intra_rounds = 4;                           // intra prediction: rounds of seven predictions per wave (next round's reference sets prefetched)
+    // fixed launch shapes (options in rounds 1-3; their sweeps are frozen in profiles/r01_*.txt, r03_tiles_one_launch.txt)
+    static constexpr int kDctLdsPerWave = 8192;     // 2 KiB used: at most 20 resident waves per CU
+    static constexpr int kTileLdsPerWave = 8192;    // table + two tile slots = 6 KiB used
+    static constexpr int kIntraRounds = 4;          // intra prediction: rounds of seven predictions per wave
     // Internal device scratch, ONE BUFFER PER STREAM AND KIND, so that calls enqueued on different streams never share it:
     // kind 0 = motion search (128 B per 8x8 block of the current frame).  Each table is bounded (kMeScratchMax streams, least recently used evicted after waiting for its
     // last use); a buffer that was handed out during a stream capture may be referenced by a recorded graph and is kept
@@ -66,26 +68,16 @@ struct x266hip_ctx {
     std::vector<MeScratch> scratch[kScratchKinds];
     std::vector<void *> me_retired;
     unsigned long long me_stamp = 0;
-    int tr_lds_stage = 1;                           // transform set, contiguous batches: stage tiles through LDS
-    int tr_tiles_per_wave = 1;                      // transform set: 32x32 tiles per wave
-    int tr32_simple = 0;                            // diagnostic: run DCT-II 32 through the transform-set kernel
-    int satd_lds_stage = 1;                         // line-dense nontemporal loads through a 4 KiB LDS slot: +5-10 % over fragment loads (profiles/r01_satd_staged_nt.txt)
-    // staged DCT32 launch shape, measured optimum (profiles/r01_wg_occupancy.txt): forward one-wave workgroups
-    // capped at 20 resident waves per CU (160 KiB / 8 KiB), 1 block per wave forward, 2 inverse
-    int dct_lds_per_wave = 8192, dct_inv_lds_per_wave = 8192;
-    int satd_lds_per_wave = 6144;                   // staged SATD variant: LDS charged per wave (>= 4096)
-    int dct_wg_threads = 64, dct_inv_wg_threads = 64;
-    int dct_lds_stage = 1;                          // see dct32_kernels.hip: dct32_lds_kernel
-    int passthrough = 0;                            // diagnostic, see x266_device.hpp
-    int satd_interleave = 0;
-    int satd_shape = 0;                             // A/B: SATD batch kernel body (x266_device.hpp LaunchCfg::shape)
     // host-pointer staging (lazily allocated)
     static constexpr int kSlots = 3;                // chunk i+1 uploading and chunk i-1 downloading while chunk i is transformed
     void *d_stage_in[kSlots] = {};
     void *d_stage_out[kSlots] = {};
     size_t stage_in_bytes = 0, stage_out_bytes = 0;
-    hipStream_t stage_stream[kSlots] = {};
-    int host_register = 0;                          // env X266HIP_HOST_REGISTER=1: pin the caller's pageable buffers for the duration of a large host-pointer call
+    // one stream per ENGINE, not per slot: every upload on [0], every kernel on [1], every download on [2], ordered by the
+    // slots' events.  With a stream per slot (rounds 1-3) uploads and downloads of different chunks did not overlap on this
+    // runtime: 28-30 GB/s each way from pinned memory against 43 this way (profiles/r04_hostpipe.txt; the link gives 48.5 both ways)
+    hipStream_t stage_stream[3] = {};
+    hipEvent_t stage_up[kSlots] = {}, stage_done[kSlots] = {}, stage_down[kSlots] = {};
     std::string err;
 };
 
@@ -131,17 +123,18 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
 {
     LaunchCfg c;
     c.cu_count = ctx->prop.multiProcessorCount;
-    c.nontemporal = ctx->nontemporal;
     c.adaptive = ctx->adaptive_per_wave;
-    c.units_per_wave = op == 2 ? ctx->satd_groups_per_wave : (op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave);
-    c.wg_threads = op == 2 ? ctx->satd_wg_threads : ctx->wg_threads;
-    c.passthrough = ctx->passthrough;
-    c.shape = op == 2 ? ctx->satd_shape : 0;
-    c.interleave = op == 2 ? ctx->satd_interleave : 0;
-    c.lds_stage = op == 2 ? ctx->satd_lds_stage : ctx->dct_lds_stage;
-    c.lds_bytes_per_wave = op == 2 ? ctx->satd_lds_per_wave : (op == 1 ? ctx->dct_inv_lds_per_wave : ctx->dct_lds_per_wave);
-    if (op != 2 && ctx->dct_lds_stage) c.wg_threads = op == 1 ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
-    c.lds_pad_bytes = op == 2 ? ctx->lds_pad_satd : (op == 1 ? ctx->lds_pad_inv : ctx->lds_pad_dct);
+    if (op == 2) {
+        c.units_per_wave = ctx->satd_groups_per_wave;
+        c.wg_threads = ctx->satd_wg_threads;
+        c.lds_bytes_per_wave = ctx->satd_lds_per_wave;
+        c.shape = ctx->satd_variant == 1 || ctx->satd_variant == 3 ? ctx->satd_variant : 0;
+    } else {
+        c.units_per_wave = op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave;
+        c.wg_threads = ctx->dct_wg_threads;
+        c.lds_bytes_per_wave = x266hip_ctx::kDctLdsPerWave;
+        c.shape = 0;
+    }
     return c;
 }
 
@@ -151,14 +144,14 @@ int launch_op(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n,
     switch (op) {
     case 0:
         if (ctx->dct_variant == 2) e = launch_dct32_butterfly((const int16_t *)d_in, (int16_t *)d_out, n, s);   // VALU comparison variant
-        else e = launch_dct32(false, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_fwd, nullptr, cfg_for(ctx, 0), s);
+        else e = launch_dct32(false, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_fwd, cfg_for(ctx, 0), s);
         break;
-    case 1: e = launch_dct32(true, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_inv, ctx->d_inv_lds, cfg_for(ctx, 1), s); break;
+    case 1: e = launch_dct32(true, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_inv_lds, cfg_for(ctx, 1), s); break;
     case 2:
         if (ctx->satd_variant == 2) e = launch_satd8x8_butterfly((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s);   // VALU comparison variant
         else e = launch_satd8x8((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s);
         break;
-    case 3: case 4: case 5: e = launch_mem_ceiling(op - 3, d_in, d_out, n * 2048, s); break;      // xHipTimeKernel only
+    case 3: case 4: case 5: case 6: e = launch_mem_ceiling(op - 3, d_in, d_out, n * 2048, s); break;      // xHipTimeKernel only
     default: return fail(ctx, X266HIP_EINVAL, "unknown op");
     }
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "kernel launch", e);
@@ -303,7 +296,6 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
     x266hip_ctx *ctx = new (std::nothrow) x266hip_ctx;
     if (!ctx) return X266HIP_ENOMEM;
     ctx->device = device_id;
-    if (const char *hr = std::getenv("X266HIP_HOST_REGISTER")) ctx->host_register = std::atoi(hr) != 0;
     DeviceScope dev_scope_(device_id);
     if (dev_scope_.status != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess) {
         delete ctx;
@@ -317,15 +309,10 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
     }
     DctOps *h = new (std::nothrow) DctOps;
     bool ok = h != nullptr;
-    if (ok) ok = hipMalloc((void **)&ctx->d_fwd, sizeof(DctOps)) == hipSuccess &&
-                 hipMalloc((void **)&ctx->d_inv, sizeof(DctOps)) == hipSuccess;
+    if (ok) ok = hipMalloc((void **)&ctx->d_fwd, sizeof(DctOps)) == hipSuccess;
     if (ok) {
         build_fwd_ops(*h);
         ok = hipMemcpy(ctx->d_fwd, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
-    }
-    if (ok) {
-        build_inv_ops(*h);
-        ok = hipMemcpy(ctx->d_inv, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok) {
         build_inv_ops(*h, true);
@@ -358,8 +345,12 @@ void xHipCodecFree(x266hip_ctx *ctx)
     for (int i = 0; i < x266hip_ctx::kSlots; ++i) {
         if (ctx->d_stage_in[i]) (void)hipFree(ctx->d_stage_in[i]);
         if (ctx->d_stage_out[i]) (void)hipFree(ctx->d_stage_out[i]);
-        if (ctx->stage_stream[i]) (void)hipStreamDestroy(ctx->stage_stream[i]);
+        if (ctx->stage_up[i]) (void)hipEventDestroy(ctx->stage_up[i]);
+        if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
+        if (ctx->stage_down[i]) (void)hipEventDestroy(ctx->stage_down[i]);
     }
+    for (hipStream_t st : ctx->stage_stream)
+        if (st) (void)hipStreamDestroy(st);
     for (int type = 0; type < x266hip_ctx::kTypes; ++type)
         for (int l = 0; l < 3; ++l) {
             if (ctx->d_tr[type][l]) (void)hipFree(ctx->d_tr[type][l]);
@@ -371,7 +362,6 @@ void xHipCodecFree(x266hip_ctx *ctx)
     if (ctx->d_tile_fwd) (void)hipFree(ctx->d_tile_fwd);
     if (ctx->d_tile_inv) (void)hipFree(ctx->d_tile_inv);
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
-    if (ctx->d_inv) (void)hipFree(ctx->d_inv);
     if (ctx->d_inv_lds) (void)hipFree(ctx->d_inv_lds);
     delete ctx;
 }
@@ -400,36 +390,18 @@ struct OptionDesc {
 };
 
 static const OptionDesc kOptions[] = {
-    {"nontemporal", &x266hip_ctx::nontemporal, 0, 15, 1},
     {"adaptive_per_wave", &x266hip_ctx::adaptive_per_wave, 0, 1, 1},
     {"dct32_variant", &x266hip_ctx::dct_variant, 0, 2, 2},          // 0 or 2
-    {"satd_variant", &x266hip_ctx::satd_variant, 0, 2, 2},
+    {"satd_variant", &x266hip_ctx::satd_variant, 0, 3, 1},
     {"dct32_blocks_per_wave", &x266hip_ctx::dct_blocks_per_wave, 1, 4096, 1},
     {"dct32_inv_blocks_per_wave", &x266hip_ctx::dct_inv_blocks_per_wave, 1, 4096, 1},
     {"dct32_fwdinv_blocks_per_wave", &x266hip_ctx::dct_fwdinv_blocks_per_wave, 1, 4096, 1},
-    {"satd_groups_per_wave", &x266hip_ctx::satd_groups_per_wave, 1, 4096, 1},
-    {"tr_tiles_per_wave", &x266hip_ctx::tr_tiles_per_wave, 1, 64, 1},
-    {"tile_tiles_per_wave", &x266hip_ctx::tile_tiles_per_wave, 0, 64, 1},
-    {"tile_lds_bytes_per_wave", &x266hip_ctx::tile_lds_per_wave, 6144, 40960, 1},
-    {"wg_threads", &x266hip_ctx::wg_threads, 64, 256, 64},
-    {"satd_wg_threads", &x266hip_ctx::satd_wg_threads, 64, 256, 64},
     {"dct32_wg_threads", &x266hip_ctx::dct_wg_threads, 64, 256, 64},
-    {"dct32_inv_wg_threads", &x266hip_ctx::dct_inv_wg_threads, 64, 256, 64},
-    {"dct32_lds_stage", &x266hip_ctx::dct_lds_stage, 0, 1, 1},
-    {"satd_lds_stage", &x266hip_ctx::satd_lds_stage, 0, 1, 1},
-    {"tr_lds_stage", &x266hip_ctx::tr_lds_stage, 0, 1, 1},
-    {"dct32_lds_bytes_per_wave", &x266hip_ctx::dct_lds_per_wave, 2048, 40960, 1},
-    {"dct32_inv_lds_bytes_per_wave", &x266hip_ctx::dct_inv_lds_per_wave, 2048, 40960, 1},
-    {"satd_lds_bytes_per_wave", &x266hip_ctx::satd_lds_per_wave, 2048, 163840, 1},
-    {"dct32_lds_pad_bytes", &x266hip_ctx::lds_pad_dct, 0, 160 * 1024, 1},
-    {"dct32_inv_lds_pad_bytes", &x266hip_ctx::lds_pad_inv, 0, 160 * 1024, 1},
-    {"satd_lds_pad_bytes", &x266hip_ctx::lds_pad_satd, 0, 160 * 1024, 1},
+    {"satd_groups_per_wave", &x266hip_ctx::satd_groups_per_wave, 0, 4096, 1},
+    {"satd_wg_threads", &x266hip_ctx::satd_wg_threads, 0, 256, 64},
+    {"satd_lds_bytes_per_wave", &x266hip_ctx::satd_lds_per_wave, 0, 65536, 1},
+    {"tile_tiles_per_wave", &x266hip_ctx::tile_tiles_per_wave, 0, 64, 1},
     {"me_tile_rows", &x266hip_ctx::me_tile_rows, 0, 8, 1},
-    {"intra_rounds", &x266hip_ctx::intra_rounds, 1, 16, 1},
-    {"diag_passthrough", &x266hip_ctx::passthrough, 0, 1, 1},
-    {"diag_satd_shape", &x266hip_ctx::satd_shape, 0, 5, 1},
-    {"diag_satd_interleave", &x266hip_ctx::satd_interleave, 0, 1, 1},
-    {"diag_tr32_simple", &x266hip_ctx::tr32_simple, 0, 1, 1},
 };
 
 static const OptionDesc *find_option(const char *key)
@@ -523,7 +495,7 @@ int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out, s
 int xHipMemCeilingDev(x266hip_ctx *ctx, int kind, const void *d_src, void *d_dst, size_t bytes, void *stream)
 {
     if (!ctx) return X266HIP_EINVAL;
-    if (kind < X266_MEM_COPY || kind > X266_MEM_WRITE) return fail(ctx, X266HIP_EINVAL, "xHipMemCeilingDev: kind must be X266_MEM_COPY, _READ or _WRITE");
+    if (kind < X266_MEM_COPY || kind > X266_MEM_READ_PROBE) return fail(ctx, X266HIP_EINVAL, "xHipMemCeilingDev: kind must be X266_MEM_COPY, _READ, _WRITE or _READ_PROBE");
     if ((bytes & 15u) || bad_ptrs(kind == X266_MEM_WRITE ? d_dst : d_src, d_dst, bytes)) return fail(ctx, X266HIP_EINVAL, "xHipMemCeilingDev: NULL or unaligned buffer, or bytes not a multiple of 16");
     X_DEV(ctx);
     const hipError_t e = launch_mem_ceiling(kind, d_src, d_dst, bytes, (hipStream_t)stream);
@@ -538,7 +510,7 @@ int xIntra32PredictDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const u
     if (n && (!d_refs || !d_modes || !d_pred || (((uintptr_t)d_refs | (uintptr_t)d_pred) & 15u) || ((uintptr_t)d_ref_index & 3u)))
         return fail(ctx, X266HIP_EINVAL, "xIntra32PredictDev: NULL or unaligned buffer");
     X_DEV(ctx);
-    hipError_t e = launch_intra32_predict(d_refs, d_modes, d_ref_index, d_pred, n, ctx->intra_rounds, (hipStream_t)stream);
+    hipError_t e = launch_intra32_predict(d_refs, d_modes, d_ref_index, d_pred, n, x266hip_ctx::kIntraRounds, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "intra launch", e);
     return X266HIP_OK;
 }
@@ -578,25 +550,40 @@ int xTransformFwdBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
     if (n && ((uintptr_t)d_offsets & 3u)) return fail(ctx, X266HIP_EINVAL, "xTransformFwdBatchDev: unaligned offset table");
     if (!ctx->tr_tables_valid) return fail(ctx, X266HIP_EDEVICE, "xTransformFwdBatchDev: the transform tables of this context are invalid (a failed xTransformSetMatrix)");
     X_DEV(ctx);
-    if (size == 32) {
-        if (!d_offsets && !ctx->tr32_simple) return launch_op(ctx, 0, d_in, d_out, n, (hipStream_t)stream);
-        LaunchCfg cfg32 = cfg_for(ctx, 0);
-        cfg32.units_per_wave = ctx->tr_tiles_per_wave;
-        cfg32.lds_stage = ctx->tr_lds_stage;
-        cfg32.wg_threads = ctx->dct_wg_threads;
-        cfg32.lds_bytes_per_wave = ctx->dct_lds_per_wave;
-        hipError_t e32 = launch_transform_small(5, d_in, d_out, n, ctx->d_fwd, d_offsets, cfg32, (hipStream_t)stream);
-        if (e32 != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "transform launch", e32);
-        return X266HIP_OK;
-    }
+    if (size == 32 && !d_offsets) return launch_op(ctx, 0, d_in, d_out, n, (hipStream_t)stream);
     const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
     LaunchCfg cfg = cfg_for(ctx, 0);
-    cfg.units_per_wave = ctx->tr_tiles_per_wave;
-    cfg.lds_stage = ctx->tr_lds_stage;
-    cfg.wg_threads = ctx->dct_wg_threads;
-    cfg.lds_bytes_per_wave = ctx->dct_lds_per_wave;
-    hipError_t e = launch_transform_small(l + 2, d_in, d_out, n, ctx->d_tr[type][l], d_offsets, cfg, (hipStream_t)stream);
+    cfg.units_per_wave = 1;                                             // one 32x32 tile per wave (profiles/r01_launch_sweep.txt)
+    hipError_t e = size == 32 ? launch_transform_small(5, d_in, d_out, n, ctx->d_fwd, d_offsets, cfg, (hipStream_t)stream)
+                              : launch_transform_small(l + 2, d_in, d_out, n, ctx->d_tr[type][l], d_offsets, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "transform launch", e);
+    return X266HIP_OK;
+}
+
+// All or nothing: the device tables are built from `next`, a COPY of the slot matrices with the wanted changes, and the context's
+// own copy changes only once every upload has succeeded; after a failed upload the old tables are put back, and if even that fails
+// the transform set of this context is marked unusable (its calls then fail) rather than left half old, half new.
+static int commit_slot_matrices(x266hip_ctx *ctx, const SlotMatrices &next, const char *who)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "transform matrices: device synchronisation");   // launches in flight read the tables
+    DctOps *h = new (std::nothrow) DctOps;
+    if (!h) return fail(ctx, X266HIP_ENOMEM, who);
+    bool ok = true, touched = false;
+    for (int slot = 0; slot < 2 && ok; ++slot)
+        for (int l = 0; l < 3 && ok; ++l)
+            if (std::memcmp(next[slot][l], ctx->slot_mat[slot][l], 256)) { touched = true; ok = upload_slot_tables(ctx, next, slot, l, h); }
+    if (!ok) {
+        bool back = true;
+        for (int slot = 0; slot < 2 && back; ++slot)
+            for (int l = 0; l < 3 && back; ++l)
+                if (std::memcmp(next[slot][l], ctx->slot_mat[slot][l], 256)) back = upload_slot_tables(ctx, ctx->slot_mat, slot, l, h);
+        ctx->tr_tables_valid = back;
+    }
+    delete h;
+    if (!ok) return fail(ctx, X266HIP_EDEVICE, ctx->tr_tables_valid ? "transform matrices: table upload failed, previous matrices kept"
+                                                                      : "transform matrices: table upload failed and the previous tables could not be restored: transform set unusable");
+    if (touched) std::memcpy(ctx->slot_mat, next, sizeof(SlotMatrices));
+    ctx->tr_tables_valid = true;
     return X266HIP_OK;
 }
 
@@ -607,26 +594,34 @@ int xTransformSetMatrix(x266hip_ctx *ctx, int slot, int size, const int8_t *m)
     if (size != 4 && size != 8 && size != 16)
         return fail(ctx, X266HIP_EINVAL, "xTransformSetMatrix: size must be 4, 8 or 16 (the 32-point DCT-II is the reference's g_t32 and stays)");
     X_DEV(ctx);
-    if (hipDeviceSynchronize() != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "xTransformSetMatrix: device synchronisation");   // launches in flight read the tables
     const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
-    // All or nothing: the device tables are built from a COPY of the slot matrices and the context's own copy changes only
-    // once every upload has succeeded; after a failed upload the old tables are put back, and if even that fails the
-    // transform set of this context is marked unusable (its calls then fail) rather than left half old, half new.
     SlotMatrices next;
     std::memcpy(next, ctx->slot_mat, sizeof next);
     if (m) std::memcpy(next[slot][l], m, (size_t)size * size);
     else default_slot_matrix(slot, size, next[slot][l]);
-    DctOps *h = new (std::nothrow) DctOps;
-    if (!h) return fail(ctx, X266HIP_ENOMEM, "xTransformSetMatrix");
-    const bool ok = upload_slot_tables(ctx, next, slot, l, h);
-    if (!ok) ctx->tr_tables_valid = upload_slot_tables(ctx, ctx->slot_mat, slot, l, h);
-    delete h;
-    if (!ok) return fail(ctx, X266HIP_EDEVICE, ctx->tr_tables_valid ? "xTransformSetMatrix: table upload failed, previous matrices kept"
-                                                                      : "xTransformSetMatrix: table upload failed and the previous tables could not be restored: transform set unusable");
-    std::memcpy(ctx->slot_mat, next, sizeof next);
-    ctx->tr_tables_valid = true;
-    return X266HIP_OK;
+    const int rc = commit_slot_matrices(ctx, next, "xTransformSetMatrix");
+    if (rc == X266HIP_OK && slot == 1) ctx->slot1_preset = -1;
+    return rc;
 }
+
+int xTransformUsePreset(x266hip_ctx *ctx, int preset)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (preset < X266_PRESET_CLOSED_FORM || preset > X266_PRESET_VTM_DCT8) return fail(ctx, X266HIP_EINVAL, "xTransformUsePreset: unknown preset");
+    X_DEV(ctx);
+    SlotMatrices next;
+    std::memcpy(next, ctx->slot_mat, sizeof next);
+    for (int l = 0; l < 3; ++l) {
+        std::memset(next[1][l], 0, 256);
+        if (preset == X266_PRESET_CLOSED_FORM) default_slot_matrix(1, 4 << l, next[1][l]);
+        else vtm_slot1_matrix(4 << l, preset == X266_PRESET_VTM_DCT8, next[1][l]);
+    }
+    const int rc = commit_slot_matrices(ctx, next, "xTransformUsePreset");
+    if (rc == X266HIP_OK) ctx->slot1_preset = preset;
+    return rc;
+}
+
+int xTransformPreset(const x266hip_ctx *ctx) { return ctx ? ctx->slot1_preset : -1; }
 
 int xTransformGetMatrix(const x266hip_ctx *ctx, int slot, int size, int8_t *m)
 {
@@ -644,8 +639,7 @@ int xTransformTilesDev(x266hip_ctx *ctx, int inverse, const int16_t *d_in, int16
     if (!ctx->tr_tables_valid) return fail(ctx, X266HIP_EDEVICE, "xTransformTilesDev: the transform tables of this context are invalid (a failed xTransformSetMatrix)");
     X_DEV(ctx);
     LaunchCfg cfg = cfg_for(ctx, inverse ? 1 : 0);
-    cfg.wg_threads = inverse ? ctx->dct_inv_wg_threads : ctx->dct_wg_threads;
-    cfg.lds_bytes_per_wave = ctx->tile_lds_per_wave;                    // dependent fetches per tile (class, images, data): more waves in flight pay here
+    cfg.lds_bytes_per_wave = x266hip_ctx::kTileLdsPerWave;
     cfg.units_per_wave = ctx->tile_tiles_per_wave ? ctx->tile_tiles_per_wave : 2;   // measured optimum (profiles/r03_tiles_one_launch.txt): the wave's table copy serves two tiles
     hipError_t e = launch_transform_tiles(inverse != 0, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class,
                                           inverse ? ctx->d_tile_inv : ctx->d_tile_fwd, cfg, (hipStream_t)stream);
@@ -707,10 +701,7 @@ int xDct32FwdFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const
     if (!d_cur || !d_pred || !d_coef || ((((uintptr_t)d_cur | (uintptr_t)d_pred | (uintptr_t)d_coef)) & 15u))
         return fail(ctx, X266HIP_EINVAL, "xDct32FwdFromTilesDev: NULL or unaligned buffer");
     X_DEV(ctx);
-    LaunchCfg cfg = cfg_for(ctx, 0);
-    cfg.wg_threads = ctx->dct_wg_threads;
-    cfg.lds_bytes_per_wave = ctx->dct_lds_per_wave;
-    hipError_t e = launch_dct32_from_tiles(d_cur, d_pred, d_coef, width, height, ctx->d_fwd, cfg, (hipStream_t)stream);
+    hipError_t e = launch_dct32_from_tiles(d_cur, d_pred, d_coef, width, height, ctx->d_fwd, cfg_for(ctx, 0), (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fused transform launch", e);
     return X266HIP_OK;
 }
@@ -723,7 +714,7 @@ int xSatd8x8FromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const 
     if (!d_cur || !d_pred || !d_out || ((((uintptr_t)d_cur | (uintptr_t)d_pred)) & 15u) || ((uintptr_t)d_out & 3u))
         return fail(ctx, X266HIP_EINVAL, "xSatd8x8FromTilesDev: NULL or unaligned buffer");
     X_DEV(ctx);
-    hipError_t e = launch_satd8x8_from_tiles(d_cur, d_pred, d_out, width, height, cfg_for(ctx, 2), (hipStream_t)stream);
+    hipError_t e = launch_satd8x8_from_tiles(d_cur, d_pred, d_out, width, height, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fused satd launch", e);
     return X266HIP_OK;
 }
@@ -753,10 +744,7 @@ int xTransformInvBatchDev(x266hip_ctx *ctx, int type, int size, const int16_t *d
     X_DEV(ctx);
     if (size == 32 && !d_offsets) return launch_op(ctx, 1, d_in, d_out, n, (hipStream_t)stream);
     const int l = size == 4 ? 0 : (size == 8 ? 1 : 2);
-    LaunchCfg cfg = cfg_for(ctx, 1);
-    cfg.units_per_wave = ctx->dct_inv_blocks_per_wave;
-    cfg.wg_threads = ctx->dct_inv_wg_threads;
-    cfg.lds_bytes_per_wave = ctx->dct_inv_lds_per_wave;
+    const LaunchCfg cfg = cfg_for(ctx, 1);
     hipError_t e = size == 32 ? launch_transform_small_inv(5, d_in, d_out, n, ctx->d_inv_lds, d_offsets, cfg, (hipStream_t)stream)
                               : launch_transform_small_inv(l + 2, d_in, d_out, n, ctx->d_tr_inv[type][l], d_offsets, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "inverse transform launch", e);
@@ -814,12 +802,17 @@ int xSad8x8SearchDev(x266hip_ctx *ctx, const uint8_t *d_cur, intptr_t cur_stride
 }
 
 // ---- host-pointer batch API --------------------------------------------------
-// Chunks of the batch rotate over three staging slots, each with its own
-// stream: H2D(i+1) and D2H(i-1) overlap kernel(i).
+// Chunks of the batch rotate over three staging slots; uploads, kernels and downloads each have a stream of their own
+// and are ordered by the slots' events: H2D(i+1) and D2H(i-1) overlap kernel(i).
 static int ensure_staging(x266hip_ctx *ctx, size_t in_bytes, size_t out_bytes)
 {
-    for (int i = 0; i < x266hip_ctx::kSlots; ++i)
-        if (!ctx->stage_stream[i]) X_HIP(ctx, hipStreamCreateWithFlags(&ctx->stage_stream[i], hipStreamNonBlocking));
+    for (hipStream_t &st : ctx->stage_stream)
+        if (!st) X_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (int i = 0; i < x266hip_ctx::kSlots; ++i) {
+        if (!ctx->stage_up[i]) X_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_up[i], hipEventDisableTiming));
+        if (!ctx->stage_done[i]) X_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+        if (!ctx->stage_down[i]) X_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_down[i], hipEventDisableTiming));
+    }
     if (in_bytes > ctx->stage_in_bytes) {
         for (int i = 0; i < x266hip_ctx::kSlots; ++i) {
             if (ctx->d_stage_in[i]) (void)hipFree(ctx->d_stage_in[i]);
@@ -839,51 +832,98 @@ static int ensure_staging(x266hip_ctx *ctx, size_t in_bytes, size_t out_bytes)
     return X266HIP_OK;
 }
 
+// Uploads + kernels are issued by the calling thread, downloads by a helper thread that lives for the call: a copy from / to
+// PAGEABLE memory blocks the thread that issues it while the runtime stages it, so one thread keeps only one direction of the
+// link busy (27 GB/s each way); two threads reach what pinned buffers reach, 43-44 GB/s each way of the 48.5 the link gives
+// with both directions running (profiles/r04_hostpipe.txt).
 static int host_batch(x266hip_ctx *ctx, int op, const void *in, void *out, size_t n, size_t in_unit, size_t out_unit)
 {
     if (!ctx) return X266HIP_EINVAL;
     if (n == 0) return X266HIP_OK;
     if (!in || !out) return fail(ctx, X266HIP_EINVAL, "NULL host buffer");
     X_DEV(ctx);
-    const size_t chunk_bytes = (size_t)32 << 20;                       // 32 MiB of input per chunk
+    const size_t chunk_bytes = (size_t)16 << 20;                       // 16 MiB of input per chunk
     size_t chunk = chunk_bytes / in_unit;
     if (chunk > n) chunk = n;
     int rc = ensure_staging(ctx, chunk * in_unit, chunk * out_unit);
     if (rc) return rc;
-    // optional: pin the caller's pageable buffers while the call runs (the runtime otherwise stages them through its own
-    // pinned bounce buffers); only where the registration cost can pay, and never for memory that is pinned already
-    bool reg_in = false, reg_out = false;
-    if (ctx->host_register && n * in_unit >= ((size_t)64 << 20)) {
-        hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, in) != hipSuccess) reg_in = hipHostRegister(const_cast<void *>(in), n * in_unit, hipHostRegisterDefault) == hipSuccess;
-        if (hipPointerGetAttributes(&attr, out) != hipSuccess) reg_out = hipHostRegister(out, n * out_unit, hipHostRegisterDefault) == hipSuccess;
-        (void)hipGetLastError();
+    hipStream_t s_up = ctx->stage_stream[0], s_k = ctx->stage_stream[1], s_down = ctx->stage_stream[2];
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    constexpr long kSlots = x266hip_ctx::kSlots;
+
+    struct Shared {
+        std::mutex m;
+        std::condition_variable cv;
+        long launched = 0, drained = 0;                               // chunks whose kernel is enqueued / whose results have arrived
+        bool stop = false;                                            // a failure on either side: both loops leave
+        hipError_t down_error = hipSuccess;
+    } sh;
+
+    std::thread down;
+    if (n_chunks > 1) {
+        down = std::thread([&]() {
+            (void)hipSetDevice(ctx->device);
+            for (size_t i = 0; i < n_chunks; ++i) {
+                {
+                    std::unique_lock<std::mutex> lk(sh.m);
+                    sh.cv.wait(lk, [&] { return sh.stop || sh.launched > (long)i; });
+                    if (sh.launched <= (long)i) return;              // stopped before this chunk was issued
+                }
+                const int slot = (int)(i % kSlots);
+                const size_t done = i * chunk, cnt = n - done < chunk ? n - done : chunk;
+                hipError_t e = hipStreamWaitEvent(s_down, ctx->stage_done[slot], 0);
+                if (e == hipSuccess) e = hipMemcpyAsync((char *)out + done * out_unit, ctx->d_stage_out[slot], cnt * out_unit, hipMemcpyDeviceToHost, s_down);
+                if (e == hipSuccess) e = hipStreamSynchronize(s_down);
+                std::lock_guard<std::mutex> lk(sh.m);
+                if (e != hipSuccess) { sh.down_error = e; sh.stop = true; }
+                sh.drained = (long)i + 1;
+                sh.cv.notify_all();
+                if (e != hipSuccess) return;
+            }
+        });
     }
-    size_t done = 0;
-    int slot = 0;
     hipError_t e = hipSuccess;
     const char *what = "";
 #define STAGE(call) do { if (e == hipSuccess && rc == X266HIP_OK) { e = (call); what = #call; } } while (0)
-    while (done < n && e == hipSuccess && rc == X266HIP_OK) {
-        const size_t cnt = (n - done < chunk) ? n - done : chunk;
-        hipStream_t s = ctx->stage_stream[slot];
-        STAGE(hipStreamSynchronize(s));                               // slot's previous chunk fully drained
-        STAGE(hipMemcpyAsync(ctx->d_stage_in[slot], (const char *)in + done * in_unit, cnt * in_unit, hipMemcpyHostToDevice, s));
-        if (e == hipSuccess) rc = launch_op(ctx, op, ctx->d_stage_in[slot], ctx->d_stage_out[slot], cnt, s);
-        STAGE(hipMemcpyAsync((char *)out + done * out_unit, ctx->d_stage_out[slot], cnt * out_unit, hipMemcpyDeviceToHost, s));
-        done += cnt;
-        slot = slot + 1 == x266hip_ctx::kSlots ? 0 : slot + 1;
+    for (size_t i = 0; i < n_chunks && e == hipSuccess && rc == X266HIP_OK; ++i) {
+        const int slot = (int)(i % kSlots);
+        const size_t done = i * chunk, cnt = n - done < chunk ? n - done : chunk;
+        if (n_chunks > 1) {                                             // the slot's previous chunk has left
+            std::unique_lock<std::mutex> lk(sh.m);
+            sh.cv.wait(lk, [&] { return sh.stop || (long)i - sh.drained < kSlots; });
+            if (sh.stop) break;
+        }
+        STAGE(hipMemcpyAsync(ctx->d_stage_in[slot], (const char *)in + done * in_unit, cnt * in_unit, hipMemcpyHostToDevice, s_up));
+        STAGE(hipEventRecord(ctx->stage_up[slot], s_up));
+        STAGE(hipStreamWaitEvent(s_k, ctx->stage_up[slot], 0));
+        if (e == hipSuccess) rc = launch_op(ctx, op, ctx->d_stage_in[slot], ctx->d_stage_out[slot], cnt, s_k);
+        STAGE(hipEventRecord(ctx->stage_done[slot], s_k));
+        if (n_chunks == 1) {                                            // a small call: no helper thread, the download follows in stream order
+            STAGE(hipStreamWaitEvent(s_down, ctx->stage_done[slot], 0));
+            STAGE(hipMemcpyAsync(out, ctx->d_stage_out[slot], cnt * out_unit, hipMemcpyDeviceToHost, s_down));
+        } else if (e == hipSuccess && rc == X266HIP_OK) {
+            std::lock_guard<std::mutex> lk(sh.m);
+            sh.launched = (long)i + 1;
+            sh.cv.notify_all();
+        }
     }
 #undef STAGE
+    if (down.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(sh.m);
+            if (e != hipSuccess || rc != X266HIP_OK) sh.stop = true;
+            sh.cv.notify_all();
+        }
+        down.join();                                                    // it leaves once every issued chunk has been downloaded (or on a failure)
+    }
     // Drain EVERY staging stream on every path: after a failure an already enqueued D2H copy must not still be
     // writing the caller's `out` once this function has returned (the caller may free it).
-    for (int i = 0; i < x266hip_ctx::kSlots; ++i) {
-        const hipError_t es = hipStreamSynchronize(ctx->stage_stream[i]);
+    for (hipStream_t st : ctx->stage_stream) {
+        const hipError_t es = hipStreamSynchronize(st);
         if (e == hipSuccess && es != hipSuccess) { e = es; what = "hipStreamSynchronize(stage)"; }
     }
-    if (reg_in) (void)hipHostUnregister(const_cast<void *>(in));
-    if (reg_out) (void)hipHostUnregister(out);
     if (rc != X266HIP_OK) return rc;
+    if (e == hipSuccess && sh.down_error != hipSuccess) { e = sh.down_error; what = "download (helper thread)"; }
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, what, e);
     return X266HIP_OK;
 }
@@ -901,6 +941,26 @@ int xHipMalloc(x266hip_ctx *ctx, void **d_ptr, size_t bytes)
     if (bytes == 0) return X266HIP_OK;
     hipError_t e = hipMalloc(d_ptr, bytes);
     if (e != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "hipMalloc", e);
+    return X266HIP_OK;
+}
+
+int xHipHostAlloc(x266hip_ctx *ctx, void **h_ptr, size_t bytes)
+{
+    if (!ctx || !h_ptr) return X266HIP_EINVAL;
+    X_DEV(ctx);
+    *h_ptr = nullptr;
+    if (bytes == 0) return X266HIP_OK;
+    hipError_t e = hipHostMalloc(h_ptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, X266HIP_ENOMEM, "hipHostMalloc", e);
+    return X266HIP_OK;
+}
+
+int xHipHostFree(x266hip_ctx *ctx, void *h_ptr)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (!h_ptr) return X266HIP_OK;
+    X_DEV(ctx);
+    X_HIP(ctx, hipHostFree(h_ptr));
     return X266HIP_OK;
 }
 

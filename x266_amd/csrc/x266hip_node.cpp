@@ -151,6 +151,7 @@ struct x266hip_nstream {
     // three slots: a frame's kernels take ~30 us, and only a third frame in flight covers the ramp and tail of the two before it
     // (one-rank 8K stream: 36.8 -> 34.3 us per frame); kRing >= kSlots + 3 step records
     static constexpr int kSlots = 3, kRing = 6;
+    static_assert(X266_STREAM_IN_RING == kSlots + 1 && X266_STREAM_OUT_RING == kSlots + 2 && kRing >= X266_STREAM_OUT_RING, "ring sizes of the header follow the slots");
     static_assert(kSlots == LocalRank::kComputeStreams, "one compute stream per slot");
     struct Step {
         bool has_frame = false;
@@ -167,6 +168,7 @@ struct x266hip_nstream {
     };
     std::vector<PerRank> per;
     long n_steps = 0;
+    long flushed_steps = 0;                // steps [0, flushed_steps) are complete: their buffers belong to the caller again
 };
 
 namespace {
@@ -269,6 +271,7 @@ struct Xfer {
 // peer-side entry and its matching root-side entry (same order on both sides by construction).
 int post_transfers(x266hip_node *node, const std::vector<Xfer> &xs)
 {
+    if (node->failed) return nfail(node, X266HIP_ECOMM, "an earlier step of this node failed and its communicators were aborted");
     if (xs.empty()) return X266HIP_OK;
     if (node->transport == 0) {
         if (!node->have_rccl) return nfail(node, X266HIP_ECOMM, "RCCL did not initialise on this node");
@@ -504,10 +507,20 @@ int xHipNodeRcclInfo(int *version, char *path, size_t path_cap)
     return X266HIP_OK;
 }
 
+static int self_test_impl(x266hip_node *node);
+
 int xHipNodeSelfTest(x266hip_node *node)
 {
     if (!node) return X266HIP_EINVAL;
+    if (node->failed) return nfail(node, X266HIP_ECOMM, "an earlier step of this node failed and its communicators were aborted");
     if (!node->have_rccl) return nfail(node, X266HIP_ECOMM, "RCCL did not initialise");
+    const int rc = self_test_impl(node);
+    if (rc == X266HIP_ECOMM || rc == X266HIP_EDEVICE) abort_comms(node);   // a rank may sit in a group that will never complete
+    return rc;
+}
+
+static int self_test_impl(x266hip_node *node)
+{
     Rccl *R = rccl();
     const size_t n = 1 << 16;                                         // 64 Ki uint32 each way
     const int W = node->world;
@@ -638,7 +651,7 @@ int xNodeFrameStreamCreate(x266hip_node *node, int width, int height, x266hip_ns
 namespace {
 
 // Step t: transfers {inputs of frame t, results of frame t-2}, then kernels of frame t.
-int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units, void *producer_stream, bool has_frame)
+int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units, void *producer_stream, bool has_frame, bool *posted)
 {
     x266hip_node *node = s->node;
     if (node->failed) return nfail(node, X266HIP_ECOMM, "an earlier step of this node failed and its communicators were aborted");
@@ -658,6 +671,22 @@ int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d
                     return nfail(node, X266HIP_EINVAL, "xNodeStreamPush: NULL or unaligned frame buffer on the root");
                 cur.d_in[l] = (const char *)d_in[l];
                 cur.d_out[l] = (char *)d_out[l];
+            }
+        }
+        // buffer ownership (include/x266hip.h, xNodeStreamPush): this frame's outputs must not overlap the outputs of the frames that
+        // are still in flight -- the previous X266_STREAM_OUT_RING - 1 steps unless a flush has completed them
+        if (drives_root) {
+            for (long back = 1; back < X266_STREAM_OUT_RING && back <= t - s->flushed_steps; ++back) {
+                const x266hip_nstream::Step &prev = s->ring[(t - back) % x266hip_nstream::kRing];
+                if (!prev.has_frame) continue;
+                for (int l = 0; l < s->n_lanes; ++l)
+                    for (int m = 0; m < s->n_lanes; ++m) {
+                        if (!cur.units[l] || !prev.units[m]) continue;
+                        const char *a0 = cur.d_out[l], *a1 = a0 + cur.units[l] * kOutUnit[s->op[l]];
+                        const char *b0 = prev.d_out[m], *b1 = b0 + prev.units[m] * kOutUnit[s->op[m]];
+                        if (a0 < b1 && b0 < a1)
+                            return nfail(node, X266HIP_EINVAL, "xNodeStreamPush: an output buffer overlaps the output of a frame still in flight (output rings need X266_STREAM_OUT_RING buffers)");
+                    }
             }
         }
     }
@@ -730,6 +759,7 @@ int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d
             }
         }
     }
+    *posted = true;                                                  // from here on a failure leaves peers in a group: the caller aborts
     int rc = post_transfers(node, xs);
     if (rc) return rc;
     // (3) kernels of frame t behind the transfers
@@ -773,8 +803,11 @@ int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d
 
 int stream_step(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units, void *producer_stream, bool has_frame)
 {
-    const int rc = stream_step_impl(s, d_in, d_out, units, producer_stream, has_frame);
-    if (rc != X266HIP_OK && rc != X266HIP_EINVAL) abort_comms(s->node);     // argument errors are detected before anything is posted
+    bool posted = false;
+    const int rc = stream_step_impl(s, d_in, d_out, units, producer_stream, has_frame, &posted);
+    // a failure after the step's group was posted -- whatever its code: a per-rank launch can still refuse an argument there --
+    // or any non-argument failure before it: the other ranks will post a group this rank never joins
+    if (rc != X266HIP_OK && (posted || rc != X266HIP_EINVAL)) abort_comms(s->node);
     return rc;
 }
 
@@ -810,6 +843,7 @@ int xNodeStreamFlush(x266hip_nstream *s)
         N_HIP(s->node, hipStreamSynchronize(lr.comm_stream));
         for (hipStream_t cs : lr.compute) N_HIP(s->node, hipStreamSynchronize(cs));
     }
+    s->flushed_steps = s->n_steps;
     return X266HIP_OK;
 }
 
@@ -834,6 +868,7 @@ int xNodeStreamWait(x266hip_nstream *s, long ticket)
             if (s->per[i].xfer_recorded[slot]) N_HIP(s->node, hipEventSynchronize(s->per[i].ev_xfer[slot]));
         }
     }
+    if (ticket + 1 > s->flushed_steps) s->flushed_steps = ticket + 1;   // results return in step order: everything up to the ticket is complete
     return X266HIP_OK;
 }
 
@@ -870,10 +905,23 @@ int xNodeBatchScatterGather(x266hip_node *node, int op, const void *d_in, void *
     return rc;
 }
 
+static int node_search_impl(x266hip_node *node, const uint8_t *d_cur, intptr_t cur_stride, const uint8_t *d_ref,
+                            intptr_t ref_stride, int width, int height, int range, int n_stripes, x266_me_result_t *d_best);
+
 int xNodeSatd8x8Search(x266hip_node *node, const uint8_t *d_cur, intptr_t cur_stride, const uint8_t *d_ref,
                        intptr_t ref_stride, int width, int height, int range, int n_stripes, x266_me_result_t *d_best)
 {
     if (!node) return X266HIP_EINVAL;
+    if (node->failed) return nfail(node, X266HIP_ECOMM, "an earlier step of this node failed and its communicators were aborted");
+    // argument errors are detected before anything is posted (node_search_impl validates first); everything later leaves peers in a group
+    const int rc = node_search_impl(node, d_cur, cur_stride, d_ref, ref_stride, width, height, range, n_stripes, d_best);
+    if (rc == X266HIP_ECOMM || rc == X266HIP_EDEVICE || rc == X266HIP_ENOMEM) abort_comms(node);
+    return rc;
+}
+
+static int node_search_impl(x266hip_node *node, const uint8_t *d_cur, intptr_t cur_stride, const uint8_t *d_ref,
+                            intptr_t ref_stride, int width, int height, int range, int n_stripes, x266_me_result_t *d_best)
+{
     if (width < 8 || height < 8 || (width & 7) || (height & 7)) return nfail(node, X266HIP_EINVAL, "xNodeSatd8x8Search: frame size must be a multiple of 8");
     if (range < 1 || range > 64) return nfail(node, X266HIP_EINVAL, "xNodeSatd8x8Search: range must be 1..64");
     if (cur_stride < width || ref_stride < width + 2 * range) return nfail(node, X266HIP_EINVAL, "xNodeSatd8x8Search: stride too small");

@@ -132,6 +132,15 @@ class Node:
     def drives_root(self):
         return 0 in self.local_ranks
 
+    def rank_codec(self, local_index):
+        """The context of the local_index-th rank this process drives (xHipNodeCtx), as a borrowed Codec: lets a host run its own
+        work on that rank's device through the same ABI."""
+        from ._lib import Codec
+        p = self.L.xHipNodeCtx(self.h, local_index)
+        if not p:
+            raise X266Error("xHipNodeCtx(%d): no such local rank" % local_index)
+        return Codec.borrowed(p)
+
     def set_option(self, key, value):
         self._check(self.L.xHipNodeSetOption(self.h, key.encode(), int(value)), "xHipNodeSetOption(%s)" % key)
 
