@@ -39,7 +39,15 @@ def test_bench_small_run_has_every_leg_and_field():
     assert r["kernel_ms_per_launch"] <= d["ms_per_step"] * 1.0001
     for leg in ("dct32_inv", "dct32_fwd_inv_fused", "satd8x8", "satd8x8_me_search"):
         assert d["also"][leg]["kernel_ms_mean"] <= d["also"][leg]["ms_per_step"] * 1.0001, leg
-    # HBM bytes per launch: measured in this run by two rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE), or an honest label why not
+    # the same-run ceilings of THIS box and every HBM-bound leg expressed in them (round 4)
+    sb = r["same_box"]
+    assert 5.0 < sb["copy_TBps"] < 8.0 and 5.0 < sb["read_TBps"] < 8.0 and 4.5 < sb["write_TBps"] < 8.0 and sb["read_no_store_TBps"] >= 0.97 * sb["read_TBps"]
+    assert 0 < r["frac_of_same_box_copy"] <= 1.1 and 0 < d["also"]["satd8x8"]["roofline"]["frac_of_same_box_read"] <= 1.1
+    assert "frac_of_same_box_copy" in d["also"]["dct32_fwd_inv_fused"] and "frac_of_same_box_write" in d["also"]["intra32"]["predict"]
+    # the literal drop-in path (host pointers): PCIe-inclusive, next to what the link gives
+    h = d["also"]["host_api"]
+    assert h["pinned"]["same_result_as_pageable"] is True and h["pinned"]["GBps_each_way"] > 5 and h["link_GBps"]["each_way_both_directions_at_once"] > 5
+    # HBM bytes per launch: measured in this run by two rocprofv3 --pmc passes (counter factors calibrated on a copy of known size), or an honest label why not
     assert r["traffic_source"]
     if r["traffic"] is not None and "measured in this run" in r["traffic_source"]:
         assert 0.98 <= r["traffic"] / r["algorithmic_bytes_per_launch"] <= 1.10, r
@@ -73,6 +81,17 @@ def test_bench_two_ranks_share_the_gpu_and_agree_with_one_rank():
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["cpu_baseline"] is None
     assert two["output_checksum_sum_i16"] == one["output_checksum_sum_i16"]
     assert two["config"]["blocks_per_gpu"] == n
+    assert len(two["roofline"]["frac_by_rank"]) == 2 and min(two["roofline"]["frac_by_rank"]) > 0
+    # the same job WITHOUT torchrun on the command line: plain `python bench.py --gpus 2` spawns its own ranks (how a scaling harness
+    # that re-uses the single-GPU command shape would call it)
+    env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--dct-blocks", str(n), "--no-also", "--no-cpu-baseline"], cwd=ROOT, env=env2, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    self_spawned = json.loads(lines[0])
+    assert self_spawned["n_gpus"] == 2 and self_spawned["output_checksum_sum_i16"] == one["output_checksum_sum_i16"]
 
 
 def test_bench_node_legs_with_two_processes_under_the_rccl_model():
@@ -87,8 +106,9 @@ def test_bench_node_legs_with_two_processes_under_the_rccl_model():
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, X266_BENCH_SHARE_GPU="1", X266HIP_RCCL_LIB=model, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    # no torchrun on the command line: bench.py --gpus 2 spawns its own ranks
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                           "--dct-blocks", "16384", "--satd-blocks", "65536", "--stream8k", "6", "--no-transform-set", "--no-cpu-baseline"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -99,4 +119,9 @@ def test_bench_node_legs_with_two_processes_under_the_rccl_model():
     assert "node_layer_error" not in also, also.get("node_layer_error")
     assert also["stream8k"]["bit_exact_vs_single_device"] is True and also["stream8k"]["frames"] == 6
     assert also["dct32_scatter_gather"]["value"] > 0
+    # the N > 1 line carries what a reader needs to judge the multi-device numbers: per-rank roofline fractions, the RCCL every rank
+    # talks to, and the measured end-to-end rates NEXT TO the per-link prediction (153 GB/s per direction and peer)
+    assert len(d["roofline"]["frac_by_rank"]) == 2 and len(also["rccl_by_rank"]) == 2
+    assert also["dct32_scatter_gather"]["link_bound_blocks_per_s"] == pytest.approx(2 * 153e9 / 2048)
+    assert also["stream8k"]["link_bound_frames_per_s"] == pytest.approx(153e9 / ((32400 * 2048 + 518400 * 128) / 2))
     assert also["satd8x8_me_search_sharded"]["identical_to_single_device"] is True and also["satd8x8_me_search_sharded"]["stripes"] == 2

@@ -158,3 +158,21 @@ def test_python_fallback_of_the_plan_functions_equals_the_c_functions():
             for n_stripes in (1, 2, 3, 8, 300):
                 for stripe in range(min(n_stripes, 9)):
                     assert shard.me_stripe_py(height, rng, stripe, n_stripes) == me_stripe_plan(height, rng, stripe, n_stripes)
+
+
+def test_bench_spawns_its_own_ranks_when_run_plainly():
+    """`python bench.py --gpus 2` without WORLD_SIZE must become the torch.distributed.run job itself instead of
+    refusing.  Without a GPU both ranks stop at "needs an MI355X" -- which proves that two ranks were started and each got as far as
+    the device check (a GPU box runs the same path to the end in tests/test_gpu_bench.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU box runs the real thing (tests/test_gpu_bench.py)")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-also"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+    assert "needs torch.distributed.run" not in r.stderr

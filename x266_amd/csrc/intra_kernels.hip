@@ -353,6 +353,8 @@ hipError_t launch_intra32_predict(const x266_intra_ref_t *d_refs, const uint8_t 
     const size_t per_wave = (size_t)kUnits * rounds;
     const size_t waves = (n + per_wave - 1) / per_wave, wgs = (waves + 3) / 4;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    // (not write-bound: capping the resident waves the way the write-only stream likes it -- 10 per CU, 7.4 TB/s -- slows this
+    //  kernel from 5.4 to 3.2-5.1 TB/s written; it is paced by its own VALU + LDS work, profiles/r04_intra_occupancy.txt)
     hipLaunchKernelGGL(intra32_predict_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, d_refs, d_modes, d_ref_index, d_pred, n, rounds);
     return hipGetLastError();
 }
