@@ -407,17 +407,21 @@ def host_api_leg(codec, torch, n):
         return best
     hp_in, hp_out = torch.empty(nbytes, dtype=torch.uint8).pin_memory(), torch.empty(nbytes, dtype=torch.uint8).pin_memory()
     d_a, d_b = torch.empty(nbytes, dtype=torch.uint8, device="cuda"), torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    streams = [torch.cuda.Stream() for _ in range(4)]
 
-    def both():
+    def both(s1, s2):
         with torch.cuda.stream(s1):
             d_a.copy_(hp_in, non_blocking=True)
         with torch.cuda.stream(s2):
             hp_out.copy_(d_b, non_blocking=True)
+    # HIP multiplexes streams onto a few hardware queues; two streams that land on the same one serialise their copies. The link's
+    # two-way rate is what the best of a few stream pairs reaches.
+    two_way = max(nbytes / best_of(lambda a=a, b=b: both(a, b), reps=2) / 1e9 for a, b in ((streams[0], streams[1]), (streams[0], streams[2]),
+                                                                                              (streams[1], streams[3]), (streams[2], streams[3])))
     out["link_GBps"] = {"h2d_alone": nbytes / best_of(lambda: d_a.copy_(hp_in, non_blocking=True)) / 1e9,
                         "d2h_alone": nbytes / best_of(lambda: hp_out.copy_(d_b, non_blocking=True)) / 1e9,
-                        "each_way_both_directions_at_once": nbytes / best_of(both) / 1e9,
-                        "how": "one plain %d MiB copy from / to pinned memory per direction (torch)" % (nbytes >> 20)}
+                        "each_way_both_directions_at_once": two_way,
+                        "how": "one plain %d MiB copy from / to pinned memory per direction (torch); two-way: best of four stream pairs" % (nbytes >> 20)}
     del hp_in, hp_out, d_a, d_b
     x_dev = torch.empty(n * 1024, dtype=torch.int16, device="cuda")
     codec.fill_residual_dev(x_dev.data_ptr(), n * 1024, DCT_SEED, 0, 0)

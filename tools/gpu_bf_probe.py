@@ -28,4 +28,4 @@ for rnd in range(2):
             cd.time_kernel(OP_SATD8X8, din.ptr, dout.ptr, NS, 5)
             ms = min(cd.time_kernel(OP_SATD8X8, din.ptr, dout.ptr, NS, 20) for _ in range(3))
             print("%-20s tpb=%3d lds/wave=%5d: %.4f ms  %.3e blocks/s  %.2f TB/s" % (name, tpb, lds, ms, NS / ms * 1e3, NS * 132 / ms / 1e9), flush=True)
-cd.set_option("satd_variant", 0); cd.set_option("satd_wg_threads", 128); cd.set_option("satd_lds_bytes_per_wave", 6144)
+cd.set_option("satd_variant", 0); cd.set_option("satd_wg_threads", 0); cd.set_option("satd_lds_bytes_per_wave", 0)
