@@ -69,23 +69,23 @@ const char *xHipLastError(const x266hip_ctx *ctx);
 /* Device facts for reports: name, CU count, max engine clock (MHz), HBM bytes. */
 int  xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap,
                     int *cu_count, int *clock_mhz, size_t *hbm_bytes);
-/* Launch options, for A/B measurement (defaults are the measured optimum; results never depend on
- * them; unknown keys and out-of-range values return X266HIP_EINVAL).  The full list with ranges is
- * the kOptions table in x266_amd/csrc/x266hip_abi.hip; the ones that matter:
- *   "nontemporal"            cache-policy bits for line-dense accesses: 1 nt loads, 2 nt stores,
- *                            8 "sc1 nt" stores (default 11); 4 = hints on fragment loads too
- *   "dct32_lds_stage", "satd_lds_stage", "tr_lds_stage"
- *                            1 = move tiles with 1 KiB-linear instructions through LDS (default)
- *   "dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "dct32_fwdinv_blocks_per_wave",
- *   "satd_groups_per_wave", "tr_tiles_per_wave"
- *                            consecutive units one wave loops over
- *   "dct32_wg_threads", "dct32_inv_wg_threads", "satd_wg_threads" (64..256)
- *   "dct32_lds_bytes_per_wave", ... LDS charged per wave = cap on resident waves per CU
+/* Launch options, for A/B measurement (defaults are the measured optimum; results never depend on them; unknown keys and
+ * out-of-range values return X266HIP_EINVAL).  The complete list (the kOptions table of x266_amd/csrc/x266hip_abi.hip):
+ *   "dct32_variant"          0 matrix-core kernel, 2 the reference's even/odd butterfly on the vector ALU
+ *   "satd_variant"           0 by batch size (staged kernel below 3 Mi blocks, LDS-DMA kernel from there on), 1 staged kernel,
+ *                            2 radix-2 butterflies on the vector ALU, 3 LDS-DMA kernel
+ *                            (2 = the one comparison variant per kernel family north_star asks for)
+ *   "dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "dct32_fwdinv_blocks_per_wave" (1 / 2 / 4)
+ *                            consecutive blocks (tiles, for the transform set's inverses) one wave loops over
+ *   "dct32_wg_threads"       workgroup size of the DCT32 / transform-set kernels (64, 128, 192, 256; default 64)
+ *   "satd_groups_per_wave", "satd_wg_threads", "satd_lds_bytes_per_wave"
+ *                            SATD batch: 32-block groups per wave, workgroup size, LDS charged per wave (= cap on resident
+ *                            waves per CU); 0 (default) = the chosen kernel's own: 2 / 128 / 6144 staged, 4 / 256 / 16384 LDS-DMA
+ *   "tile_tiles_per_wave"    xTransformTilesDev: consecutive tiles per wave (0 = 2)
  *   "adaptive_per_wave"      shrink the per-wave run on small batches (default 1)
- *   "dct32_variant" / "satd_variant" 2 = the reference's butterfly on the vector ALU instead of the matrix core
- *                            (the one comparison variant per kernel family north_star asks for; 0 = default)
- *   "me_tile_rows"           motion-search tile height in block rows (0, the default: chosen from the frame size
- *                            and the CU count) */
+ *   "me_tile_rows"           motion-search tile height in block rows (0, the default: chosen from the frame size and the CU count)
+ * Rounds 1-3 had sixteen more (cache-policy bits, LDS staging on / off, padding, per-kernel LDS charges, ...): the forms they
+ * selected lost their A/Bs (profiles/r01_*.txt) and are gone. */
 int  xHipSetOption(x266hip_ctx *ctx, const char *key, int value);
 int  xHipGetOption(const x266hip_ctx *ctx, const char *key, int *value);
 
