@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""DESIGN.md section 5's measured table, generated from a committed bench line so that the prose cannot drift from it:
+    python tools/design_table.py profiles/r04_bench.json            # print the table
+    python tools/design_table.py profiles/r04_bench.json --write    # replace the region between the bench-table markers in DESIGN.md
+"""
+import json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BEGIN, END = "<!-- bench-table:begin (tools/design_table.py) -->", "<!-- bench-table:end -->"
+
+
+def f(x, d=3):
+    return ("%%.%df" % d) % x
+
+
+def e(x):
+    m = "%.2e" % x
+    mant, ex = m.split("e")
+    return "%se%d" % (mant, int(ex))
+
+
+def table(path):
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    a, r = d["also"], d["roofline"]
+    sb = r["same_box"]
+    ts, ft, fe, it, ha, s8 = a["transform_set"], a["fused_from_tiles"], a["front_end_and_sad"], a["intra32"], a["host_api"], a["stream8k"]
+    cl, mix = ts["classes"], ts["per_ctu_mixed"]
+    rows = []
+    add = lambda *c: rows.append("  | " + " | ".join(c) + " |")
+    add("kernel", "avg launch", "units/s", "of 8 TB/s", "of this box's stream")
+    add("---", "---", "---", "---", "---")
+    add("`dct32_lds_kernel<fwd>` 2²⁰ blocks", f(r["kernel_ms_per_launch"]) + " ms", e(d["value"]) + " blocks", "**" + f(r["frac"]) + "**", "**" + f(r["frac_of_same_box_copy"]) + "** copy")
+    i = a["dct32_inv"]
+    add("`dct32_lds_kernel<inv>`", f(i["kernel_ms_mean"]) + " ms", e(i["value"]), f(i["roofline"]["frac"]), f(i["roofline"]["frac_of_same_box_copy"]) + " copy")
+    u = a["dct32_fwd_inv_fused"]
+    add("`dct32_fwdinv_lds_kernel` (6144 B/block)", f(u["kernel_ms_mean"]) + " ms", e(u["value"]), f(u["hbm_frac"]), f(u["frac_of_same_box_copy"]) + " copy")
+    s = a["satd8x8"]
+    add("`satd8x8_dma_kernel` 2²⁴ blocks", f(s["kernel_ms_mean"]) + " ms", e(s["value"]) + " blocks", "**" + f(s["roofline"]["frac"]) + "**", "**" + f(s["roofline"]["frac_of_same_box_read"]) + "** read")
+    for fam, tag in (("dct2", "`tr_fwd_small_lds_kernel` DCT-II"), ("dst7", "… DST-VII"), ("dct2_inv", "`tr_inv_small_lds_kernel` DCT-II"), ("dst7_inv", "… DST-VII")):
+        c = [cl["%s_%dx%d" % (fam, n, n)] for n in (4, 8, 16)]
+        add(tag + " 4×4 / 8×8 / 16×16", " / ".join(f(x["kernel_ms_mean"]) for x in c) + " ms", " / ".join(e(x["value"]) for x in c), " / ".join(f(x["hbm_frac"], 2) for x in c),
+            " / ".join(f(x["frac_of_same_box_copy"], 2) for x in c) + " copy")
+    o, oi, sv = mix["per_ctu_one_launch"], mix["per_ctu_one_launch_inverse"], mix["seven_calls_over_offset_tables"]
+    add("`tr_tiles_kernel` (configs[3], one launch) fwd / inv", f(o["kernel_ms_mean"]) + " / " + f(oi["kernel_ms_mean"]) + " ms", e(o["value"]) + " / " + e(oi["value"]) + " CTUs",
+        f(o["hbm_frac"]) + " / " + f(oi["hbm_frac"]), f(o["frac_of_same_box_copy"]) + " / " + f(oi["frac_of_same_box_copy"]) + " copy")
+    add("seven calls over offset tables (comparison only)", f(sv["kernel_ms_mean"]) + " ms", e(sv["value"]) + " CTUs", f(sv["hbm_frac"]), f(sv["frac_of_same_box_copy"]))
+    dt, st = ft["dct32_from_tiles"], ft["satd8x8_from_tiles"]
+    add("`dct32_from_tiles_kernel` / `satd8x8_from_tiles_kernel`", f(dt["kernel_ms_mean"]) + " / " + f(st["kernel_ms_mean"]) + " ms",
+        e(dt["value"]) + " / " + e(st["value"]) + " blocks (two-kernel paths: " + e(ft["dct32_residual_then_transform"]["value"]) + " / " + e(ft["satd8x8_residual_then_cost"]["value"]) + ")",
+        f(dt["hbm_frac"]) + " / " + f(st["hbm_frac"]), f(dt["frac_of_same_box_copy"]) + " copy / " + f(st["frac_of_same_box_read"]) + " read")
+    cv = [fe[k] for k in ("conv_input_fmt", "conv_output_420", "residual_luma_32")]
+    add("`tile_convert_kernel` in / out, `residual_luma_kernel`", " / ".join(f(x["kernel_ms_mean"]) for x in cv) + " ms", " / ".join(f(x["GBps"] / 1e3, 2) for x in cv) + " TB/s",
+        " / ".join(f(x["hbm_frac"], 2) for x in cv), " / ".join(f(x["frac_of_same_box_copy"], 2) for x in cv) + " copy")
+    sd = [fe[k] for k in ("sad_8x8", "sad_16x16", "sad_64x64")]
+    add("`sad_kernel` 8×8 / 16×16 / 64×64", " / ".join(f(x["kernel_ms_mean"]) for x in sd) + " ms", " / ".join(f(x["GBps"] / 1e3, 2) for x in sd) + " TB/s",
+        " / ".join(f(x["hbm_frac"], 2) for x in sd), " / ".join(f(x["frac_of_same_box_read"], 2) for x in sd) + " read")
+    m, m2 = a["satd8x8_me_search"], a["sad8x8_me_search"]
+    add("`satd_search_kernel` one 4K frame, ±64", f(m["kernel_ms_mean"]) + " ms", e(m["value"]) + " SATD",
+        f(m["frac_of_v_sad_u16_floor"]) + " of the `v_sad_u16` floor at 2.4 GHz, **" + f(m["frac_of_v_sad_u16_floor_at_sclk"]) + "** at the %d MHz sysfs showed during the leg" % m["sclk_mhz"], "–")
+    add("`sad_search_kernel`", f(m2["kernel_ms_mean"]) + " ms", e(m2["value"]) + " SAD",
+        f(m2["frac_of_v_sad_u8_floor"]) + " of the `v_sad_u8` floor at 2.4 GHz, **" + f(m2["frac_of_v_sad_u8_floor_at_sclk"]) + "** at %d MHz" % m2["sclk_mhz"], "–")
+    p, dc = it["predict"], it["decide_35_modes"]
+    add("`intra32_predict_kernel` 2.1e6 predictions", f(p["kernel_ms_mean"]) + " ms", e(p["value"]) + " predictions", f(p["written_hbm_frac"]) + " written", f(p["frac_of_same_box_write"]) + " write — NOT write-bound (§11)")
+    add("`intra32_costs_kernel` × 35 modes", f(dc["kernel_ms_mean"]) + " ms", e(dc["value"]) + " blocks = " + e(dc["satd8x8_per_s"]) + " SATD", "VALU-bound", "–")
+    frame_bytes = 2 * (32400 * 2048) + 518400 * 128 + 518400 * 4
+    add("node layer, one rank, 7680×4320 stream", "%.1f µs per frame (kernel %.1f)" % (s8["ms_per_frame"] * 1e3, s8["kernel_us"]),
+        e(s8["frames_per_s"]) + " frames = " + e(s8["dct32_blocks_per_s"]) + " DCT32 + " + e(s8["satd8x8_blocks_per_s"]) + " SATD blocks",
+        f(frame_bytes * s8["frames_per_s"] / 8e12, 2), f(frame_bytes * s8["frames_per_s"] / (sb["copy_TBps"] * 1e12), 2) + " copy")
+    lk = ha["link_GBps"]
+    add("host-pointer `xDct32FwdBatch`, 2¹⁷ blocks, pageable / pinned", f(ha["pageable"]["ms"], 2) + " / " + f(ha["pinned"]["ms"], 2) + " ms", e(ha["pageable"]["blocks_per_s"]) + " / " + e(ha["pinned"]["blocks_per_s"]) + " blocks",
+        "PCIe: %.1f / %.1f GB/s each way" % (ha["pageable"]["GBps_each_way"], ha["pinned"]["GBps_each_way"]),
+        "%.2f / %.2f of the link with both directions running (%.1f GB/s each way; %.1f / %.1f alone)" % (ha["pageable"]["frac_of_link_both_directions"], ha["pinned"]["frac_of_link_both_directions"],
+                                                                                                  lk["each_way_both_directions_at_once"], lk["h2d_alone"], lk["d2h_alone"]))
+    head = ("  This box's streams (`roofline.same_box`): copy %.2f, read %.2f, read-no-store %.2f, write %.2f TB/s.  CPU baseline in the same line: %s blocks/s on %d threads (`%s`).\n"
+            % (sb["copy_TBps"], sb["read_TBps"], sb["read_no_store_TBps"], sb["write_TBps"], e(d["cpu_baseline"]["value"]), d["cpu_baseline"]["cores"], d["cpu_baseline"]["kind"]))
+    return head + "\n" + "\n".join(rows)
+
+
+def main():
+    path = sys.argv[1]
+    t = table(path)
+    if "--write" not in sys.argv:
+        print(t)
+        return
+    p = os.path.join(ROOT, "DESIGN.md")
+    s = open(p).read()
+    b, en = s.index(BEGIN), s.index(END)
+    s = s[:b] + BEGIN + "\n" + "  (generated from `%s`)\n\n" % os.path.relpath(os.path.abspath(path), ROOT) + t + "\n\n  " + s[en:]
+    open(p, "w").write(s)
+    print("DESIGN.md: table regenerated from", path)
+
+
+if __name__ == "__main__":
+    main()
