@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -860,7 +861,7 @@ static int host_batch(x266hip_ctx *ctx, int op, const void *in, void *out, size_
     } sh;
 
     std::thread down;
-    if (n_chunks > 1) {
+    if (n_chunks > 1) try {
         down = std::thread([&]() {
             (void)hipSetDevice(ctx->device);
             for (size_t i = 0; i < n_chunks; ++i) {
@@ -881,6 +882,8 @@ static int host_batch(x266hip_ctx *ctx, int op, const void *in, void *out, size_
                 if (e != hipSuccess) return;
             }
         });
+    } catch (const std::system_error &) {                               // no thread to be had: nothing has been issued yet
+        return fail(ctx, X266HIP_ENOMEM, "could not start the download thread of a host-pointer batch call");
     }
     hipError_t e = hipSuccess;
     const char *what = "";
