@@ -13,7 +13,7 @@
 // adjacent bytes of ref[], so one v_dot4_u32_u8 per sample against the weights (32 - f, f) with
 // the rounding term as the accumulator.  The vertical family (modes 18..34) produces rows and is
 // stored directly; the horizontal family (2..17) produces columns and is turned through a 1 KiB
-// LDS tile.  Stores are 1 KiB-linear, "sc1 nt" (x266_device.hpp).
+// LDS tile with the transposing read ds_read_b64_tr_b8.  Stores are 1 KiB-linear, "sc1 nt" (x266_device.hpp).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -154,15 +154,24 @@ __device__ __forceinline__ bool predict_line16(int mode, const unsigned char *le
     return false;
 }
 
-// lane (k, h) holds samples 16h..16h+15 of COLUMN k: scatter them into a row-major 32x32 byte tile
-template <int PITCH>
-__device__ __forceinline__ void scatter_column(unsigned char *tile, int lane, const uint32_t (&px)[4])
+// lane (k, h) holds samples 16h..16h+15 of COLUMN k in px[]; afterwards it holds 16 consecutive samples of a ROW and the return value
+// is their byte offset in the row-major 32x32 prediction.  The columns go to LDS as they are (a column-major tile, one b128 write per
+// lane) and come back through gfx950's transposing read, which turns 8x8 byte blocks: ds_read_b64_tr_b8 hands lane 16q + 8p + e, as
+// byte j, element e of the 8 bytes lane 16q + 2j + p addressed (tools/lds_tr8_read_test.hip).  Source lane 16q + 2j + p addresses
+// column 16H + j (second read: + 8), rows R..R+7 of block (R, H) = (8 ((2q + p) & 3), (2q + p) >> 2); the receiving lane holds row
+// R + e, columns 16H..16H+15.  (Round 3 scattered the column with sixteen ds_write_b8 per lane.)
+__device__ __forceinline__ unsigned turn_columns(unsigned char *cm, int lane, uint32_t (&px)[4])
 {
-    const int k = lane >> 1, h = lane & 1;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) tile[(16 * h + 4 * g + jj) * PITCH + k] = (unsigned char)(px[g] >> (8 * jj));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<v4i *>(cm + lane * 16) = v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]};      // cm[32 k + 16 h ..]
+    const int q = lane >> 4, s = lane & 15;
+    const int src_blk = 2 * q + (s & 1);
+    const unsigned src = (unsigned)(uintptr_t)cm + (unsigned)((16 * (src_blk >> 2) + (s >> 1)) * 32 + 8 * (src_blk & 3));   // low 32 bits of the generic pointer = LDS offset
+    u2 a, b;
+    asm volatile("ds_read_b64_tr_b8 %0, %2\n\tds_read_b64_tr_b8 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(src) : "memory");
+    px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y;
+    const int blk = 2 * q + ((lane >> 3) & 1);
+    return (unsigned)((8 * (blk & 3) + (lane & 7)) * 32 + 16 * (blk >> 2));
 }
 
 // A wave takes `rounds` x kUnits consecutive predictions.  Per round ONE round trip fetches the modes, the set indices and
@@ -225,14 +234,9 @@ __global__ __launch_bounds__(256) void intra32_predict_kernel(const x266_intra_r
             const int mode = __builtin_amdgcn_readlane(my_mode, j);
             const unsigned char *left = raw_all + j * kRawBytes, *top = left + 64;   // top[0] = corner
             uint32_t px[4];
-            if (predict_line16(mode, left, top, ext, lane, px)) {    // columns: turn through the tile
-                scatter_column<32>(tile, lane, px);
-                __builtin_amdgcn_wave_barrier();
-                const v4i row = *reinterpret_cast<const v4i *>(tile + lane * 16);
-                px[0] = (uint32_t)row[0]; px[1] = (uint32_t)row[1]; px[2] = (uint32_t)row[2]; px[3] = (uint32_t)row[3];
-                __builtin_amdgcn_wave_barrier();
-            }
-            store16_sc1nt(pred + unit * 1024 + lane * 16, v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]});
+            unsigned at = (unsigned)lane * 16;                       // rows: lane (k, h) holds samples 16h.. of row k
+            if (predict_line16(mode, left, top, ext, lane, px)) at = turn_columns(tile, lane, px);   // columns: turned through the tile
+            store16_sc1nt(pred + unit * 1024 + at, v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]});
         }
         if (more) {
             if (lane < 9 * kUnits) *reinterpret_cast<v4i *>(raw2 + ((rd + 1) & 1) * (kUnits * kRawBytes) + lane * 16) = sets;
@@ -308,13 +312,13 @@ __global__ __launch_bounds__(256) void intra32_costs_kernel(const x266_intra_ref
 #pragma unroll
             for (int g = 0; g < 4; ++g) px[g] ^= 0x80808080u;
             unsigned char *tile = ptile + t * kTileB;
-            if (columns) {
-                scatter_column<kPitch>(tile, lane, px);
-            } else {
-                unsigned char *d = tile + (lane >> 1) * kPitch + (lane & 1) * 16;
-                *reinterpret_cast<uint2 *>(d) = make_uint2(px[0], px[1]);
-                *reinterpret_cast<uint2 *>(d + 8) = make_uint2(px[2], px[3]);
+            unsigned at = (unsigned)((lane >> 1) * kPitch + (lane & 1) * 16);
+            if (columns) {                                   // turned inside the tile's own first KiB (one wave: its LDS operations execute in order)
+                const unsigned o = turn_columns(tile, lane, px);
+                at = (o >> 5) * kPitch + (o & 31);
             }
+            *reinterpret_cast<uint2 *>(tile + at) = make_uint2(px[0], px[1]);
+            *reinterpret_cast<uint2 *>(tile + at + 8) = make_uint2(px[2], px[3]);
         }
         __builtin_amdgcn_wave_barrier();
         v4i w0, w1;
