@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer probe: same-box A/B of the SAD batch kernels between tools/_ab/libx266hip_ref.so (tools/ab_build.sh <git-ref>) and the working tree's library."""
 import ctypes
-ROOT = "/root/repo"
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = ctypes.c_void_p; SZ = ctypes.c_size_t
 def load(path):
     L = ctypes.CDLL(path); ctx = P()
