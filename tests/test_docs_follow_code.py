@@ -21,6 +21,15 @@ def test_design_measured_table_is_the_generated_one():
         "DESIGN.md section 5 is stale: python tools/design_table.py %s --write" % src
 
 
+def test_design_sq_counter_table_is_the_generated_one():
+    import design_table
+    s = open(os.path.join(ROOT, "DESIGN.md")).read()
+    region = s[s.index(design_table.SQ_BEGIN) + len(design_table.SQ_BEGIN):s.index(design_table.SQ_END)]
+    src = re.search(r"generated from `([^`]+)`", region).group(1)
+    assert region.split("\n\n", 1)[1].strip() == design_table.sq_table(os.path.join(ROOT, src)).strip(), \
+        "DESIGN.md's SQ table is stale: python tools/design_table.py profiles/<round>_bench.json --write"
+
+
 def _abi_option_keys():
     src = open(os.path.join(ROOT, "x266_amd", "csrc", "x266hip_abi.hip")).read()
     body = src[src.index("kOptions[]"):]

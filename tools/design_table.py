@@ -76,18 +76,66 @@ def table(path):
     return head + "\n" + "\n".join(rows)
 
 
+SQ_BEGIN, SQ_END = "<!-- sq-table:begin (tools/design_table.py) -->", "<!-- sq-table:end -->"
+SQ_ROWS = [  # (label, kernels of the derived section of <round>_pmc_sq_counters.csv)
+    ("`dct32_lds_kernel` fwd / inv", ["dct32_lds_kernel<false>", "dct32_lds_kernel<true>"]),
+    ("`dct32_fwdinv_lds_kernel`", ["dct32_fwdinv_lds_kernel"]),
+    ("`satd8x8_dma_kernel` (round 3's staged kernel: 17.7 / 57 / 14 / 66)", ["satd8x8_dma_kernel"]),
+    ("`dct32_from_tiles_kernel` / `satd8x8_from_tiles_kernel`", ["dct32_from_tiles_kernel", "satd8x8_from_tiles_kernel"]),
+    ("`tr_fwd_small_lds_kernel` 4×4 / 8×8 / 16×16", ["tr_fwd_small_lds_kernel<2, false>", "tr_fwd_small_lds_kernel<3, false>", "tr_fwd_small_lds_kernel<4, false>"]),
+    ("`tr_inv_small_lds_kernel` 4×4 / 8×8 / 16×16", ["tr_inv_small_lds_kernel<2, false>", "tr_inv_small_lds_kernel<3, false>", "tr_inv_small_lds_kernel<4, false>"]),
+    ("`tr_tiles_kernel` forward / inverse", ["tr_tiles_kernel<false, true>", "tr_tiles_kernel<true, true>"]),
+    ("`satd_search_kernel` / `sad_search_kernel`", ["satd_search_kernel<8, false, 512, 4>", "sad_search_kernel<2, false>"]),
+    ("`intra32_predict_kernel` / `intra32_costs_kernel`", ["intra32_predict_kernel", "intra32_costs_kernel"]),
+    ("`sad_kernel` 8×8 / 16×16 / 64×64", ["sad_kernel<2, 4>", "sad_kernel<4, 4>", "sad_kernel<8, 4>"]),
+    ("`mem_ceiling_kernel` copy / read / write (the streams)", ["mem_ceiling_kernel<0, 2>", "mem_ceiling_kernel<1, 4>", "mem_ceiling_kernel<2, 2>"]),
+]
+
+
+def sq_table(path):
+    """The derived section of profiles/<round>_pmc_sq_counters.csv (tools/collect_profiles.py) as DESIGN.md's SQ table."""
+    lines = open(path).read().splitlines()
+    at = next(i for i, l in enumerate(lines) if l.startswith("kernel,mfma_busy_frac"))
+    rows = {}
+    for l in lines[at + 1:]:
+        r = l.rsplit(",", 5)                                          # kernel names contain commas
+        if len(r) == 6:
+            rows[r[0]] = r
+
+    def col(ks, i):
+        vals = [float(rows[k][i]) for k in ks]
+        return "–" if all(v == 0 for v in vals) else " / ".join("–" if v == 0 else "%.0f" % (100 * v) if i != 1 else "%.1f" % (100 * v) for v in vals) + " %"
+    out = ["  | kernel | MFMA busy | VALU busy | LDS busy | wave time waiting |", "  | --- | --- | --- | --- | --- |"]
+    for label, ks in SQ_ROWS:
+        if not all(k in rows for k in ks):
+            raise SystemExit("kernel missing from %s: %s" % (path, [k for k in ks if k not in rows]))
+        out.append("  | %s | %s | %s | %s | %s |" % (label, col(ks, 1), col(ks, 2), col(ks, 3), col(ks, 5)))
+    return "\n".join(out)
+
+
+def replace_region(s, begin, end, body, src):
+    b, en = s.index(begin), s.index(end)
+    return s[:b] + begin + "\n" + "  (generated from `%s`)\n\n" % src + body + "\n\n  " + s[en:]
+
+
 def main():
     path = sys.argv[1]
     t = table(path)
+    sq_path = os.path.join(os.path.dirname(os.path.abspath(path)), os.path.basename(path).split("_")[0] + "_pmc_sq_counters.csv")
+    sq = sq_table(sq_path) if os.path.exists(sq_path) else None
     if "--write" not in sys.argv:
         print(t)
+        if sq:
+            print()
+            print(sq)
         return
     p = os.path.join(ROOT, "DESIGN.md")
     s = open(p).read()
-    b, en = s.index(BEGIN), s.index(END)
-    s = s[:b] + BEGIN + "\n" + "  (generated from `%s`)\n\n" % os.path.relpath(os.path.abspath(path), ROOT) + t + "\n\n  " + s[en:]
+    s = replace_region(s, BEGIN, END, t, os.path.relpath(os.path.abspath(path), ROOT))
+    if sq and SQ_BEGIN in s:
+        s = replace_region(s, SQ_BEGIN, SQ_END, sq, os.path.relpath(sq_path, ROOT))
     open(p, "w").write(s)
-    print("DESIGN.md: table regenerated from", path)
+    print("DESIGN.md: tables regenerated from", path)
 
 
 if __name__ == "__main__":
