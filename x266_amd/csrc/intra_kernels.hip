@@ -120,8 +120,8 @@ __device__ __forceinline__ bool predict_line16(int mode, const unsigned char *le
     }
     if (mode == 1) {                                        // DC: 32 top + 32 left samples
         uint32_t s = lane < 32 ? (uint32_t)top[1 + lane] + (uint32_t)left[lane] : 0u;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += (uint32_t)__shfl_xor((int)s, m);
+        s = sum_over_row16(s);
+        s = (uint32_t)(__builtin_amdgcn_readlane((int)s, 0) + __builtin_amdgcn_readlane((int)s, 16));   // lanes 32.. hold zeros
         const uint32_t dc = (s + 32u) >> 6;
         px[0] = px[1] = px[2] = px[3] = dc * 0x01010101u;
         return false;
@@ -328,10 +328,8 @@ __global__ __launch_bounds__(256) void intra32_costs_kernel(const x266_intra_ref
         uint32_t s = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s = __builtin_amdgcn_sad_u16(p[k], cs[k], s);
-        s += (uint32_t)__shfl_xor((int)s, 32);               // the other half of the coefficient rows
-        uint32_t c = (s + 2u) >> 2;                          // satd8x8 of this sub-block
-#pragma unroll
-        for (int m = 1; m <= 8; m <<= 1) c += (uint32_t)__shfl_xor((int)c, m);   // sixteen sub-blocks
+        s = sum_with_other_half(s);                          // the other half of the coefficient rows
+        const uint32_t c = sum_over_row16((s + 2u) >> 2);    // satd8x8 of this sub-block, summed over the sixteen sub-blocks (one row of lanes per tile)
         __builtin_amdgcn_wave_barrier();
         const uint32_t c_a = (uint32_t)__builtin_amdgcn_readlane((int)c, 0), c_b = (uint32_t)__builtin_amdgcn_readlane((int)c, 16);
         const int m_a = 2 * pair, m_b = 2 * pair + 1;

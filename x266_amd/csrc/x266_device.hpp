@@ -41,6 +41,23 @@ __device__ __forceinline__ void store16_sc1nt(void *p, const v4i &v)
     asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v));
 }
 
+// ---- cross-lane sums without LDS traffic (a __shfl_xor is a ds_bpermute: address arithmetic, an LDS instruction and its latency) ----
+// x + (lane ^ 32's x): gfx950's v_permlane32_swap exchanges the upper half of one register with the lower half of another
+__device__ __forceinline__ uint32_t sum_with_other_half(uint32_t x)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // r[0] = {lo, lo}, r[1] = {hi, hi}
+    return r[0] + r[1];
+}
+// sum over the lane's row of 16 lanes (every lane of the row ends up with it): two quad permutes, then the two row mirrors
+__device__ __forceinline__ uint32_t sum_over_row16(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xF, 0xF, true);   // row_mirror
+    return x;
+}
+
 // SM: 0 plain, 1 nontemporal, 2 "sc1 nt"
 template <int SM>
 __device__ __forceinline__ void store16m(void *p, const v4i &v)
