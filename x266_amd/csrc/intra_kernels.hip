@@ -51,12 +51,20 @@ constexpr int kRawBytes = 144;      // x266_intra_ref_t
 constexpr int kExtBytes = 128;      // ref[-32 .. 95]: negative-angle modes only
 constexpr int kSlotBytes = 16 + 2 * kUnits * kRawBytes + kExtBytes + 1024;   // two raw areas (current round, next round)
 
+// a * b + c on two 16-bit lanes, as ONE instruction (written as an expression, the compiler turns "two products plus a constant" into
+// multiply, multiply-add, add)
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // 16 samples of one line: taps are the 17 bytes from `p` on (any alignment), weights (32 - f, f).
 // Packed 16-bit arithmetic, two samples per instruction: even samples (32-f)*B[2i] + f*B[2i+1],
 // odd samples (32-f)*B[2i+1] + f*B[2i+2].
 __device__ __forceinline__ void interpolate16(const unsigned char *p, uint32_t f, uint32_t (&px)[4])
 {
-    typedef unsigned short v2u __attribute__((ext_vector_type(2)));
     const int o = (int)((uintptr_t)p & 3);
     const uint32_t *q = reinterpret_cast<const uint32_t *>(p - o);
     uint32_t d[6], a[5];
@@ -64,16 +72,18 @@ __device__ __forceinline__ void interpolate16(const unsigned char *p, uint32_t f
     for (int i = 0; i < 6; ++i) d[i] = q[i];
 #pragma unroll
     for (int i = 0; i < 5; ++i) a[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], (uint32_t)(8 * o));   // bytes p[4i .. 4i+3]
-    const uint32_t w0 = (32u - f) * 0x00010001u, w1 = f * 0x00010001u;
-    const v2u W0 = __builtin_bit_cast(v2u, w0), W1 = __builtin_bit_cast(v2u, w1), R = {16, 16}, S = {5, 5};
+    // weights and rounding term times 8: the ">> 5" becomes ">> 8", i.e. the sample is the HIGH byte of its 16-bit lane and the byte
+    // permute that interleaves even and odd samples picks it up for free (255 * 256 + 128 < 2^16: no overflow)
+    const uint32_t w0 = (256u - 8u * f) * 0x00010001u, w1 = (8u * f) * 0x00010001u;
+    const uint32_t R = 0x00800080u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const v2u t0 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a[g], 0x0c020c00u));            // B0, B2
-        const v2u t1 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a[g], 0x0c030c01u));            // B1, B3
-        const v2u t2 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(a[g + 1], a[g], 0x0c040c02u));      // B2, B4
-        const v2u e = (t0 * W0 + R + t1 * W1) >> S;          // samples 0, 2
-        const v2u od = (t1 * W0 + R + t2 * W1) >> S;         // samples 1, 3
-        px[g] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, od), __builtin_bit_cast(uint32_t, e), 0x06020400u);   // e0 o0 e1 o1
+        const uint32_t t0 = __builtin_amdgcn_perm(0u, a[g], 0x0c020c00u);            // B0, B2
+        const uint32_t t1 = __builtin_amdgcn_perm(0u, a[g], 0x0c030c01u);            // B1, B3
+        const uint32_t t2 = __builtin_amdgcn_perm(a[g + 1], a[g], 0x0c040c02u);      // B2, B4
+        const uint32_t e = pk_mad_u16(t0, w0, pk_mad_u16(t1, w1, R));     // samples 0, 2 (times 256)
+        const uint32_t od = pk_mad_u16(t1, w0, pk_mad_u16(t2, w1, R));    // samples 1, 3
+        px[g] = __builtin_amdgcn_perm(od, e, 0x07030501u);                // e0 o0 e1 o1, the high bytes
     }
 }
 
@@ -128,14 +138,15 @@ __device__ __forceinline__ bool predict_line16(int mode, const unsigned char *le
     }
     // planar, row y = k, columns 16h..: ((31-x) L + (x+1) TR + (31-y) T[x] + (y+1) BL + 32) >> 6
     //   = (C + x (TR - L) + (31-y) T[x]) >> 6,  C = 31 L + TR + (y+1) BL + 32: a per-lane ramp plus one
-    // multiply per sample, in packed 16-bit lanes (all partial sums stay below 2^16 modulo wraparound).
+    // multiply per sample, in packed 16-bit lanes (the ramps wrap modulo 2^16 on the way; every finished sum is below 2^16).
     typedef unsigned short v2u __attribute__((ext_vector_type(2)));
     const int tr = top[33], bl = left[32], y = k, lv = left[y];
     const int D = tr - lv, x0 = 16 * h;
-    const int c0 = 31 * lv + tr + (y + 1) * bl + 32 + x0 * D;
-    v2u re = {(unsigned short)c0, (unsigned short)(c0 + 2 * D)}, ro = {(unsigned short)(c0 + D), (unsigned short)(c0 + 3 * D)};
-    const v2u inc = {(unsigned short)(4 * D), (unsigned short)(4 * D)}, S = {6, 6};
-    const unsigned short wy = (unsigned short)(31 - y);
+    // everything times 4: the ">> 6" becomes ">> 8" and the interleaving byte permute takes the high bytes (4 * (255 * 64 + 32) < 2^16)
+    const int c0 = 4 * (31 * lv + tr + (y + 1) * bl + 32 + x0 * D), D4 = 4 * D;
+    v2u re = {(unsigned short)c0, (unsigned short)(c0 + 2 * D4)}, ro = {(unsigned short)(c0 + D4), (unsigned short)(c0 + 3 * D4)};
+    const v2u inc = {(unsigned short)(4 * D4), (unsigned short)(4 * D4)};
+    const unsigned short wy = (unsigned short)(4 * (31 - y));
     const v2u W = {wy, wy};
     const uint32_t *q = reinterpret_cast<const uint32_t *>(top + x0);               // top[1 + x0 ..]: one byte past a dword boundary
     uint32_t d[5];
@@ -146,8 +157,8 @@ __device__ __forceinline__ bool predict_line16(int mode, const unsigned char *le
         const uint32_t a = __builtin_amdgcn_alignbit(d[g + 1], d[g], 8u);
         const v2u t0 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a, 0x0c020c00u));
         const v2u t1 = __builtin_bit_cast(v2u, __builtin_amdgcn_perm(0u, a, 0x0c030c01u));
-        const v2u e = (t0 * W + re) >> S, od = (t1 * W + ro) >> S;
-        px[g] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, od), __builtin_bit_cast(uint32_t, e), 0x06020400u);
+        const v2u e = t0 * W + re, od = t1 * W + ro;
+        px[g] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, od), __builtin_bit_cast(uint32_t, e), 0x07030501u);
         re += inc;
         ro += inc;
     }
