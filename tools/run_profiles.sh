@@ -17,7 +17,7 @@ timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIV
 cd $R
 python bench.py | tail -1 > gpurun_out/bench_${T}_$S.json
 python bench.py --steps 20 --warmup 5 | tail -1 > gpurun_out/bench_${T}_${S}_driver_args.json
-python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -2 > gpurun_out/pytest_gpu.log
+python -m pytest tests -q -m gpu -rf 2>&1 | grep -E "passed|failed|error|^FAILED" | tail -6 > gpurun_out/pytest_gpu.log
 cat gpurun_out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 ./host/stream8k 0 500 | tail -1 > gpurun_out/stream8k_${T}_$S.json 2>/dev/null; cat gpurun_out/stream8k_${T}_$S.json
