@@ -7,6 +7,7 @@
  *
  *   usage: batch_example [n_blocks]        exit code 0 on success
  */
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -52,6 +53,18 @@ int main(int argc, char **argv)
     int worst = 0;
     for (size_t i = 0; i < n * 1024; i++) { int e = abs((int)x[i] - (int)r[i]); if (e > worst) worst = e; }
     printf("%zu blocks forward + inverse on the device: max reconstruction error %d\n", n, worst);
+    /* 3. the literal drop-in path: host pointers in and out (chunks of 16 MiB over three staging slots, uploads, kernels and
+     *    downloads overlapped -- include/x266hip.h); must equal what the device-pointer call left in d_z */
+    int16_t *zh = malloc(n * 2048), *zd = malloc(n * 2048);
+    uint32_t *cost = malloc((n * 16) * sizeof *cost);
+    CHECK(xDct32FwdBatch(hip, x, zh, n));
+    CHECK(xHipMemcpyD2H(hip, zd, d_z, n * 2048));
+    if (memcmp(zh, zd, n * 2048) != 0) { fprintf(stderr, "host-pointer and device-pointer forward transforms differ\n"); return -1; }
+    CHECK(xSatd8x8Batch(hip, x, cost, n * 16));               /* the same samples as 8x8 blocks */
+    CHECK(xDct32InvBatch(hip, zh, zd, n));
+    if (memcmp(zd, r, n * 2048) != 0) { fprintf(stderr, "host-pointer and device-pointer inverse transforms differ\n"); return -1; }
+    printf("host-pointer calls agree with the device-pointer calls on %zu blocks (first SATD cost %u)\n", n, cost[0]);
+    free(zh); free(zd); free(cost);
     double ms = 0;
     CHECK(xHipTimeKernel(hip, 0, d_x, d_z, n, 20, NULL, &ms));
     printf("forward: %.3f ms per launch, %.3e blocks/s\n", ms, n / ms * 1e3);
