@@ -9,7 +9,7 @@ from _util import extremes_np, fullrange_np, intra_refs_np, residual_np
 
 pytestmark = pytest.mark.gpu
 
-# X266_FUZZ_SCALE=k multiplies the example counts and turns random seeds on (campaigns run by hand: round 3, after the tile kernel rewrite and with the three round-3 tests, 100x = 23 000 examples, clean; the round-2 campaign was
+# X266_FUZZ_SCALE=k multiplies the example counts and turns random seeds on (campaigns run by hand: round 4, after the SATD LDS-DMA kernel, the kernel prune, the new SAD and intra kernels, 100x = 25 500 examples, clean; round 3, after the tile kernel rewrite and with the three round-3 tests, 100x = 23 000 examples, clean; the round-2 campaign was
 # 200x = 33 000 examples, clean); by default the examples are derived deterministically from the test body, so that a regular run of the
 # suite does not depend on a random seed.
 import os
@@ -258,3 +258,23 @@ def test_installed_matrices_through_the_tile_launch(oracle, slot, size, n_tiles,
             want = oracle.transform_matrix_passes(mh, mv, x[t].reshape(-1, size * size), inverse=bool(inverse))
         assert np.array_equal(got[t], np.asarray(want).ravel()), (t, int(cls[t]))
     cd.close()
+
+
+@fuzz(25)
+@given(edge=st.sampled_from([4, 8, 16, 32, 64]), n=st.integers(0, 20000), seed=st.integers(1, 1 << 30), extreme=st.integers(0, 3))
+def test_sad_batches_random(codec, edge, n, seed, extreme):
+    """batched SAD (f3): every wave takes 256 chunks of 16 bytes, so counts around multiples of 256 / (edge*edge/16) blocks and the
+    ragged last wave are what random sizes probe; extreme 1/2 = all-0 against all-255 (the largest sums), 3 = equal inputs"""
+    if edge >= 32:
+        n = n % 3000
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (n, edge * edge), dtype=np.uint8)
+    b = rng.integers(0, 256, (n, edge * edge), dtype=np.uint8)
+    if extreme == 1:
+        a[:], b[:] = 0, 255
+    elif extreme == 2:
+        a[:], b[:] = 255, 0
+    elif extreme == 3:
+        b = a.copy()
+    want = np.abs(a.astype(np.int32) - b.astype(np.int32)).sum(axis=1).astype(np.uint32)
+    assert np.array_equal(codec.sad(edge, a, b), want)
