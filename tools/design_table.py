@@ -82,9 +82,9 @@ SQ_ROWS = [  # (label, kernels of the derived section of <round>_pmc_sq_counters
     ("`dct32_fwdinv_lds_kernel`", ["dct32_fwdinv_lds_kernel"]),
     ("`satd8x8_dma_kernel` (round 3's staged kernel: 17.7 / 57 / 14 / 66)", ["satd8x8_dma_kernel"]),
     ("`dct32_from_tiles_kernel` / `satd8x8_from_tiles_kernel`", ["dct32_from_tiles_kernel", "satd8x8_from_tiles_kernel"]),
-    ("`tr_fwd_small_lds_kernel` 4×4 / 8×8 / 16×16", ["tr_fwd_small_lds_kernel<2, false>", "tr_fwd_small_lds_kernel<3, false>", "tr_fwd_small_lds_kernel<4, false>"]),
-    ("`tr_inv_small_lds_kernel` 4×4 / 8×8 / 16×16", ["tr_inv_small_lds_kernel<2, false>", "tr_inv_small_lds_kernel<3, false>", "tr_inv_small_lds_kernel<4, false>"]),
-    ("`tr_tiles_kernel` forward / inverse", ["tr_tiles_kernel<false, true>", "tr_tiles_kernel<true, true>"]),
+    ("`tr_fwd_small_lds_kernel` 4×4 / 8×8 / 16×16", ["tr_fwd_small_lds_kernel<2>", "tr_fwd_small_lds_kernel<3>", "tr_fwd_small_lds_kernel<4>"]),
+    ("`tr_inv_small_lds_kernel` 4×4 / 8×8 / 16×16", ["tr_inv_small_lds_kernel<2>", "tr_inv_small_lds_kernel<3>", "tr_inv_small_lds_kernel<4>"]),
+    ("`tr_tiles_kernel` forward / inverse", ["tr_tiles_kernel<false>", "tr_tiles_kernel<true>"]),
     ("`satd_search_kernel` / `sad_search_kernel`", ["satd_search_kernel<8, false, 512, 4>", "sad_search_kernel<2, false>"]),
     ("`intra32_predict_kernel` / `intra32_costs_kernel`", ["intra32_predict_kernel", "intra32_costs_kernel"]),
     ("`sad_kernel` 8×8 / 16×16 / 64×64", ["sad_kernel<2, 4>", "sad_kernel<4, 4>", "sad_kernel<8, 4>"]),

@@ -81,13 +81,12 @@ __device__ __forceinline__ void fwd_tile_in_slot(unsigned char *slot, int lane, 
 // dct32_kernels.hip section "LDS-staged variant") and re-read from a wave-private LDS slot in
 // fragment order.  Streaming cache hints only for contiguous batches: scattered blocks may share lines across instructions.
 template <int LOGN, bool INDEXED>
-__global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
-                                                               size_t n_blocks, const DctOps *__restrict__ ops,
-                                                               const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
+__device__ __forceinline__ void tr_fwd_small_body(unsigned char *stage, const int16_t *__restrict__ in, int16_t *__restrict__ out,
+                                                  size_t n_blocks, const DctOps *__restrict__ ops,
+                                                  const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
 {
     constexpr int N = 1 << LOGN;
     constexpr int PER = 32 / N, NSB = PER * PER;
-    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 2 KiB per wave (+ occupancy padding)
     unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
 
     const int lane = threadIdx.x & 63;
@@ -134,6 +133,21 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
         if (live0) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o0, s0);   // contiguous: "sc1 nt" (x266_device.hpp)
         if (live1) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o1, s1);
     }
+}
+
+// One kernel per size: the offset-table form and the contiguous form are two complete bodies (each with its own addressing AND cache
+// policy at compile time) behind one wave-uniform test of the kernel argument.  A run-time choice INSIDE the loop costs 1-3.6 %; this
+// form measures +-0.3 % on the forward family, +0.5-1 % FASTER on the tile kernel below and 0.5-1.9 % slower on the contiguous inverse
+// family (same instruction count, another schedule) -- profiles/r04_kernel_prune.txt.  (32x32 exists only in the offset-table form:
+// contiguous 32x32 batches are dct32_kernels.hip's.)
+template <int LOGN>
+__global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
+                                                               size_t n_blocks, const DctOps *__restrict__ ops,
+                                                               const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 2 KiB per wave (+ occupancy padding)
+    if (LOGN == 5 || offsets) tr_fwd_small_body<LOGN, true>(stage, in, out, n_blocks, ops, offsets, tiles_per_wave);
+    else                      tr_fwd_small_body<LOGN, LOGN == 5>(stage, in, out, n_blocks, ops, offsets, tiles_per_wave);
 }
 
 // The inverse of fwd_tile_in_slot: the first contraction runs over the tile's ROW index, so each lane reads
@@ -203,13 +217,12 @@ __device__ __forceinline__ v16i load_c2r(const DctOps *__restrict__ ops, int h)
 // first contraction runs over the tile's ROW index, so each lane reads its COLUMN out of the staged
 // tile (16 x ds_read_u16), exactly as the staged DCT32 inverse does.
 template <int LOGN, bool INDEXED>
-__global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
-                                                               size_t n_blocks, const DctOps *__restrict__ ops,
-                                                               const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
+__device__ __forceinline__ void tr_inv_small_body(unsigned char *stage, const int16_t *__restrict__ in, int16_t *__restrict__ out,
+                                                  size_t n_blocks, const DctOps *__restrict__ ops,
+                                                  const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
 {
     constexpr int N = 1 << LOGN;
     constexpr int PER = 32 / N, NSB = PER * PER;
-    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
     unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
 
     const int lane = threadIdx.x & 63;
@@ -255,6 +268,16 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
         if (live0) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o0, s0);   // contiguous: "sc1 nt" (x266_device.hpp)
         if (live1) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o1, s1);
     }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
+                                                               size_t n_blocks, const DctOps *__restrict__ ops,
+                                                               const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
+    if (LOGN == 5 || offsets) tr_inv_small_body<LOGN, true>(stage, in, out, n_blocks, ops, offsets, tiles_per_wave);
+    else                      tr_inv_small_body<LOGN, LOGN == 5>(stage, in, out, n_blocks, ops, offsets, tiles_per_wave);
 }
 
 // ---- mixed classes, one launch (BASELINE configs[3], "batched per CTU") ------------------------------------
@@ -394,12 +417,11 @@ __device__ __forceinline__ void tile_of_class(unsigned char *slot, const unsigne
 // wave's first instructions and parked in LDS as they arrive -- nothing is held in registers across a tile's passes.
 // LDS per wave: table 2 KiB, two tile slots of 2 KiB.
 template <bool INVERSE, bool NT>
-__global__ __launch_bounds__(256) void tr_tiles_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t n_tiles,
-                                                       const uint32_t *__restrict__ tile_offsets,
-                                                       const uint8_t *__restrict__ tile_class, const TileTab *__restrict__ T,
-                                                       unsigned tiles_per_wave, unsigned lds_per_wave)
+__device__ __forceinline__ void tr_tiles_body(unsigned char *stage, const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t n_tiles,
+                                              const uint32_t *__restrict__ tile_offsets,
+                                              const uint8_t *__restrict__ tile_class, const TileTab *__restrict__ T,
+                                              unsigned tiles_per_wave, unsigned lds_per_wave)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
     unsigned char *tab = stage + (threadIdx.x >> 6) * lds_per_wave;
     unsigned char *slot0 = tab + 2048, *slot1 = tab + 4096;
     const int lane = threadIdx.x & 63;
@@ -454,6 +476,18 @@ __global__ __launch_bounds__(256) void tr_tiles_kernel(const int16_t *__restrict
     }
 }
 
+// streaming cache hints when the tiles are the buffer in order, none behind an offset table: two complete bodies, one wave-uniform test
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void tr_tiles_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t n_tiles,
+                                                       const uint32_t *__restrict__ tile_offsets,
+                                                       const uint8_t *__restrict__ tile_class, const TileTab *__restrict__ T,
+                                                       unsigned tiles_per_wave, unsigned lds_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
+    if (tile_offsets) tr_tiles_body<INVERSE, false>(stage, in, out, n_tiles, tile_offsets, tile_class, T, tiles_per_wave, lds_per_wave);
+    else              tr_tiles_body<INVERSE, true>(stage, in, out, n_tiles, tile_offsets, tile_class, T, tiles_per_wave, lds_per_wave);
+}
+
 }  // namespace
 
 hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
@@ -469,10 +503,9 @@ hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t lds = wpw * (size_t)cfg.lds_bytes_per_wave;
     dim3 grid((unsigned)wgs), block(tpb);
-#define X266_TRL(L) do { if (d_offsets) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
-                         else           hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L, false>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
+#define X266_TRL(L) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<L>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw)
     if (log2n == 2) X266_TRL(2); else if (log2n == 3) X266_TRL(3); else if (log2n == 4) X266_TRL(4);
-    else if (log2n == 5 && d_offsets) hipLaunchKernelGGL((tr_fwd_small_lds_kernel<5, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw);   // contiguous 32x32 batches are the DCT32 kernel's
+    else if (log2n == 5 && d_offsets) X266_TRL(5);                     // contiguous 32x32 batches are the DCT32 kernel's
     else return hipErrorInvalidValue;
 #undef X266_TRL
     return hipGetLastError();
@@ -491,10 +524,9 @@ hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t lds = wpw * (size_t)cfg.lds_bytes_per_wave;
     dim3 grid((unsigned)wgs), block(tpb);
-#define X266_TRI(L) do { if (d_offsets) hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); \
-                         else           hipLaunchKernelGGL((tr_inv_small_lds_kernel<L, false>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw); } while (0)
+#define X266_TRI(L) hipLaunchKernelGGL((tr_inv_small_lds_kernel<L>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw)
     if (log2n == 2) X266_TRI(2); else if (log2n == 3) X266_TRI(3); else if (log2n == 4) X266_TRI(4);
-    else if (log2n == 5 && d_offsets) hipLaunchKernelGGL((tr_inv_small_lds_kernel<5, true>), grid, block, lds, stream, d_in, d_out, n_blocks, d_ops, d_offsets, tpw);
+    else if (log2n == 5 && d_offsets) X266_TRI(5);
     else return hipErrorInvalidValue;
 #undef X266_TRI
     return hipGetLastError();
@@ -512,12 +544,8 @@ hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_
     const unsigned per_wave = (unsigned)(cfg.lds_bytes_per_wave < 6144 ? 6144 : (cfg.lds_bytes_per_wave + 15) & ~15);   // table + two tiles, then padding
     const size_t lds = wpw * (size_t)per_wave;
     dim3 grid((unsigned)wgs), block(tpb);
-    // streaming hints only when the tiles are the whole buffer in order.  (The cache policy as a run-time, wave-uniform choice inside one
-    // kernel costs 1-3.6 % same-box -- profiles/r04_kernel_prune.txt -- so these stay compile-time variants.)
-    const bool nt = !d_tile_offsets;
-#define X266_TT(INV, NTV) hipLaunchKernelGGL((tr_tiles_kernel<INV, NTV>), grid, block, lds, stream, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, d_tab, tpw, per_wave)
-    if (inverse) { if (nt) X266_TT(true, true); else X266_TT(true, false); }
-    else         { if (nt) X266_TT(false, true); else X266_TT(false, false); }
+#define X266_TT(INV) hipLaunchKernelGGL((tr_tiles_kernel<INV>), grid, block, lds, stream, d_in, d_out, n_tiles, d_tile_offsets, d_tile_class, d_tab, tpw, per_wave)
+    if (inverse) X266_TT(true); else X266_TT(false);
 #undef X266_TT
     return hipGetLastError();
 }
