@@ -81,7 +81,7 @@ __device__ __forceinline__ void fwd_tile_in_slot(unsigned char *slot, int lane, 
 // dct32_kernels.hip section "LDS-staged variant") and re-read from a wave-private LDS slot in
 // fragment order.  Streaming cache hints only for contiguous batches: scattered blocks may share lines across instructions.
 template <int LOGN, bool INDEXED>
-__device__ __forceinline__ void tr_fwd_small_body(unsigned char *stage, const int16_t *__restrict__ in, int16_t *__restrict__ out,
+__device__ __forceinline__ void tr_fwd_small_body(unsigned char *stage, size_t wave, const int16_t *__restrict__ in, int16_t *__restrict__ out,
                                                   size_t n_blocks, const DctOps *__restrict__ ops,
                                                   const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
 {
@@ -90,7 +90,6 @@ __device__ __forceinline__ void tr_fwd_small_body(unsigned char *stage, const in
     unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
 
     const int lane = threadIdx.x & 63;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t n_tiles = (n_blocks + NSB - 1) / NSB;
     size_t t = wave * tiles_per_wave;
     const size_t t_end = t + tiles_per_wave < n_tiles ? t + tiles_per_wave : n_tiles;
@@ -138,7 +137,7 @@ __device__ __forceinline__ void tr_fwd_small_body(unsigned char *stage, const in
 // One kernel per size: the offset-table form and the contiguous form are two complete bodies (each with its own addressing AND cache
 // policy at compile time) behind one wave-uniform test of the kernel argument.  A run-time choice INSIDE the loop costs 1-3.6 %; this
 // form measures +-0.3 % on the forward family, +0.5-1 % FASTER on the tile kernel below and 0.5-1.9 % slower on the contiguous inverse
-// family (same instruction count, another schedule) -- profiles/r04_kernel_prune.txt.  (32x32 exists only in the offset-table form:
+// family (same instruction count, another schedule: in the merged function the compiler issues the sixteen column reads of a tile in one burst instead of interleaving them with their packing) -- profiles/r04_kernel_prune.txt.  (32x32 exists only in the offset-table form:
 // contiguous 32x32 batches are dct32_kernels.hip's.)
 template <int LOGN>
 __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
@@ -146,8 +145,11 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
                                                                const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 2 KiB per wave (+ occupancy padding)
-    if (LOGN == 5 || offsets) tr_fwd_small_body<LOGN, true>(stage, in, out, n_blocks, ops, offsets, tiles_per_wave);
-    else                      tr_fwd_small_body<LOGN, LOGN == 5>(stage, in, out, n_blocks, ops, offsets, tiles_per_wave);
+    // everything both bodies need from the dispatch packet is read BEFORE the branch (a scalar load issued behind it would be a second
+    // round trip in every wave's prologue)
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (LOGN == 5 || offsets) tr_fwd_small_body<LOGN, true>(stage, wave, in, out, n_blocks, ops, offsets, tiles_per_wave);
+    else                      tr_fwd_small_body<LOGN, LOGN == 5>(stage, wave, in, out, n_blocks, ops, offsets, tiles_per_wave);
 }
 
 // The inverse of fwd_tile_in_slot: the first contraction runs over the tile's ROW index, so each lane reads
@@ -217,7 +219,7 @@ __device__ __forceinline__ v16i load_c2r(const DctOps *__restrict__ ops, int h)
 // first contraction runs over the tile's ROW index, so each lane reads its COLUMN out of the staged
 // tile (16 x ds_read_u16), exactly as the staged DCT32 inverse does.
 template <int LOGN, bool INDEXED>
-__device__ __forceinline__ void tr_inv_small_body(unsigned char *stage, const int16_t *__restrict__ in, int16_t *__restrict__ out,
+__device__ __forceinline__ void tr_inv_small_body(unsigned char *stage, size_t wave, const int16_t *__restrict__ in, int16_t *__restrict__ out,
                                                   size_t n_blocks, const DctOps *__restrict__ ops,
                                                   const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
 {
@@ -226,7 +228,6 @@ __device__ __forceinline__ void tr_inv_small_body(unsigned char *stage, const in
     unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
 
     const int lane = threadIdx.x & 63;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t n_tiles = (n_blocks + NSB - 1) / NSB;
     size_t t = wave * tiles_per_wave;
     const size_t t_end = t + tiles_per_wave < n_tiles ? t + tiles_per_wave : n_tiles;
@@ -276,8 +277,9 @@ __global__ __launch_bounds__(256) void tr_inv_small_lds_kernel(const int16_t *__
                                                                const uint32_t *__restrict__ offsets, unsigned tiles_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
-    if (LOGN == 5 || offsets) tr_inv_small_body<LOGN, true>(stage, in, out, n_blocks, ops, offsets, tiles_per_wave);
-    else                      tr_inv_small_body<LOGN, LOGN == 5>(stage, in, out, n_blocks, ops, offsets, tiles_per_wave);
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;       // read before the branch, as in the forward kernel
+    if (LOGN == 5 || offsets) tr_inv_small_body<LOGN, true>(stage, wave, in, out, n_blocks, ops, offsets, tiles_per_wave);
+    else                      tr_inv_small_body<LOGN, LOGN == 5>(stage, wave, in, out, n_blocks, ops, offsets, tiles_per_wave);
 }
 
 // ---- mixed classes, one launch (BASELINE configs[3], "batched per CTU") ------------------------------------
@@ -417,7 +419,7 @@ __device__ __forceinline__ void tile_of_class(unsigned char *slot, const unsigne
 // wave's first instructions and parked in LDS as they arrive -- nothing is held in registers across a tile's passes.
 // LDS per wave: table 2 KiB, two tile slots of 2 KiB.
 template <bool INVERSE, bool NT>
-__device__ __forceinline__ void tr_tiles_body(unsigned char *stage, const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t n_tiles,
+__device__ __forceinline__ void tr_tiles_body(unsigned char *stage, size_t wave, const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t n_tiles,
                                               const uint32_t *__restrict__ tile_offsets,
                                               const uint8_t *__restrict__ tile_class, const TileTab *__restrict__ T,
                                               unsigned tiles_per_wave, unsigned lds_per_wave)
@@ -425,7 +427,6 @@ __device__ __forceinline__ void tr_tiles_body(unsigned char *stage, const int16_
     unsigned char *tab = stage + (threadIdx.x >> 6) * lds_per_wave;
     unsigned char *slot0 = tab + 2048, *slot1 = tab + 4096;
     const int lane = threadIdx.x & 63;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     size_t t = wave * tiles_per_wave;
     const size_t t_end = t + tiles_per_wave < n_tiles ? t + tiles_per_wave : n_tiles;
     if (t >= t_end) return;
@@ -484,8 +485,9 @@ __global__ __launch_bounds__(256) void tr_tiles_kernel(const int16_t *__restrict
                                                        unsigned tiles_per_wave, unsigned lds_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
-    if (tile_offsets) tr_tiles_body<INVERSE, false>(stage, in, out, n_tiles, tile_offsets, tile_class, T, tiles_per_wave, lds_per_wave);
-    else              tr_tiles_body<INVERSE, true>(stage, in, out, n_tiles, tile_offsets, tile_class, T, tiles_per_wave, lds_per_wave);
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;       // read before the branch
+    if (tile_offsets) tr_tiles_body<INVERSE, false>(stage, wave, in, out, n_tiles, tile_offsets, tile_class, T, tiles_per_wave, lds_per_wave);
+    else              tr_tiles_body<INVERSE, true>(stage, wave, in, out, n_tiles, tile_offsets, tile_class, T, tiles_per_wave, lds_per_wave);
 }
 
 }  // namespace
