@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__
 
 // The inverse of fwd_tile_in_slot: the first contraction runs over the tile's ROW index, so each lane reads
 // its COLUMN out of the staged tile (16 x ds_read_u16), exactly as the staged DCT32 inverse does.
-template <int LOGN, class C2RGroup>
+template <int LOGN, class C2RGroup, bool PAIRWISE = false>
 __device__ __forceinline__ void inv_tile_in_slot_with(unsigned char *slot, int lane, const LaneConsts &k, C2RGroup c2r_group)
 {
     constexpr int N = 1 << LOGN;
@@ -179,6 +179,7 @@ __device__ __forceinline__ void inv_tile_in_slot_with(unsigned char *slot, int l
         const uint32_t e0 = *reinterpret_cast<const uint16_t *>(slot + col_base + c0);
         const uint32_t e1 = *reinterpret_cast<const uint16_t *>(slot + col_base + c1);
         w[m] = e0 | (e1 << 16);
+        if (PAIRWISE) __builtin_amdgcn_sched_barrier(0);              // two column reads, then their packing, pair after pair: the order the per-size kernels run fastest in
     }
     __builtin_amdgcn_wave_barrier();
     v4i lo, hi, r0, r1;
@@ -202,7 +203,8 @@ __device__ __forceinline__ void inv_tile_in_slot_with(unsigned char *slot, int l
 template <int LOGN>
 __device__ __forceinline__ void inv_tile_in_slot(unsigned char *slot, int lane, const LaneConsts &k, const v16i &c2r)
 {
-    inv_tile_in_slot_with<LOGN>(slot, lane, k, [&](int g) { return v4i{c2r[4 * g], c2r[4 * g + 1], c2r[4 * g + 2], c2r[4 * g + 3]}; });
+    auto group = [&](int g) { return v4i{c2r[4 * g], c2r[4 * g + 1], c2r[4 * g + 2], c2r[4 * g + 3]}; };
+    inv_tile_in_slot_with<LOGN, decltype(group), true>(slot, lane, k, group);
 }
 
 __device__ __forceinline__ v16i load_c2r(const DctOps *__restrict__ ops, int h)
