@@ -136,8 +136,9 @@ __device__ __forceinline__ void tr_fwd_small_body(unsigned char *stage, size_t w
 
 // One kernel per size: the offset-table form and the contiguous form are two complete bodies (each with its own addressing AND cache
 // policy at compile time) behind one wave-uniform test of the kernel argument.  A run-time choice INSIDE the loop costs 1-3.6 %; this
-// form measures +-0.3 % on the forward family, +0.5-1 % FASTER on the tile kernel below and 0.5-1.9 % slower on the contiguous inverse
-// family (same instruction count, another schedule: in the merged function the compiler issues the sixteen column reads of a tile in one burst instead of interleaving them with their packing) -- profiles/r04_kernel_prune.txt.  (32x32 exists only in the offset-table form:
+// form measures +-0.3 % on the forward family, +0.5-1 % FASTER on the tile kernel below and, once the inverse family's column gather
+// is pinned pair by pair (inv_tile_in_slot_with<.., PAIRWISE>: left alone, the merged function issues the sixteen reads as one burst,
+// 0.5-1.9 % slower), +0.1-1 % on the contiguous inverse family -- profiles/r04_kernel_prune.txt.  (32x32 exists only in the offset-table form:
 // contiguous 32x32 batches are dct32_kernels.hip's.)
 template <int LOGN>
 __global__ __launch_bounds__(256) void tr_fwd_small_lds_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
