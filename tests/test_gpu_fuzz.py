@@ -28,7 +28,7 @@ OPTIONS = {
     "dct32_inv_blocks_per_wave": st.integers(1, 9),
     "dct32_fwdinv_blocks_per_wave": st.integers(1, 9),
     "satd_groups_per_wave": st.integers(0, 9),
-    "dct32_wg_threads": st.sampled_from([64, 128, 192, 256]),
+    "dct32_wg_threads": st.sampled_from([0, 64, 128, 192, 256]),
     "satd_wg_threads": st.sampled_from([0, 64, 128, 192, 256]),
     "satd_lds_bytes_per_wave": st.sampled_from([0, 4096, 6144, 9216, 16384]),
 }

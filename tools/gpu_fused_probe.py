@@ -30,4 +30,4 @@ for rnd in range(2):
             cd.set_option("dct32_wg_threads", tpb)
             t = timed(lambda: cd.dct32_fwd_inv_dev(x.data_ptr(), z.data_ptr(), y.data_ptr(), n))
             print("fused fwd+inv blocks/wave %d wg %3d : %.4f ms (median %.4f)  %.3f TB/s  %.3f of 8 TB/s" % (bpw, tpb, t[0], t[1], n * 6144 / t[0] / 1e9, n * 6144 / t[0] / 8e9))
-    cd.set_option("dct32_fwdinv_blocks_per_wave", default_bpw); cd.set_option("dct32_wg_threads", 64)
+    cd.set_option("dct32_fwdinv_blocks_per_wave", default_bpw); cd.set_option("dct32_wg_threads", 0)

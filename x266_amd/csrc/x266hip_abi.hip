@@ -44,7 +44,7 @@ struct x266hip_ctx {
     int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, dct_fwdinv_blocks_per_wave = 4;   // consecutive blocks one wave loops over (profiles/r01_launch_sweep.txt)
     int satd_groups_per_wave = 0, satd_wg_threads = 0, satd_lds_per_wave = 0;                   // 0 = the chosen SATD kernel's own default (satd_kernels.hip, launch_satd8x8)
     int adaptive_per_wave = 1;                      // shrink the per-wave run on small batches
-    int dct_wg_threads = 64;                        // workgroup size of the DCT32 / transform-set kernels: one-wave workgroups stream best (profiles/r01_wg_occupancy.txt)
+    int dct_wg_threads = 0;                         // workgroup size of the DCT32 / transform-set kernels; 0 = the measured best: one-wave workgroups (profiles/r01_wg_occupancy.txt), two-wave ones for the fused forward + inverse kernel (profiles/r04_fused_mix_ceiling.txt)
     int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (0 = 2: the wave's table copy serves two tiles)
     int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (SATD search: 8, 4 or 2; SAD search: 2), else 2, 4, 8 (8: SATD search only; 1 is served by 2)
     // fixed launch shapes (options in rounds 1-3; their sweeps are frozen in profiles/r01_*.txt, r03_tiles_one_launch.txt)
@@ -132,7 +132,7 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
         c.shape = ctx->satd_variant == 1 || ctx->satd_variant == 3 ? ctx->satd_variant : 0;
     } else {
         c.units_per_wave = op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave;
-        c.wg_threads = ctx->dct_wg_threads;
+        c.wg_threads = ctx->dct_wg_threads ? ctx->dct_wg_threads : 64;
         c.lds_bytes_per_wave = x266hip_ctx::kDctLdsPerWave;
         c.shape = 0;
     }
@@ -397,7 +397,7 @@ static const OptionDesc kOptions[] = {
     {"dct32_blocks_per_wave", &x266hip_ctx::dct_blocks_per_wave, 1, 4096, 1},
     {"dct32_inv_blocks_per_wave", &x266hip_ctx::dct_inv_blocks_per_wave, 1, 4096, 1},
     {"dct32_fwdinv_blocks_per_wave", &x266hip_ctx::dct_fwdinv_blocks_per_wave, 1, 4096, 1},
-    {"dct32_wg_threads", &x266hip_ctx::dct_wg_threads, 64, 256, 64},
+    {"dct32_wg_threads", &x266hip_ctx::dct_wg_threads, 0, 256, 64},
     {"satd_groups_per_wave", &x266hip_ctx::satd_groups_per_wave, 0, 4096, 1},
     {"satd_wg_threads", &x266hip_ctx::satd_wg_threads, 0, 256, 64},
     {"satd_lds_bytes_per_wave", &x266hip_ctx::satd_lds_per_wave, 0, 65536, 1},
@@ -479,6 +479,7 @@ int xDct32FwdInvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_coef,
     X_DEV(ctx);
     LaunchCfg cfg = cfg_for(ctx, 1);
     cfg.units_per_wave = ctx->dct_fwdinv_blocks_per_wave;
+    if (!ctx->dct_wg_threads) cfg.wg_threads = 128;                     // 1.5-2 % over one-wave workgroups on every box measured
     hipError_t e = launch_dct32_fwdinv(d_in, d_coef, d_recon, n, ctx->d_fwd, ctx->d_inv_lds, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fwd+inv launch", e);
     return X266HIP_OK;
