@@ -174,5 +174,9 @@ def test_bench_spawns_its_own_ranks_when_run_plainly():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-also"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+    # at least one rank got as far as the device check; the launcher may tear the second one down the moment the first has
+    # failed (1 run in ~20 here), so "both messages" would be a race -- that the job WAS a torch.distributed.run of two ranks shows
+    # in the launcher's own failure report
+    assert r.stderr.count("bench.py needs an MI355X") >= 1, r.stderr[-2000:]
+    assert "ChildFailedError" in r.stderr or "torch.distributed" in r.stderr, r.stderr[-2000:]
     assert "needs torch.distributed.run" not in r.stderr
