@@ -32,7 +32,7 @@
 //    two 16-byte stores per lane, same address pattern as the loads.
 //
 // Kernels in this file: dct32_lds_kernel (LDS-staged line-dense traffic, forward / inverse),
-// dct32_fwdinv_lds_kernel (coefficients + reconstruction in one pass), dct32_from_tiles_kernel
+// dct32_fwdinv_kernel (coefficients + reconstruction in one pass, LDS-DMA fed), dct32_from_tiles_kernel
 // (residual formation fused in), dct32_pass_kernel (the 1-D pass by itself, for checking).  The direct
 // fragment-load forms and the variants without cache-policy hints of rounds 1-3 are gone: every A/B they
 // served is frozen in profiles/r01_*.txt (line-dense traffic +9 %, "nt" loads / "sc1 nt" stores +3-5 %).
@@ -156,38 +156,72 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
 }
 
 // ---- fused forward + inverse (coefficients AND reconstruction) ------------------------------
-// recon = IDCT32(DCT32(x)) with both results written: 2 KiB in, 2 + 2 KiB out per block (6144
-// algorithmic bytes) instead of 4 + 4 KiB for the two kernels back to back.  After the
-// forward passes the coefficient tile sits in the wave's LDS slot for its line-dense store anyway;
-// the inverse reads its columns from there, as the staged inverse does from a loaded tile.
-__global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__restrict__ in,
+// recon = IDCT32(DCT32(x)) with both results written: 2 KiB in, 2 + 2 KiB out per block (6144 algorithmic bytes)
+// instead of 4 + 4 KiB for the two kernels back to back.  Round 5's kernel (profiles/r05_fused_variants.txt):
+//  * The inverse is fed from REGISTERS.  The forward's pass 2 in the OTHER operand orientation -- coefficients = A, pass-1
+//    data = B, the orientation the inverse's pass B uses -- leaves in lane (i, h) the 16 sums Z[acc_row(r, h)][kappa(i)]:
+//    sixteen rows v of one column u, i.e. the A fragment of the inverse's first (column) contraction when that pass pairs its
+//    K-slots in accumulator-row order (build_inv_ops(o, false)).  Both orientations use the SAME constant image (k.p2) and the
+//    same data planes: two more MFMAs (the matrix core is 10 % busy) instead of round 4's trip of the coefficient tile through
+//    LDS (16 x ds_read_u16 per lane behind the tile's ds_write).  The byte-plane offset fix of the swapped pass belongs to
+//    output row v = 0 = accumulator register 0 of the lower half-wave.  With coef_out == NULL only the swapped orientation runs.
+//  * Nothing inside the loop is visible to the compiler's vmcnt bookkeeping.  Round 4's loops carried an `s_waitcnt vmcnt(0)`
+//    in the middle of pass 1 (the compiler cannot see the inline-asm stores and merged the loop-entry state, constant loads
+//    pending, into the loop): the "prefetched" next block and the previous block's stores were waited for on the spot.  Here
+//    inputs arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) into DEPTH 2 KiB slots, stores are
+//    the sc1 nt instructions with a scalar base, and the one wait per block is counted by hand -- a wave's vector memory
+//    operations retire in issue order, so "block i has landed" = at most {2 DMA per younger block in flight + the stores
+//    issued since its DMA} outstanding.  The DMA writes lane l's 16 bytes at slot + 16 l: the bank swizzle of lds_slot() is
+//    applied on the GLOBAL side (the same whole lines per instruction).  Slot DEPTH is the layout converter of the outputs.
+//  * Launch shape: 4-wave workgroups, 2 blocks per wave (both fetched up front), 12 KiB of LDS charged per wave = 12 resident
+//    waves per CU.  Deeper pipelines with long-lived waves (3 slots, 16 blocks per wave, 8 waves per CU) are 3-5 % faster on
+//    some boxes and 5-8 % slower on others; this shape gave 0.73-0.76 of 8 TB/s on every one of eight boxes (round 4's
+//    kernel: 0.66-0.77 on the same boxes).
+__device__ __forceinline__ void wait_vmcnt_even(unsigned n)
+{
+    switch (n) {
+#define X266_WAIT(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    X266_WAIT(2) X266_WAIT(4) X266_WAIT(6) X266_WAIT(8) X266_WAIT(10) X266_WAIT(12) X266_WAIT(14) X266_WAIT(16) X266_WAIT(18) X266_WAIT(20)
+    X266_WAIT(22) X266_WAIT(24) X266_WAIT(26) X266_WAIT(28) X266_WAIT(30) X266_WAIT(32) X266_WAIT(34) X266_WAIT(36) X266_WAIT(38) X266_WAIT(40)
+#undef X266_WAIT
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// two 1 KiB-linear stores of one tile: scalar base + the lane's 32-bit offset, "sc1 nt" (x266_device.hpp, store16_sc1nt)
+__device__ __forceinline__ void store_tile_sc1nt(char *base, unsigned lane_off, const v4i &s0, const v4i &s1)
+{
+    asm volatile("global_store_dwordx4 %0, %1, %3 sc1 nt\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024 sc1 nt\n\ts_nop 1"
+                 : : "v"(lane_off), "v"(s0), "v"(s1), "s"(base) : "memory");
+}
+
+template <int DEPTH, bool COEF>
+__global__ __launch_bounds__(256) void dct32_fwdinv_kernel(const int16_t *__restrict__ in,
                                                                int16_t *__restrict__ coef_out,
                                                                int16_t *__restrict__ recon_out, size_t n_blocks,
                                                                const DctOps *__restrict__ fwd_ops,
                                                                const DctOps *__restrict__ inv_ops,
-                                                               unsigned blocks_per_wave)
+                                                               unsigned blocks_per_wave, unsigned lds_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
     const int lane = threadIdx.x & 63;
-    unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    size_t b = wave * blocks_per_wave;
-    const size_t end = b + blocks_per_wave < n_blocks ? b + blocks_per_wave : n_blocks;
-    if (b >= end) return;
+    const unsigned wave_in_wg = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+    const size_t first = wave * blocks_per_wave;
+    if (first >= n_blocks) return;
+    const unsigned cnt = n_blocks - first < blocks_per_wave ? (unsigned)(n_blocks - first) : blocks_per_wave;
+    unsigned char *slots = stage + wave_in_wg * lds_per_wave;
+    unsigned char *conv = slots + DEPTH * 2048;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)slots;
 
     const unsigned c = lane & 31, h = lane >> 5;
     const unsigned lin0 = lds_slot(lane >> 2, lane & 3), lin1 = lds_slot(16 + (lane >> 2), lane & 3);
     const unsigned frag0 = lds_slot(c, 2 * h), frag1 = lds_slot(c, 2 * h + 1);
-    unsigned col_base[4];
-    {
-        const unsigned u = (unsigned)kappa((int)c);
-#pragma unroll
-        for (unsigned j = 0; j < 4; ++j) col_base[j] = 16u * h * 64u + ((((u >> 3) ^ j) & 3u) << 4) + (u & 7u) * 2u;
-    }
-    const char *src = reinterpret_cast<const char *>(in) + lane * 16;
-    const size_t lane_off = (size_t)lane * 16;
+    // the lane's LDS position 16 * lane (+ 1024) holds chunk (row, (lane & 3) ^ swizzle(row)) of the block
+    const unsigned goff0 = (unsigned)(lane >> 2) * 64u + ((((unsigned)lane & 3u) ^ (((unsigned)lane >> 4) & 3u)) << 4), goff1 = goff0 + 1024u;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    const char *src = reinterpret_cast<const char *>(in) + first * 2048;
 
-    v4i g0 = load16<true>(src + b * 2048), g1 = load16<true>(src + b * 2048 + 1024);
     const LaneConsts kf = load_consts(fwd_ops, lane);
     const LaneConsts ki = load_consts(inv_ops, lane);
     v16i c2r;
@@ -196,58 +230,101 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_lds_kernel(const int16_t *__
 #pragma unroll
         for (int r = 0; r < 16; ++r) c2r[r] = h ? s1[r] : s0[r];
     }
-    while (true) {
-        const size_t nb = b + 1;
-        *reinterpret_cast<v4i *>(slot + lin0) = g0;
-        *reinterpret_cast<v4i *>(slot + lin1) = g1;
-        if (nb < end) {
-            g0 = load16<true>(src + nb * 2048);
-            g1 = load16<true>(src + nb * 2048 + 1024);
+    auto fetch = [&](unsigned j, unsigned s) {                    // block j of this wave's run into input slot s
+        const char *blk = src + (size_t)j * 2048;
+        const unsigned lds = lds0 + s * 2048u;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(goff0), "v"(goff1), "s"(blk), "s"(lds), "s"(lds + 1024u) : "memory");
+    };
+#pragma unroll
+    for (unsigned j = 0; j < (unsigned)DEPTH; ++j)
+        if (j < cnt) fetch(j, j);
+    // every compiler-visible load has landed before the loop: no s_waitcnt vmcnt of the compiler's inside it
+    {
+        v4i a = kf.p1, b = kf.p2, d = ki.p1, e = ki.p2;
+        int c1 = kf.c1, c2 = kf.c2, c3 = ki.c1;
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(d), "+v"(e), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c2r));
+        const_cast<LaneConsts &>(kf).p1 = a; const_cast<LaneConsts &>(kf).p2 = b; const_cast<LaneConsts &>(ki).p1 = d; const_cast<LaneConsts &>(ki).p2 = e;
+        const_cast<LaneConsts &>(kf).c1 = c1; const_cast<LaneConsts &>(kf).c2 = c2; const_cast<LaneConsts &>(ki).c1 = c3;
+    }
+    const int c2s0 = (1 << 10) + (h ? 0 : 128 * 2048);            // swapped pass 2: row v = acc_row(0, 0) = 0 carries the offset fix
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr unsigned kStoresPerBlock = COEF ? 4u : 2u;
+    unsigned si = 0;                                               // i mod DEPTH
+    for (unsigned i = 0; i < cnt; ++i) {
+        const unsigned younger_loads = cnt - 1 - i < (unsigned)(DEPTH - 1) ? cnt - 1 - i : (unsigned)(DEPTH - 1);
+        const unsigned stores_since = i < (unsigned)DEPTH ? i : (unsigned)DEPTH;
+        if (i >= (unsigned)DEPTH && i + DEPTH <= cnt) {             // steady state: DEPTH - 1 younger blocks in flight, DEPTH blocks' stores since
+            constexpr unsigned kSteady = 2u * (DEPTH - 1) + kStoresPerBlock * DEPTH;
+            static_assert(kSteady <= 40, "wait_vmcnt_even");
+            wait_vmcnt_even(kSteady);
+        } else {
+            wait_vmcnt_even(2u * younger_loads + kStoresPerBlock * stores_since);
         }
-        __builtin_amdgcn_wave_barrier();
-        v4i o0, o1;
+        unsigned char *slot = slots + si * 2048u;
+        v4i ylo, yhi;
         {
             const v4i a0 = *reinterpret_cast<const v4i *>(slot + frag0);
             const v4i a1 = *reinterpret_cast<const v4i *>(slot + frag1);
-            fwd_block<4, 11>(a0, a1, kf, o0, o1);
-        }
-        __builtin_amdgcn_wave_barrier();
-        *reinterpret_cast<v4i *>(slot + frag0) = o0;               // coefficient tile, row-major (swizzled)
-        *reinterpret_cast<v4i *>(slot + frag1) = o1;
-        __builtin_amdgcn_wave_barrier();
-        if (coef_out) {
-            const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
-            const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
-            char *dst = reinterpret_cast<char *>(coef_out) + b * 2048 + lane_off;
-            store16_sc1nt(dst, s0);
-            store16_sc1nt(dst + 1024, s1);
-        }
-        {
-            uint32_t w[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const uint32_t e0 = *reinterpret_cast<const uint16_t *>(slot + col_base[((2 * m) >> 2) & 3] + (2 * m) * 64);
-                const uint32_t e1 = *reinterpret_cast<const uint16_t *>(slot + col_base[((2 * m + 1) >> 2) & 3] + (2 * m + 1) * 64);
-                w[m] = e0 | (e1 << 16);
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the fragments are in registers: the slot may be refilled
+            if (i + DEPTH < cnt) fetch(i + DEPTH, si);
             v4i lo, hi;
-            split_planes(v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}, v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]}, lo, hi);
-            inv_passes(lo, hi, ki, c2r, o0, o1);
+            split_planes(a0, a1, lo, hi);
+            v16i acc = mfma(hi, kf.p1, zero);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)kf.c1);
+            acc = mfma(lo, kf.p1, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] >> 4;
+            pack_planes(acc, ylo, yhi);
         }
+        // pass 2, swapped orientation: the inverse's input fragment
+        v4i zlo, zhi;
+        {
+            v16i acc = mfma(kf.p2, yhi, zero);
+            acc[0] = (int)(((uint32_t)acc[0] << 8) + (uint32_t)c2s0);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (1u << 10));
+            acc = mfma(kf.p2, ylo, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] >> 11;       // bytes 0 / 1 = the int16 coefficient
+            pack_planes(acc, zlo, zhi);
+        }
+        if (COEF) {
+            // pass 2, natural orientation: the coefficient tile, 16 consecutive coefficients of one row per lane
+            v16i acc = mfma(yhi, kf.p2, zero);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)kf.c2);
+            acc = mfma(ylo, kf.p2, acc);
+            uint32_t z[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                z[m] = bperm((uint32_t)(acc[2 * m + 1] >> 11), (uint32_t)(acc[2 * m] >> 11), 0x05040100u);
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<v4i *>(conv + frag0) = v4i{(int)z[0], (int)z[1], (int)z[2], (int)z[3]};
+            *reinterpret_cast<v4i *>(conv + frag1) = v4i{(int)z[4], (int)z[5], (int)z[6], (int)z[7]};
+            __builtin_amdgcn_wave_barrier();
+            const v4i s0 = *reinterpret_cast<const v4i *>(conv + lin0);
+            const v4i s1 = *reinterpret_cast<const v4i *>(conv + lin1);
+            store_tile_sc1nt(reinterpret_cast<char *>(coef_out) + (first + i) * 2048, lane_off, s0, s1);
+        }
+        v4i o0, o1;
+        inv_passes(zlo, zhi, ki, c2r, o0, o1);
         __builtin_amdgcn_wave_barrier();
-        *reinterpret_cast<v4i *>(slot + frag0) = o0;
-        *reinterpret_cast<v4i *>(slot + frag1) = o1;
+        *reinterpret_cast<v4i *>(conv + frag0) = o0;
+        *reinterpret_cast<v4i *>(conv + frag1) = o1;
         __builtin_amdgcn_wave_barrier();
         {
-            const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
-            const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
+            const v4i s0 = *reinterpret_cast<const v4i *>(conv + lin0);
+            const v4i s1 = *reinterpret_cast<const v4i *>(conv + lin1);
             __builtin_amdgcn_wave_barrier();
-            char *dst = reinterpret_cast<char *>(recon_out) + b * 2048 + lane_off;
-            store16_sc1nt(dst, s0);
-            store16_sc1nt(dst + 1024, s1);
+            store_tile_sc1nt(reinterpret_cast<char *>(recon_out) + (first + i) * 2048, lane_off, s0, s1);
         }
-        if (nb >= end) break;
-        b = nb;
+        si = si + 1 == (unsigned)DEPTH ? 0u : si + 1;
     }
 }
 
@@ -356,15 +433,19 @@ hipError_t launch_dct32_pass(const int16_t *d_in, int16_t *d_out, size_t n_block
 }
 
 hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,
-                               const DctOps *d_fwd_ops, const DctOps *d_inv_lds_ops, const LaunchCfg &cfg, hipStream_t stream)
+                               const DctOps *d_fwd_ops, const DctOps *d_inv_acc_ops, const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
+    constexpr int kDepth = 2;
     const unsigned tpb = (unsigned)cfg.wg_threads;
     const unsigned bpw = units_per_wave_for(cfg, n_blocks);
     const size_t wpw = tpb / 64, waves = (n_blocks + bpw - 1) / bpw, wgs = (waves + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const size_t lds = wpw * (size_t)cfg.lds_bytes_per_wave;
-    hipLaunchKernelGGL(dct32_fwdinv_lds_kernel, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_lds_ops, bpw);
+    const unsigned need = (kDepth + 1) * 2048u;                                // input slots + the converter
+    const unsigned per_wave = (unsigned)cfg.lds_bytes_per_wave < need ? need : (unsigned)cfg.lds_bytes_per_wave;
+    const size_t lds = wpw * (size_t)per_wave;
+    if (d_coef) hipLaunchKernelGGL((dct32_fwdinv_kernel<kDepth, true>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_acc_ops, bpw, per_wave);
+    else        hipLaunchKernelGGL((dct32_fwdinv_kernel<kDepth, false>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_acc_ops, bpw, per_wave);
     return hipGetLastError();
 }
 

@@ -104,7 +104,7 @@ hipError_t launch_transform_tiles(bool inverse, const int16_t *d_in, int16_t *d_
 hipError_t launch_dct32_butterfly(const int16_t *d_in, int16_t *d_out, size_t n_blocks, hipStream_t stream);
 hipError_t launch_dct32_pass(const int16_t *d_in, int16_t *d_out, size_t n_blocks, int shift, const DctOps *d_fwd_ops, hipStream_t stream);
 hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,
-                               const DctOps *d_fwd_ops, const DctOps *d_inv_lds_ops, const LaunchCfg &cfg, hipStream_t stream);
+                               const DctOps *d_fwd_ops, const DctOps *d_inv_acc_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_dct32(bool inverse, const int16_t *d_in, int16_t *d_out, size_t n_blocks,
                         const DctOps *d_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_transform_small(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,

@@ -29,6 +29,7 @@ struct x266hip_ctx {
     hipDeviceProp_t prop{};
     DctOps *d_fwd = nullptr;
     DctOps *d_inv_lds = nullptr;                    // inverse operand images for the LDS-staged kernel (column reads)
+    DctOps *d_inv_acc = nullptr;                    // the same with pass A's K-slots in accumulator-row order (fused kernel: the inverse is fed from the forward's registers)
     static constexpr int kTypes = 4;                // DCT-II, DST-VII, and the two mixed horizontal / vertical pairs
     DctOps *d_tr[kTypes][3] = {};                   // [type][log2N - 2], N = 4, 8, 16
     DctOps *d_tr_inv[kTypes][3] = {};
@@ -41,14 +42,15 @@ struct x266hip_ctx {
     // Launch options (xHipSetOption): A/B knobs, results never depend on them.  Defaults = the measured optimum.
     int dct_variant = 0;                            // 0 = matrix-core kernel, 2 = VALU butterfly (the comparison variant north_star asks for)
     int satd_variant = 0;                           // 0 = by batch size (staged kernel below 3 Mi blocks, LDS-DMA kernel from there), 1 = staged, 2 = VALU butterfly, 3 = LDS-DMA
-    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, dct_fwdinv_blocks_per_wave = 4;   // consecutive blocks one wave loops over (profiles/r01_launch_sweep.txt)
+    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, dct_fwdinv_blocks_per_wave = 2;   // consecutive blocks one wave loops over (profiles/r01_launch_sweep.txt)
     int satd_groups_per_wave = 0, satd_wg_threads = 0, satd_lds_per_wave = 0;                   // 0 = the chosen SATD kernel's own default (satd_kernels.hip, launch_satd8x8)
     int adaptive_per_wave = 1;                      // shrink the per-wave run on small batches
-    int dct_wg_threads = 0;                         // workgroup size of the DCT32 / transform-set kernels; 0 = the measured best: one-wave workgroups (profiles/r01_wg_occupancy.txt), two-wave ones for the fused forward + inverse kernel (profiles/r04_fused_mix_ceiling.txt)
+    int dct_wg_threads = 0;                         // workgroup size of the DCT32 / transform-set kernels; 0 = the measured best: one-wave workgroups (profiles/r01_wg_occupancy.txt), four-wave ones for the fused forward + inverse kernel (profiles/r05_fused_variants.txt)
     int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (0 = 2: the wave's table copy serves two tiles)
     int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (SATD search: 8, 4 or 2; SAD search: 2), else 2, 4, 8 (8: SATD search only; 1 is served by 2)
     // fixed launch shapes (options in rounds 1-3; their sweeps are frozen in profiles/r01_*.txt, r03_tiles_one_launch.txt)
     static constexpr int kDctLdsPerWave = 8192;     // 2 KiB used: at most 20 resident waves per CU
+    static constexpr int kFwdInvLdsPerWave = 12288; // fused forward + inverse: 6 KiB used (two DMA slots + the converter): 12 resident waves per CU
     static constexpr int kTileLdsPerWave = 8192;    // table + two tile slots = 6 KiB used
     static constexpr int kIntraRounds = 4;          // intra prediction: rounds of seven predictions per wave
     // Internal device scratch, ONE BUFFER PER STREAM AND KIND, so that calls enqueued on different streams never share it:
@@ -321,6 +323,11 @@ int xHipCodecInit(x266hip_ctx **out, int device_id)
              hipMemcpy(ctx->d_inv_lds, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok) {
+        build_inv_ops(*h, false);
+        ok = hipMalloc((void **)&ctx->d_inv_acc, sizeof(DctOps)) == hipSuccess &&
+             hipMemcpy(ctx->d_inv_acc, h, sizeof(DctOps), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (ok) {
         for (int slot = 0; slot < 2; ++slot)
             for (int l = 0; l < 3; ++l) default_slot_matrix(slot, 4 << l, ctx->slot_mat[slot][l]);
         ok = hipMalloc((void **)&ctx->d_tile_fwd, sizeof(TileTab)) == hipSuccess &&
@@ -364,6 +371,7 @@ void xHipCodecFree(x266hip_ctx *ctx)
     if (ctx->d_tile_inv) (void)hipFree(ctx->d_tile_inv);
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
     if (ctx->d_inv_lds) (void)hipFree(ctx->d_inv_lds);
+    if (ctx->d_inv_acc) (void)hipFree(ctx->d_inv_acc);
     delete ctx;
 }
 
@@ -479,8 +487,9 @@ int xDct32FwdInvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_coef,
     X_DEV(ctx);
     LaunchCfg cfg = cfg_for(ctx, 1);
     cfg.units_per_wave = ctx->dct_fwdinv_blocks_per_wave;
-    if (!ctx->dct_wg_threads) cfg.wg_threads = 128;                     // 1.5-2 % over one-wave workgroups on every box measured
-    hipError_t e = launch_dct32_fwdinv(d_in, d_coef, d_recon, n, ctx->d_fwd, ctx->d_inv_lds, cfg, (hipStream_t)stream);
+    if (!ctx->dct_wg_threads) cfg.wg_threads = 256;                     // the shape that held 0.73-0.76 of 8 TB/s on every box (profiles/r05_fused_variants.txt)
+    cfg.lds_bytes_per_wave = x266hip_ctx::kFwdInvLdsPerWave;
+    hipError_t e = launch_dct32_fwdinv(d_in, d_coef, d_recon, n, ctx->d_fwd, ctx->d_inv_acc, cfg, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fwd+inv launch", e);
     return X266HIP_OK;
 }
