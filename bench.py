@@ -7,37 +7,31 @@ Contract (one JSON line on stdout from rank 0):
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
   (plain `python bench.py --gpus N` without WORLD_SIZE in the environment spawns exactly that itself)
 
-Workload = BASELINE.json configs[1]: 1,048,576 synthetic 9-bit residual blocks of
-32x32 int16 per GPU, resident in HBM before the timed region (values a-b, a,b
-uniform bytes -- the reference's stimulus distribution, src_tb/dct32.c:191-193 --
-from SplitMix64 seed 0x266).  A "step" is one forward 2-D DCT32 pass over the
-batch (xDct32FwdBatchDev through the C ABI).  `value` is whole-job forward
-blocks/s over all ranks; every other leg (inverse, fused forward+inverse, the 8x8
-SATD residual batch of 2^24 blocks, motion search, the transform set, the
-8K frame stream of configs[4], ...) is measured the same way under "also".
+Workload = BASELINE.json configs[1]: 1,048,576 synthetic 9-bit residual blocks of 32x32 int16 per GPU, resident in HBM
+before the timed region (values a-b, a,b uniform bytes -- the reference's stimulus distribution, src_tb/dct32.c:191-193 --
+from SplitMix64 seed 0x266).  A "step" is one forward 2-D DCT32 pass over the batch (xDct32FwdBatchDev through the C ABI).
+`value` is whole-job forward blocks/s over all ranks; every other leg (inverse, fused forward+inverse, the 8x8 SATD residual
+batch of 2^24 blocks, motion search, the transform set, the 8K frame stream of configs[4], ...) is one function below,
+measured the same way, and lands under "also".
 
-How every leg is timed (`timed_leg`): its own clock pre-warm (the chip needs ~50 ms
-of load to reach steady clocks, profiles/r01_clock_warmup.txt), W untimed launches,
-then K launches between barrier + synchronize on both sides; a HIP event is
-recorded ON THE LAUNCHING STREAM before every one of those K launches and after the
-last, so `kernel_ms_mean` / `kernel_ms_median` come from the very launches whose
-wall-clock is `ms_per_step` (the former can never exceed the latter).
+The process runs on the runtime the library ships on: device memory, streams and events come from the C ABI (xHipMalloc,
+xHipMemcpy*, xHipEvent*) and, for the two raw link copies of the host-API leg, from the HIP runtime libx266hip.so itself
+loaded (ctypes) -- no torch in the single-GPU path.  With N > 1, torch.distributed is the CONTROL plane only, on gloo,
+imported after the library: barrier, max-over-ranks time, checksum sum, the broadcast of the node's RCCL id; the data path
+(RCCL send/recv groups of the node layer, x266_amd/csrc/x266hip_node.cpp) then talks to ROCm's librccl, not the older copy
+the torch wheel bundles.  `hip_runtime` / `rccl_by_rank` in the line say which libraries the process really had.
 
-Independent blocks shard across ranks with no data-path collective (weak
-scaling: every rank owns its own 1 Mi-block slice of the one seeded stream);
-torch.distributed (RCCL) carries the barrier, the max-over-ranks time, a
-checksum reduction and the broadcast of the node's RCCL id.  The end-to-end
-scatter -> transform -> gather figures (8K frame stream, batch scatter-gather,
-sharded motion search) go through the node layer of the C ABI
-(x266_amd/csrc/x266hip_node.cpp: RCCL send/recv groups) at every N, N = 1 included.
+How every leg is timed (`Bench.timed_leg`): its own clock pre-warm (the chip needs ~50 ms of load to reach steady clocks,
+profiles/r01_clock_warmup.txt), W untimed launches, then K launches between barrier + device synchronize on both sides; a HIP
+event is recorded ON THE LAUNCHING STREAM before every one of those K launches and after the last, so the kernel durations
+come from the very launches whose wall-clock is `ms_per_step`.  Fractions use `kernel_ms` = the 10 % trimmed mean of those K
+durations (a profiler's or the host's hiccup on 1 launch in 20 must not move a fraction by 2x: round 4's sad_8x8 row);
+the plain mean and the median are reported next to it.
 
-"roofline": algorithmic bytes per launch (4096 B per DCT block, 132 B per SATD
-block) / mean launch duration from the events above,
-against the 8 TB/s HBM3E peak.
-"cpu_baseline": the reference C path on this node's host cores (oracle/_ref =
-the real src_tb/dct32.c when its prebuilt .so is present, else the oracle's
-restatement), bounded sample, rank 0 at N = 1 only.  The oracle is used here and
-nowhere in the product.
+"roofline": algorithmic bytes per launch (4096 B per DCT block, 132 B per SATD block) / kernel_ms,
+against the 8 TB/s HBM3E peak.  "cpu_baseline": the reference C path on this node's host cores (oracle/_ref = the real
+src_tb/dct32.c when its prebuilt .so is present, else the oracle's restatement), rank 0 at N = 1 only.  The oracle is used
+there and nowhere in the product.
 """
 import argparse
 import ctypes
@@ -61,6 +55,7 @@ DCT_BYTES_PER_BLOCK = 4096             # 2048 read + 2048 written   (SURVEY.md 8
 SATD_BYTES_PER_BLOCK = 132             # 128 read + 4 written
 DCT_SEED, SATD_SEED = 0x266, 0x267
 PREWARM_SECONDS = 0.08
+P = ctypes.c_void_p
 
 
 def parse_args():
@@ -86,6 +81,58 @@ def parse_args():
 
 
 # ------------------------------------------------------------------------------------------------
+# the HIP runtime of this process (the copy libx266hip.so loaded), through ctypes
+# ------------------------------------------------------------------------------------------------
+def loaded_libraries(prefix):
+    """paths of the shared objects mapped into this process whose file name starts with `prefix`"""
+    seen = []
+    for line in open("/proc/self/maps"):
+        parts = line.split()
+        if len(parts) >= 6 and parts[5].rsplit("/", 1)[-1].startswith(prefix) and parts[5] not in seen:
+            seen.append(parts[5])
+    return seen
+
+
+class HipRuntime:
+    """what bench.py needs of HIP beyond the C ABI: device synchronize, the PCI address, raw async copies for the link's own rate"""
+
+    def __init__(self):
+        self.paths = loaded_libraries("libamdhip64.so")
+        if not self.paths:
+            raise SystemExit("libx266hip.so did not bring a HIP runtime into the process")
+        self.lib = L = ctypes.CDLL(self.paths[0])
+        L.hipMemcpyAsync.argtypes = [P, P, ctypes.c_size_t, ctypes.c_int, P]
+        L.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(P), ctypes.c_uint]
+        L.hipStreamSynchronize.argtypes = [P]
+        L.hipStreamDestroy.argtypes = [P]
+        L.hipDeviceGetPCIBusId.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: hipError %d" % (what, rc))
+
+    def device_sync(self):
+        self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")
+
+    def version(self):
+        v = ctypes.c_int()
+        self.check(self.lib.hipRuntimeGetVersion(ctypes.byref(v)), "hipRuntimeGetVersion")
+        return v.value
+
+    def pci_bus_id(self, device):
+        buf = ctypes.create_string_buffer(64)
+        return buf.value.decode().lower() if self.lib.hipDeviceGetPCIBusId(buf, 64, device) == 0 else None
+
+    def stream_create(self):
+        s = P()
+        self.check(self.lib.hipStreamCreateWithFlags(ctypes.byref(s), 1), "hipStreamCreateWithFlags")   # hipStreamNonBlocking
+        return s
+
+    def memcpy_async(self, dst, src, nbytes, kind, stream):
+        self.check(self.lib.hipMemcpyAsync(P(dst), P(src), nbytes, kind, stream), "hipMemcpyAsync")
+
+
+# ------------------------------------------------------------------------------------------------
 # roofline.traffic, live: HBM bytes of one headline launch from the PMC counters, collected as
 # MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes with --kernel-trace only
 # (never with sys / hip / hsa traces), units KB.  gfx950's FETCH_SIZE counts the 128-byte requests of 16 B-per-lane
@@ -95,19 +142,16 @@ def parse_args():
 # ------------------------------------------------------------------------------------------------
 def traffic_child(args):
     """what the profiled passes run: the calibration copy and the headline launch on the full batch, a few times, nothing else"""
-    import torch
     import x266_amd
     codec = x266_amd.Codec(0)
     n = args.dct_blocks
-    x = torch.empty(n * 1024, dtype=torch.int16, device="cuda")
-    z = torch.empty_like(x)
-    stream = torch.cuda.current_stream().cuda_stream
-    codec.fill_residual_dev(x.data_ptr(), n * 1024, DCT_SEED, 0, stream)
+    x, z = codec.alloc(n * 2048), codec.alloc(n * 2048)
+    codec.fill_residual_dev(x.ptr, n * 1024, DCT_SEED, 0, 0)
     for _ in range(3):
-        codec.mem_ceiling_dev(0, x.data_ptr(), z.data_ptr(), n * 2048, stream)
+        codec.mem_ceiling_dev(0, x.ptr, z.ptr, n * 2048, 0)
     for _ in range(6):
-        codec.dct32_fwd_dev(x.data_ptr(), z.data_ptr(), n, stream)
-    torch.cuda.synchronize()
+        codec.dct32_fwd_dev(x.ptr, z.ptr, n, 0)
+    codec.stream_sync()
 
 
 def measure_traffic_live(n_dct, budget_s=150.0):
@@ -248,41 +292,8 @@ def run_pinned(n_units, cores, work, make_local):
     return max(ends) - t0, outs, bounds
 
 
-def cpu_baseline_dct(x_host, gpu_out_host):
-    """Reference C path timed on the host cores (rank 0, N = 1).  Returns the
-    cpu_baseline object; also checks the GPU output against it bit-for-bit."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from _util import Oracle, Reference, ref_path
-
-    orc = Oracle()
-    n = x_host.shape[0]
-    have_ref = os.path.exists(ref_path())
-    ref = Reference() if have_ref else None
-
-    def call(fn_ref, fn_orc):
-        def work(loc_in, loc_out, cnt):
-            if have_ref:
-                fn_ref(ctypes.c_void_p(loc_in.ctypes.data), ctypes.c_void_p(loc_out.ctypes.data), ctypes.c_ulong(cnt))
-            else:
-                fn_orc(ctypes.c_void_p(loc_in.ctypes.data), ctypes.c_void_p(loc_out.ctypes.data), ctypes.c_size_t(cnt), 1)
-        return work
-
-    work = call(ref.lib.ref_dct32_fwd if have_ref else None, orc.lib.orc_dct32_fwd_mt)
-
-    def make_local(b, e):
-        loc_in = x_host[b:e].copy()
-        loc_out = np.zeros_like(loc_in)
-        return loc_in, loc_out
-
-    # single pinned thread, bounded sample, same code path
-    n1 = min(n, 32768)
-    dt1, _, _ = run_pinned(n1, 1, work, make_local)
-    single = n1 / dt1
-    cores, hw, quota, trial = best_thread_count(n, work, make_local)
-    dt, outs, bounds = run_pinned(n, cores, work, make_local)
-    exact = all(np.array_equal(outs[i], gpu_out_host[int(bounds[i]):int(bounds[i + 1])]) for i in range(cores))
-    # secondary figure (BASELINE.md section 4): the restatement built -O3 -march=native ON THIS HOST
-    native = None
+def native_port_rate(n, cores, make_local, outs_ref):
+    """secondary figure: the restatement built -O3 -march=native ON THIS HOST; None when it cannot be built"""
     try:
         import glob
         import subprocess
@@ -294,13 +305,41 @@ def cpu_baseline_dct(x_host, gpu_out_host):
         nat = ctypes.CDLL(so)
 
         def work_n(loc_in, loc_out, cnt):
-            nat.orc_dct32_fwd_mt(ctypes.c_void_p(loc_in.ctypes.data), ctypes.c_void_p(loc_out.ctypes.data), ctypes.c_size_t(cnt), 1)
+            nat.orc_dct32_fwd_mt(P(loc_in.ctypes.data), P(loc_out.ctypes.data), ctypes.c_size_t(cnt), 1)
         dt_n, outs_n, _ = run_pinned(n, cores, work_n, make_local)
-        if all(np.array_equal(a, b) for a, b in zip(outs_n, outs)):
-            native = n / dt_n
         os.unlink(so)
+        return n / dt_n if all(np.array_equal(a, b) for a, b in zip(outs_n, outs_ref)) else None
     except Exception:
-        native = None
+        return None
+
+
+def cpu_baseline_dct(x_host, gpu_out_host):
+    """Reference C path timed on the host cores (rank 0, N = 1).  Returns the
+    cpu_baseline object; also checks the GPU output against it bit-for-bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _util import Oracle, Reference, ref_path
+
+    orc = Oracle()
+    n = x_host.shape[0]
+    have_ref = os.path.exists(ref_path())
+    ref = Reference() if have_ref else None
+
+    def work(loc_in, loc_out, cnt):
+        if have_ref:
+            ref.lib.ref_dct32_fwd(P(loc_in.ctypes.data), P(loc_out.ctypes.data), ctypes.c_ulong(cnt))
+        else:
+            orc.lib.orc_dct32_fwd_mt(P(loc_in.ctypes.data), P(loc_out.ctypes.data), ctypes.c_size_t(cnt), 1)
+
+    def make_local(b, e):
+        loc_in = x_host[b:e].copy()
+        return loc_in, np.zeros_like(loc_in)
+
+    n1 = min(n, 32768)                                                    # single pinned thread, bounded sample, same code path
+    dt1, _, _ = run_pinned(n1, 1, work, make_local)
+    single = n1 / dt1
+    cores, hw, quota, trial = best_thread_count(n, work, make_local)
+    dt, outs, bounds = run_pinned(n, cores, work, make_local)
+    exact = all(np.array_equal(outs[i], gpu_out_host[int(bounds[i]):int(bounds[i + 1])]) for i in range(cores))
     model, flags = host_cpu_facts()
     return {
         "value": n / dt, "unit": "blocks/s", "cores": cores, "kind": "reference" if have_ref else "port",
@@ -310,34 +349,51 @@ def cpu_baseline_dct(x_host, gpu_out_host):
         "parallel_efficiency": (n / dt) / (min(cores, quota) * single),
         "host_hw_threads": hw, "container_cpu_quota": quota,
         "short_trials_blocks_per_s_by_threads": {str(k): v for k, v in trial.items()},
-        "port_O3_march_native_all_cores_blocks_per_s": native,
+        "port_O3_march_native_all_cores_blocks_per_s": native_port_rate(n, cores, make_local, outs),
         "host_cpu": model, "host_cpu_flags": flags,
         "gpu_output_bit_exact_vs_cpu": exact,
     }, exact
 
 
-def gpu_sysfs_dir(torch):
-    """/sys/class/drm/cardN/device of cuda:0, matched by PCI address (a box shows every GPU of the host in sysfs, not only its own)"""
+def cpu_baseline_satd(dh, gpu_s):
+    """the SATD port on the host cores over the first blocks of the GPU batch, and the GPU's costs against it"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _util import Oracle
+    orc = Oracle()
+    ns = dh.shape[0]
+
+    def satd_work(loc_in, loc_out, cnt):
+        orc.lib.orc_satd8x8_batch_mt(P(loc_in.ctypes.data), P(loc_out.ctypes.data), ctypes.c_size_t(cnt), 1)
+
+    def mk(b, e):
+        return dh[b:e].copy(), np.zeros(e - b, np.uint32)
+    cores_s, _, _, _ = best_thread_count(ns, satd_work, mk)
+    dt, outs, bounds = run_pinned(ns, cores_s, satd_work, mk)
+    return {"value": ns / dt, "unit": "blocks/s", "cores": cores_s, "kind": "port",
+            "sample": "first %d blocks of the GPU batch, %d pinned threads, pre-touched thread-local buffers" % (ns, cores_s),
+            "gpu_output_bit_exact_vs_cpu": all(np.array_equal(outs[i], gpu_s[int(bounds[i]):int(bounds[i + 1])]) for i in range(len(outs)))}
+
+
+# ------------------------------------------------------------------------------------------------
+# sysfs facts of the device (matched by PCI address: a box shows every GPU of the host, not only its own)
+# ------------------------------------------------------------------------------------------------
+def gpu_sysfs_dir(pci):
     import glob
-    try:
-        p = torch.cuda.get_device_properties(0)
-        want = "%04x:%02x:%02x." % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
-    except Exception:
+    if not pci:
         return None
     for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
-        if os.path.realpath(dev).split("/")[-1].startswith(want):
+        if os.path.realpath(dev).split("/")[-1].lower() == pci:
             return dev
     return None
 
 
 class SclkSampler:
-    """median shader clock (MHz) of cuda:0 while a leg runs, read from the device's hwmon freq1_input every 10 ms by a thread;
+    """median shader clock (MHz) of the device while a leg runs, read from its hwmon freq1_input every 10 ms by a thread;
     None where sysfs does not show it.  The VALU floors of the motion searches scale with it."""
 
-    def __init__(self, torch):
+    def __init__(self, sysfs_dir):
         import glob
-        dev = gpu_sysfs_dir(torch)
-        files = glob.glob(dev + "/hwmon/hwmon*/freq1_input") if dev else []
+        files = glob.glob(sysfs_dir + "/hwmon/hwmon*/freq1_input") if sysfs_dir else []
         self.path = files[0] if files else None
         self.samples = []
 
@@ -365,70 +421,455 @@ class SclkSampler:
         return statistics.median(busy) if busy else None
 
 
-def pcie_link_facts(torch):
-    """negotiated generation / width of the GPU's PCIe link from sysfs (the device of cuda:0 by PCI address when torch exposes it,
-    else whatever the AMD devices agree on)"""
-    import glob
-    dev = gpu_sysfs_dir(torch)
-    if dev:
-        try:
-            return {"speed": open(dev + "/current_link_speed").read().strip(), "width": open(dev + "/current_link_width").read().strip(),
-                    "device": os.path.realpath(dev).split("/")[-1]}
-        except OSError:
-            pass
-    seen = {}
-    for d in sorted(glob.glob("/sys/class/drm/card*/device")):
-        try:
-            if open(d + "/vendor").read().strip() != "0x1002":
-                continue
-            facts = tuple(open(d + "/" + k).read().strip() for k in ("current_link_speed", "current_link_width"))
-        except OSError:
-            continue
-        seen[facts] = seen.get(facts, 0) + 1
-    if len(seen) == 1:
-        (speed, width), cnt = next(iter(seen.items()))
-        return {"speed": speed, "width": width, "device": "all %d AMD devices in sysfs agree" % cnt}
-    return None
+def pcie_link_facts(sysfs_dir):
+    """negotiated generation / width of the GPU's PCIe link from sysfs"""
+    if not sysfs_dir:
+        return None
+    try:
+        return {"speed": open(sysfs_dir + "/current_link_speed").read().strip(), "width": open(sysfs_dir + "/current_link_width").read().strip(),
+                "device": os.path.realpath(sysfs_dir).split("/")[-1]}
+    except OSError:
+        return None
 
 
-def host_api_leg(codec, torch, n):
-    """xDct32FwdBatch on n blocks from pageable and from pinned host buffers, next to what the link itself gives (plain copies)"""
+def trimmed_mean(d, frac=0.10):
+    """mean of the middle 1 - 2 frac of the sorted durations"""
+    s = sorted(d)
+    k = int(len(s) * frac)
+    s = s[k:len(s) - k] if len(s) - 2 * k >= 1 else s
+    return sum(s) / len(s)
+
+
+def smooth_frame_pair(w, h, pad, seed, mv=(5, -3)):
+    """(cur [h, w], padded reference [h + 2 pad, w + 2 pad]) uint8: low-passed noise, the reference displaced by `mv` (planted motion)"""
+    rs = np.random.RandomState(seed)
+    big = rs.randint(0, 256, (h + 2 * pad + 16, w + 2 * pad + 16)).astype(np.float32)
+    c = np.cumsum(np.pad(big, ((3, 2), (3, 2)), mode="edge"), axis=0)
+    c = c[5:] - c[:-5]
+    c = np.cumsum(c, axis=1)
+    sm = (c[:, 5:] - c[:, :-5]) / 25.0                                   # 5x5 box low-pass so that motion is findable
+    sm = np.clip((sm - 128.0) * 3.0 + 128.0, 0, 255).astype(np.uint8)
+    cur = np.ascontiguousarray(sm[pad + 8:pad + 8 + h, pad + 8:pad + 8 + w])
+    refp = np.ascontiguousarray(sm[8 - mv[1]:8 - mv[1] + h + 2 * pad, 8 - mv[0]:8 - mv[0] + w + 2 * pad])
+    return cur, refp
+
+
+# ------------------------------------------------------------------------------------------------
+# the run: device, ranks, timing helpers
+# ------------------------------------------------------------------------------------------------
+class Bench:
+    def __init__(self, args):
+        import x266_amd                                                 # the library first: ITS HIP runtime is the process's
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch one rank per GPU (or run without torch.distributed.run: bench.py spawns its own ranks)" % (args.gpus, self.world))
+        n_dev = int(x266_amd.load_library().xHipDeviceCount())
+        if n_dev < 1:
+            raise SystemExit("bench.py needs an MI355X: libx266hip has no CPU path")
+        # Test hook (never set by the driver): X266_BENCH_SHARE_GPU=1 lets several ranks share the visible GPUs, so that the N > 1 code
+        # path -- shard offsets, max-over-ranks timing, checksum reduction -- can be exercised on a one-GPU box.  RCCL refuses two ranks
+        # on one device, so the node-layer legs run there only when X266HIP_RCCL_LIB names the tests' RCCL model.
+        self.share = os.environ.get("X266_BENCH_SHARE_GPU") == "1"
+        self.local_rank = local_rank % n_dev if self.share else local_rank
+        self.codec = x266_amd.Codec(self.local_rank)
+        self.hip = HipRuntime()
+        self.hip.check(self.hip.lib.hipSetDevice(self.local_rank), "hipSetDevice")
+        self.dist = None
+        if self.world > 1:                                              # control plane only, on gloo, AFTER the library (module docstring)
+            import torch.distributed as dist
+            import torch
+            self.torch = torch
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            self.dist = dist
+        self.K, self.W = args.steps, args.warmup
+        self.n_dct, self.n_satd = args.dct_blocks, args.satd_blocks
+        self.stream = 0                                                 # every launch and event of the legs: the NULL stream
+        self.events = [self.codec.event_create() for _ in range(max(self.K, 64) + 1)]
+        self.info = self.codec.device_info()
+        self.sysfs = gpu_sysfs_dir(self.hip.pci_bus_id(self.local_rank))
+        self.ceil = {}                                                  # this box's streams, bytes per second (leg_same_box)
+        self._keep = []
+
+    # -- device memory through the C ABI -----------------------------------------------------------
+    def dev(self, nbytes):
+        return self.codec.alloc(max(int(nbytes), 16))
+
+    def dev_from(self, arr):
+        arr = np.ascontiguousarray(arr)
+        b = self.dev(arr.nbytes)
+        b.upload(arr)
+        return b
+
+    def dev_random_bytes(self, nbytes, seed):
+        """uniform low bytes, sign-extension high bytes (the residual stream seen as bytes): contents never steer a kernel here"""
+        b = self.dev(nbytes)
+        self.codec.fill_residual_dev(b.ptr, nbytes // 2, seed, 0, self.stream)
+        return b
+
+    # -- control plane ------------------------------------------------------------------------------
+    def barrier(self):
+        self.hip.device_sync()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.hip.device_sync()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_ranks(self, value):
+        """the value of every rank, in rank order (control-plane all-gather)"""
+        if self.dist is None:
+            return [value]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64)
+        t[self.rank] = value
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def sum_over_ranks_i64(self, value):
+        if self.dist is None:
+            return int(value)
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
+
+    # -- timing ---------------------------------------------------------------------------------------
+    def timed_leg(self, fn, steps=None, warmup=None):
+        """fn() enqueues one step on the NULL stream.  Returns dict(wall_s, ms_per_step, kernel_ms (trimmed mean), kernel_ms_mean, kernel_ms_median)."""
+        codec, events = self.codec, self.events
+        steps = self.K if steps is None else max(1, min(steps, len(events) - 1))
+        warmup = self.W if warmup is None else warmup
+        self.hip.device_sync()                                          # clock pre-warm: a few launches to size one step, then ~PREWARM_SECONDS of load
+        t0 = time.perf_counter()
+        for _ in range(2):
+            fn()
+        self.hip.device_sync()
+        per = max((time.perf_counter() - t0) / 2, 1e-6)
+        pre = min(2000, int(PREWARM_SECONDS / per))
+        for _ in range(pre + warmup):
+            fn()
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            codec.event_record(events[i], self.stream)
+            fn()
+        codec.event_record(events[steps], self.stream)
+        self.barrier()
+        wall = self.max_over_ranks(time.perf_counter() - t0)
+        d = [codec.event_elapsed_ms(events[i], events[i + 1]) for i in range(steps)]
+        # kernel time like wall time: the slowest rank's (every rank runs the same launches on its own shard)
+        trim_all = self.all_ranks(trimmed_mean(d))
+        return {"wall_s": wall, "steps": steps, "ms_per_step": wall / steps * 1e3, "kernel_ms": max(trim_all),
+                "kernel_ms_mean": max(self.all_ranks(sum(d) / steps)), "kernel_ms_median": max(self.all_ranks(statistics.median(d))),
+                "kernel_ms_by_rank": trim_all if self.world > 1 else None, "clock_prewarm_launches": pre}
+
+    def rate(self, leg, units_per_step):
+        return self.world * units_per_step * leg["steps"] / leg["wall_s"]
+
+    def of_box(self, achieved_bytes_per_s, kind):
+        """fraction of this box's own stream of that kind"""
+        return achieved_bytes_per_s / self.ceil[kind]
+
+    def hbm(self, leg, bytes_per_step, box_kind="copy"):
+        """{hbm_frac, frac_of_same_box_<kind>} of a leg, from the trimmed mean of its launches"""
+        achieved = bytes_per_step / (leg["kernel_ms"] * 1e-3)
+        return {"hbm_frac": achieved / HBM_PEAK_BYTES_PER_S, "frac_of_same_box_%s" % box_kind: self.of_box(achieved, box_kind)}
+
+    def roofline(self, leg, bytes_per_unit, n_units, traffic=None, traffic_source=None, box_kind="copy"):
+        per_launch = bytes_per_unit * n_units
+        achieved = per_launch / (leg["kernel_ms"] * 1e-3)
+        return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_BYTES_PER_S, "frac_of_same_box_%s" % box_kind: self.of_box(achieved, box_kind),
+                "traffic": traffic, "traffic_source": traffic_source,
+                "kernel_ms_per_launch": leg["kernel_ms"], "kernel_ms_mean": leg["kernel_ms_mean"], "kernel_ms_median": leg["kernel_ms_median"],
+                "kernel_ms_per_launch_is": "10 % trimmed mean of the HIP-event durations of the timed launches (events on the launching stream); with several ranks the slowest rank's",
+                "frac_by_rank": [per_launch / (m * 1e-3) / HBM_PEAK_BYTES_PER_S for m in leg["kernel_ms_by_rank"]] if leg.get("kernel_ms_by_rank") else None,
+                "frac_at_mean": per_launch / (leg["kernel_ms_mean"] * 1e-3) / HBM_PEAK_BYTES_PER_S,
+                "frac_at_median": per_launch / (leg["kernel_ms_median"] * 1e-3) / HBM_PEAK_BYTES_PER_S,
+                "algorithmic_bytes_per_launch": per_launch}
+
+    @staticmethod
+    def brief(leg):
+        return {k: leg[k] for k in ("ms_per_step", "kernel_ms", "kernel_ms_mean", "kernel_ms_median")}
+
+    def same_on_device(self, a, b, nbytes, chunk=256 << 20):
+        """two device buffers hold the same bytes (downloaded in chunks and compared on the host)"""
+        for off in range(0, nbytes, chunk):
+            n = min(chunk, nbytes - off)
+            ha, hb = np.empty(n, np.uint8), np.empty(n, np.uint8)
+            self.codec._check(self.codec.L.xHipMemcpyD2H(self.codec.ctx, ha.ctypes.data, a.ptr + off, n), "xHipMemcpyD2H")
+            self.codec._check(self.codec.L.xHipMemcpyD2H(self.codec.ctx, hb.ctypes.data, b.ptr + off, n), "xHipMemcpyD2H")
+            if not np.array_equal(ha, hb):
+                return False
+        return True
+
+
+# ------------------------------------------------------------------------------------------------
+# the legs: each returns its sub-dict of the line
+# ------------------------------------------------------------------------------------------------
+def leg_same_box(b, x, z):
+    """What THIS box's memory system gives the streaming launch shapes, with no arithmetic (xHipMemCeilingDev): the same-run reference
+    every HBM-bound leg is also expressed in, because boxes of the pool differ by 3-10 % in what a plain stream reaches."""
+    ceil_bytes = b.n_dct * 2048
+    for kind, name, moved in ((0, "copy", 2 * ceil_bytes), (1, "read", ceil_bytes), (3, "read_probe", ceil_bytes), (2, "write", ceil_bytes)):
+        leg = b.timed_leg(lambda k=kind: b.codec.mem_ceiling_dev(k, x.ptr, z.ptr, ceil_bytes, b.stream), steps=min(b.K, 40), warmup=min(b.W, 10))
+        b.ceil[name] = moved / (leg["kernel_ms"] * 1e-3)
+    return {"copy_TBps": b.ceil["copy"] / 1e12, "read_TBps": b.ceil["read"] / 1e12, "read_no_store_TBps": b.ceil["read_probe"] / 1e12,
+            "write_TBps": b.ceil["write"] / 1e12,
+            "how": "xHipMemCeilingDev on the headline input / output buffers (%d MiB), trimmed mean of the timed launches' HIP-event durations, slowest rank: "
+                   "nontemporal 16 B/lane streams in the launch shape that measured fastest for each (copy = the transform kernels' pattern, read = one XOR "
+                   "checksum per 2 KiB, read_no_store = the same loads with nothing flowing back, write = the intra predictor's pattern)" % (ceil_bytes >> 20)}
+
+
+def traffic_of_headline(b):
+    """(pmc dict, source text): HBM bytes per launch from the counters -- measured live at N = 1, else replayed from profiles/traffic.json"""
+    pmc, pmc_src = {}, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and b.n_dct == DCT_BLOCKS_PER_GPU and b.n_satd == SATD_BLOCKS_PER_GPU:
+        try:
+            pmc = json.load(open(tpath))
+            pmc_src = "replayed from %s (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command); not measured in this run" % pmc.get("_source", "profiles/traffic.json")
+        except Exception:
+            pmc = {}
+    if b.world == 1 and not b.args.no_live_traffic:
+        b.hip.device_sync()
+        live, how = measure_traffic_live(b.n_dct)
+        if live is not None:
+            pmc = dict(pmc, dct32_fwd_bytes_per_launch=live)
+            pmc_src = how
+        elif pmc_src:
+            pmc_src += " (live passes: %s)" % how
+        else:
+            pmc_src = "not measured: " + how
+    return pmc, pmc_src
+
+
+def leg_dct32_inverse_and_fused(b, x, z, pmc, pmc_src):
+    """inverse DCT32 of the headline's coefficients, and coefficients + reconstruction from one pass (6144 B per block)"""
+    n, codec, out = b.n_dct, b.codec, {}
+    r = b.dev(n * 2048)
+    leg = b.timed_leg(lambda: codec.dct32_inv_dev(z.ptr, r.ptr, n, b.stream))
+    xs, rs = x.download(np.int16, 4096 * 1024).astype(np.int32), r.download(np.int16, 4096 * 1024).astype(np.int32)
+    out["dct32_inv"] = dict(value=b.rate(leg, n), unit="blocks/s", **b.brief(leg),
+                            roofline=b.roofline(leg, DCT_BYTES_PER_BLOCK, n, pmc.get("dct32_inv_bytes_per_launch"), pmc_src),
+                            parity="unpinned (no inverse in the reference); bit-exact vs this repo's oracle",
+                            roundtrip_max_abs_err=int(np.abs(rs - xs).max()))
+    z2 = b.dev(n * 2048)
+    leg = b.timed_leg(lambda: codec.dct32_fwd_inv_dev(x.ptr, z2.ptr, r.ptr, n, b.stream))
+    out["dct32_fwd_inv_fused"] = dict(value=b.rate(leg, n), unit="blocks/s", **b.brief(leg), **b.hbm(leg, 6144.0 * n),
+                                      same_bytes_as_two_kernels=b.same_on_device(z2, z, n * 2048),
+                                      note="2 KiB in, 2 + 2 KiB out per block; inverse fed from the forward's registers, inputs by LDS-DMA (DESIGN.md 3.7)")
+    leg = b.timed_leg(lambda: codec.dct32_fwd_inv_dev(x.ptr, 0, r.ptr, n, b.stream), steps=max(4, b.K // 4), warmup=3)
+    out["dct32_fwd_inv_fused"]["reconstruction_only"] = dict(value=b.rate(leg, n), unit="blocks/s", **b.brief(leg), **b.hbm(leg, 4096.0 * n),
+                                                             note="d_coef = NULL: 2 KiB in, 2 KiB out, the natural-orientation pass 2 is skipped")
+    return out
+
+
+def leg_satd(b, pmc, pmc_src):
+    """the 8x8 SATD residual batch (the secondary metric), with the port timed on the host cores at N = 1"""
+    n, codec = b.n_satd, b.codec
+    d, s = b.dev(n * 128), b.dev(n * 4)
+    codec.fill_residual_dev(d.ptr, n * 64, SATD_SEED, b.rank * n * 64, b.stream)
+    leg = b.timed_leg(lambda: codec.satd8x8_dev(d.ptr, s.ptr, n, b.stream))
+    out = dict(value=b.rate(leg, n), unit="blocks/s", blocks_per_gpu=n, **b.brief(leg),
+               roofline=b.roofline(leg, SATD_BYTES_PER_BLOCK, n, pmc.get("satd8x8_bytes_per_launch"), pmc_src, box_kind="read"))
+    if b.rank == 0 and b.world == 1 and not b.args.no_cpu_baseline:
+        ns = min(n, 1 << 23)
+        out["cpu_baseline"] = cpu_baseline_satd(d.download(np.int16, ns * 64).reshape(ns, 64), s.download(np.uint32, ns))
+    return out
+
+
+def leg_motion_search(b, keep):
+    """BASELINE configs[2]: full-search motion estimation of one 3840x2160 luma frame, window +-64 -- SATD, then the SAD metric"""
+    codec = b.codec
+    w, h, rng = 3840, 2160, 64
+    cur_h, refp_h = smooth_frame_pair(w, h, rng, 0x266 + b.rank)           # planted motion (5, -3)
+    cur, refp = b.dev_from(cur_h), b.dev_from(refp_h)
+    rstride = refp_h.shape[1]
+    nb = (w // 8) * (h // 8)
+    best = b.dev(nb * 8)
+    origin = refp.ptr + rng * rstride + rng
+    keep.update(cur=cur, refp=refp, best=best, origin=origin, rstride=rstride)
+    ncand = nb * (2 * rng + 1) ** 2
+    me_steps = max(4, b.K // 4)
+    out = {}
+    # VALU floors: 32 x v_sad_u16 (SATD) / 16 x v_sad_u8 (SAD) per 64 candidates, 4 cycles per wave64 instruction (tools/alubench), at the
+    # 2.4 GHz the part is specified for and -- where sysfs shows it -- at the shader clock this box sustained during the leg
+    for key, fn, per64, unit, floor_name, steps in (("satd8x8_me_search", codec.satd_search_dev, 32, "SATD/s", "v_sad_u16", max(me_steps, 40)),
+                                                    ("sad8x8_me_search", codec.sad_search_dev, 16, "SAD/s", "v_sad_u8", max(me_steps, 60))):
+        with SclkSampler(b.sysfs) as clk:
+            leg = b.timed_leg(lambda f=fn: f(cur.ptr, w, origin, rstride, w, h, rng, best.ptr, 0, b.stream), steps=steps, warmup=2)
+        mv = best.download(np.int16, nb * 4).reshape(nb, 4)[:, :2]
+        cycles = ncand / 64 * per64 * 4 / (4 * b.info["cu_count"])
+        sclk = clk.mhz()
+        out[key] = dict(value=b.rate(leg, ncand), unit=unit, ms_per_frame=leg["ms_per_step"], **b.brief(leg), sclk_mhz=sclk,
+                        planted_mv_found_fraction=float(((mv[:, 0] == 5) & (mv[:, 1] == -3)).mean()))
+        out[key]["frac_of_%s_floor" % floor_name] = cycles / 2.4e9 / (leg["kernel_ms"] * 1e-3)
+        out[key]["frac_of_%s_floor_at_sclk" % floor_name] = (cycles / (sclk * 1e6) / (leg["kernel_ms"] * 1e-3)) if sclk else None
+    out["satd8x8_me_search"].update(
+        frame="%dx%d luma, 8x8 blocks, window +-%d (%d candidates per block)" % (w, h, rng, (2 * rng + 1) ** 2),
+        bound="VALU issue (v_sad_u16), not HBM: ~18 MB of compulsory traffic per frame",
+        parity="per-candidate cost pinned by satd8x8 (src_tb/satd.c); harness (order, tie-break, padding) unpinned")
+    out["sad8x8_me_search"]["parity"] = "metric = sad() of riscv/programs/benchmarks/sad/sad.c at n = 8; harness unpinned, as for the SATD search"
+    return out
+
+
+def leg_transform_set(b, x):
+    """BASELINE configs[3]: the mixed transform set (DCT-II 4..32 + closed-form DST-VII 4/8/16), 2 GiB of residual per class,
+    and the CTU-ordered mixed buffer in one launch"""
+    codec, n_dct = b.codec, b.n_dct
+    zt = b.dev(n_dct * 2048)                                            # own output buffer: z still holds the headline leg's result
+    short = max(4, b.K // 4)
+    ts = {}
+    for ttype, tname, inverse in ((0, "dct2", False), (1, "dst7", False), (0, "dct2_inv", True), (1, "dst7_inv", True)):
+        for n in (4, 8, 16):
+            nblk = (n_dct * 1024) // (n * n)
+            call = codec.transform_inv_dev if inverse else codec.transform_fwd_dev
+            leg = b.timed_leg(lambda c=call, tt=ttype, nn=n, cnt=nblk: c(tt, nn, x.ptr, zt.ptr, cnt, 0, b.stream), steps=short, warmup=3)
+            ts["%s_%dx%d" % (tname, n, n)] = dict(value=b.rate(leg, nblk), unit="blocks/s", **b.hbm(leg, 4.0 * n * n * nblk), **b.brief(leg))
+    # per-CTU mixed batch: every 64x64 CTU's 32x32 quadrants cycle through the seven (type, size) classes; every quadrant is a tile
+    # with its own class byte, the whole buffer is ONE launch (xTransformTilesDev)
+    n_ctu = (n_dct * 1024) // 4096
+    q = np.arange(n_ctu * 4, dtype=np.int64)
+    tile_cls = b.dev_from(np.array([3, 2, 6, 1, 5, 0, 4], np.uint8)[(q + q // 4) % 7])   # kinds -> type*4 + log2N-2
+    per_ctu = {"layout": "64x64 CTUs whose 32x32 quadrants cycle through the seven classes (DCT-II 32/16/8/4, DST-VII 16/8/4), "
+                         "TUs of a quadrant contiguous", "ctus": n_ctu}
+    for inv_flag, name in ((0, "per_ctu_one_launch"), (1, "per_ctu_one_launch_inverse")):
+        leg = b.timed_leg(lambda f=inv_flag: codec.transform_tiles_dev(f, x.ptr, zt.ptr, n_ctu * 4, 0, tile_cls.ptr, b.stream), steps=short, warmup=3)
+        per_ctu[name] = dict(value=b.rate(leg, n_ctu), unit="CTUs/s", **b.hbm(leg, 4.0 * n_ctu * 4096), **b.brief(leg))
+    return {"classes": ts, "per_ctu_mixed": per_ctu, "parity": "unpinned upstream except DCT-II 32; bit-exact vs this repo's oracle",
+            "note": "4*N*N algorithmic bytes per block; hbm_frac from the trimmed mean of the timed launches' HIP-event durations; the seven-calls-over-offset-"
+                    "tables form of the mixed buffer (rounds 1-4: 0.59 of 8 TB/s, superseded by the one-launch call) is still tested, no longer benched"}
+
+
+def leg_fused_from_tiles(b):
+    """Tiled cur / pred frames -> coefficients / costs, residual never in HBM, next to the two-kernel paths.  32768^2 luma: exactly 2^20
+    DCT32 blocks and 2^24 SATD blocks, i.e. the two-kernel legs launch the headline kernels at the headline sizes."""
+    codec = b.codec
+    fw, fh = 32768, 32768
+    ntile = (fw // 16) * (fh // 16)
+    tcur, tpred = b.dev_random_bytes(ntile * 512, 0x266), b.dev_random_bytes(ntile * 512, 0x268)
+    fcoef, fcost, fres = b.dev(fw * fh * 2), b.dev(fw * fh // 64 * 4), b.dev(fw * fh * 2)
+    short = max(4, b.K // 4)
+    fused = {}
+    legs = (("dct32_from_tiles", fw * fh // 1024, 4096, lambda: codec.dct32_fwd_from_tiles_dev(tcur.ptr, tpred.ptr, fw, fh, fcoef.ptr, b.stream)),
+            ("dct32_residual_then_transform", fw * fh // 1024, None,
+             lambda: (codec.residual_luma_dev(tcur.ptr, tpred.ptr, fw, fh, 32, fres.ptr, b.stream), codec.dct32_fwd_dev(fres.ptr, fcoef.ptr, fw * fh // 1024, b.stream))),
+            ("satd8x8_from_tiles", fw * fh // 64, 132, lambda: codec.satd8x8_from_tiles_dev(tcur.ptr, tpred.ptr, fw, fh, fcost.ptr, b.stream)),
+            ("satd8x8_residual_then_cost", fw * fh // 64, None,
+             lambda: (codec.residual_luma_dev(tcur.ptr, tpred.ptr, fw, fh, 8, fres.ptr, b.stream), codec.satd8x8_dev(fres.ptr, fcost.ptr, fw * fh // 64, b.stream))))
+    for name, units, bytes_per_unit, fn in legs:
+        leg = b.timed_leg(fn, steps=short, warmup=3)
+        fused[name] = dict(value=b.rate(leg, units), unit="blocks/s", **b.brief(leg))
+        if bytes_per_unit:
+            fused[name].update(b.hbm(leg, bytes_per_unit * units, "read" if name.startswith("satd") else "copy"))
+    fused["note"] = ("%dx%d tiled frame pair (x266.cpp ref_block_t); fused kernels are bit-identical to the two-kernel paths "
+                     "listed next to them (tests/test_gpu_tiles.py)" % (fw, fh))
+    return fused
+
+
+def leg_front_end_and_sad(b):
+    """frame container conversion, residual formation, SAD -- pure data movement, HBM-bound"""
+    codec = b.codec
+    fw2, fh2 = 16384, 16384                                              # 256 Mi luma samples
+    npx = fw2 * fh2
+    ypl = b.dev_random_bytes(npx, 0x77 + b.rank)
+    upl, vpl = b.dev_random_bytes(npx // 4, 0x78), b.dev_random_bytes(npx // 4, 0x79)
+    t_a, t_b = b.dev_random_bytes(npx * 2, 0x7a), b.dev_random_bytes(npx * 2, 0x7b)   # 512-byte tiles: 2 bytes per luma sample
+    res2, sad_o = b.dev(npx * 2), b.dev(npx // 64 * 4)
+    short = max(4, b.K // 4)
+    front = {}
+    for name, nbytes, fn in (
+            ("conv_input_fmt", 3.0 * npx, lambda: codec.conv_input_fmt_dev(t_a.ptr, ypl.ptr, upl.ptr, vpl.ptr, fw2, fw2, fh2, b.stream)),
+            ("conv_output_420", 3.0 * npx, lambda: codec.conv_output_420_dev(t_a.ptr, ypl.ptr, fw2, upl.ptr, vpl.ptr, fw2 // 2, fw2, fh2, b.stream)),
+            ("residual_luma_32", 4.0 * npx, lambda: codec.residual_luma_dev(t_a.ptr, t_b.ptr, fw2, fh2, 32, res2.ptr, b.stream)),
+            ("sad_8x8", 2.0 * npx + 4.0 * (npx // 64), lambda: codec.sad_dev(8, ypl.ptr, t_b.ptr, sad_o.ptr, npx // 64, b.stream)),
+            ("sad_16x16", 2.0 * npx + 4.0 * (npx // 256), lambda: codec.sad_dev(16, ypl.ptr, t_b.ptr, sad_o.ptr, npx // 256, b.stream)),
+            ("sad_64x64", 2.0 * npx + 4.0 * (npx // 4096), lambda: codec.sad_dev(64, ypl.ptr, t_b.ptr, sad_o.ptr, npx // 4096, b.stream))):
+        leg = b.timed_leg(fn, steps=short, warmup=3)
+        front[name] = dict(GBps=b.world * nbytes * leg["steps"] / leg["wall_s"] / 1e9, **b.hbm(leg, nbytes, "read" if name.startswith("sad") else "copy"),
+                           samples_per_s=b.world * npx * leg["steps"] / leg["wall_s"], **b.brief(leg))
+    front["note"] = ("%dx%d frame; bytes = planes read + tile bytes written (conv), luma of both tile frames + int16 residual "
+                     "(residual), both blocks + 4-byte result (sad)" % (fw2, fh2))
+    return front
+
+
+def leg_intra(b):
+    """32x32 intra prediction, mode decision, and prediction -> residual -> DCT32 in one kernel (HEVC 35 modes; parity unpinned upstream)"""
+    codec = b.codec
+    n_sets = 59918                                                       # x 35 modes = 2 GiB of predictions
+    rs = np.random.RandomState(0x32 + b.rank)
+    refs_t = b.dev_from(rs.randint(0, 256, (n_sets, 144)).astype(np.uint8))
+    modes_t = b.dev_from(np.tile(np.arange(35, dtype=np.uint8), n_sets))
+    index_t = b.dev_from(np.repeat(np.arange(n_sets, dtype=np.int32), 35))
+    pred_t = b.dev(n_sets * 35 * 1024)
+    n_dec = min(1 << 17, n_sets)
+    src_t = b.dev_random_bytes(n_dec * 1024, 0x33)
+    cost_t, bestm_t = b.dev(n_dec * 35 * 4), b.dev(n_dec)
+    short = max(4, b.K // 4)
+    intra = {}
+    leg = b.timed_leg(lambda: codec.intra32_predict_dev(refs_t.ptr, modes_t.ptr, index_t.ptr, pred_t.ptr, n_sets * 35, b.stream), steps=short, warmup=3)
+    written = 1024.0 * n_sets * 35 / (leg["kernel_ms"] * 1e-3)
+    intra["predict"] = dict(value=b.rate(leg, n_sets * 35), unit="predictions/s", written_hbm_frac=written / HBM_PEAK_BYTES_PER_S,
+                            frac_of_same_box_write=b.of_box(written, "write"), **b.brief(leg))
+    leg = b.timed_leg(lambda: codec.intra32_costs_dev(refs_t.ptr, src_t.ptr, cost_t.ptr, bestm_t.ptr, n_dec, b.stream), steps=short, warmup=3)
+    intra["decide_35_modes"] = dict(value=b.rate(leg, n_dec), unit="blocks/s", satd8x8_per_s=b.rate(leg, n_dec) * 35 * 16, **b.brief(leg))
+    if hasattr(codec, "intra32_residual_dct32_dev"):
+        # the encoder loop's form: the chosen mode's prediction never reaches HBM (1 KiB of source + 144 B of references in, 2 KiB of coefficients out)
+        n_blk = min(1 << 20, n_sets * 35)
+        src_b, coef_b = b.dev_random_bytes(n_blk * 1024, 0x34), b.dev(n_blk * 2048)
+        leg = b.timed_leg(lambda: codec.intra32_residual_dct32_dev(refs_t.ptr, modes_t.ptr, index_t.ptr, src_b.ptr, coef_b.ptr, n_blk, b.stream), steps=short, warmup=3)
+        intra["predict_residual_dct32"] = dict(value=b.rate(leg, n_blk), unit="blocks/s", **b.hbm(leg, 3072.0 * n_blk), **b.brief(leg),
+                                               note="xIntra32ResidualDct32Dev: predict (given mode) -> src - pred -> forward DCT32 in one kernel; 1 KiB in + 2 KiB out per block")
+    intra["parity"] = "unpinned upstream (src/mkIntra32-wip.bsv is a sketch without a model); bit-exact vs this repo's oracle"
+    return intra
+
+
+def leg_host_api(b, n):
+    """The literal drop-in path: xDct32FwdBatch on n blocks from pageable and from pinned host buffers (what INTEGRATION.md section 2 tells an
+    x266.cpp maintainer to call, src/x266.cpp:526-555), next to what the link itself gives (plain copies).  PCIe-inclusive -- never `value`."""
+    codec, hip = b.codec, b.hip
     nbytes = n * 2048
-    out = {"blocks": n, "MiB_each_way": nbytes >> 20, "pcie_link": pcie_link_facts(torch)}
+    out = {"blocks": n, "MiB_each_way": nbytes >> 20, "pcie_link": pcie_link_facts(b.sysfs)}
 
     def best_of(fn, reps=4):
         best = 1e9
         for _ in range(reps):
-            torch.cuda.synchronize()
+            hip.device_sync()
             t0 = time.perf_counter()
             fn()
-            torch.cuda.synchronize()
+            hip.device_sync()
             best = min(best, time.perf_counter() - t0)
         return best
-    hp_in, hp_out = torch.empty(nbytes, dtype=torch.uint8).pin_memory(), torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-    d_a, d_b = torch.empty(nbytes, dtype=torch.uint8, device="cuda"), torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    streams = [torch.cuda.Stream() for _ in range(4)]
+    hp_in, hp_out = codec.host_alloc(nbytes, np.uint8), codec.host_alloc(nbytes, np.uint8)
+    d_a, d_b = b.dev(nbytes), b.dev(nbytes)
+    streams = [hip.stream_create() for _ in range(4)]
+    H2D, D2H = 1, 2                                                      # hipMemcpyHostToDevice / DeviceToHost
 
     def both(s1, s2):
-        with torch.cuda.stream(s1):
-            d_a.copy_(hp_in, non_blocking=True)
-        with torch.cuda.stream(s2):
-            hp_out.copy_(d_b, non_blocking=True)
+        hip.memcpy_async(d_a.ptr, hp_in.ctypes.data, nbytes, H2D, s1)
+        hip.memcpy_async(hp_out.ctypes.data, d_b.ptr, nbytes, D2H, s2)
     # HIP multiplexes streams onto a few hardware queues; two streams that land on the same one serialise their copies. The link's
     # two-way rate is what the best of a few stream pairs reaches.
-    two_way = max(nbytes / best_of(lambda a=a, b=b: both(a, b), reps=2) / 1e9 for a, b in ((streams[0], streams[1]), (streams[0], streams[2]),
-                                                                                              (streams[1], streams[3]), (streams[2], streams[3])))
-    out["link_GBps"] = {"h2d_alone": nbytes / best_of(lambda: d_a.copy_(hp_in, non_blocking=True)) / 1e9,
-                        "d2h_alone": nbytes / best_of(lambda: hp_out.copy_(d_b, non_blocking=True)) / 1e9,
+    two_way = max(nbytes / best_of(lambda a=a, c=c: both(streams[a], streams[c]), reps=2) / 1e9 for a, c in ((0, 1), (0, 2), (1, 3), (2, 3)))
+    out["link_GBps"] = {"h2d_alone": nbytes / best_of(lambda: hip.memcpy_async(d_a.ptr, hp_in.ctypes.data, nbytes, H2D, streams[0])) / 1e9,
+                        "d2h_alone": nbytes / best_of(lambda: hip.memcpy_async(hp_out.ctypes.data, d_b.ptr, nbytes, D2H, streams[1])) / 1e9,
                         "each_way_both_directions_at_once": two_way,
-                        "how": "one plain %d MiB copy from / to pinned memory per direction (torch); two-way: best of four stream pairs" % (nbytes >> 20)}
+                        "how": "one plain %d MiB hipMemcpyAsync from / to pinned memory per direction; two-way: best of four stream pairs" % (nbytes >> 20)}
+    for s in streams:
+        hip.lib.hipStreamDestroy(s)
     del hp_in, hp_out, d_a, d_b
-    x_dev = torch.empty(n * 1024, dtype=torch.int16, device="cuda")
-    codec.fill_residual_dev(x_dev.data_ptr(), n * 1024, DCT_SEED, 0, 0)
-    torch.cuda.synchronize()
-    xh = x_dev.cpu().numpy().reshape(n, 1024)                           # pageable, touched
+    x_dev = b.dev(nbytes)
+    codec.fill_residual_dev(x_dev.ptr, n * 1024, DCT_SEED, 0, 0)
+    xh = x_dev.download(np.int16, n * 1024).reshape(n, 1024)            # pageable, touched
     zh = np.ones_like(xh)
-    P = ctypes.c_void_p
 
     def call(i, o):
         rc = codec.L.xDct32FwdBatch(codec.ctx, P(i), P(o), n)
@@ -440,12 +881,201 @@ def host_api_leg(codec, torch, n):
     xp[:] = xh
     dt = best_of(lambda: call(xp.ctypes.data, zp.ctypes.data))
     out["pinned"] = {"blocks_per_s": n / dt, "GBps_each_way": nbytes / dt / 1e9, "ms": dt * 1e3, "same_result_as_pageable": bool(np.array_equal(zp, zh))}
-    both_rate = out["link_GBps"]["each_way_both_directions_at_once"]
-    out["pinned"]["frac_of_link_both_directions"] = out["pinned"]["GBps_each_way"] / both_rate
-    out["pageable"]["frac_of_link_both_directions"] = out["pageable"]["GBps_each_way"] / both_rate
+    for k in ("pinned", "pageable"):
+        out[k]["frac_of_link_both_directions"] = out[k]["GBps_each_way"] / two_way
     out["note"] = ("host pointers in and out, best of 4 calls: 16 MiB chunks over three staging slots, uploads + kernels issued by the calling thread, "
                    "downloads by a helper thread (a pageable copy blocks its issuing thread); inputs are NOT resident, so this is never `value`")
     return out
+
+
+def leg_node_stream8k(b, node, also):
+    """BASELINE configs[4]: the 7680x4320 frame stream through the node layer (one RCCL group per step with N > 1; in place with one rank)"""
+    codec, rank, world = b.codec, b.rank, b.world
+    fw8, fh8 = 7680, 4320
+    nd8, ns8 = (fw8 // 32) * (fh8 // 32), (fw8 // 8) * (fh8 // 8)
+    IN_RING, OUT_RING = 4, 5                                             # X266_STREAM_IN_RING / X266_STREAM_OUT_RING (include/x266hip.h)
+    fin = fout = None
+    if rank == 0:
+        fin = [(b.dev(nd8 * 2048), b.dev(ns8 * 128)) for _ in range(IN_RING)]
+        fout = [(b.dev(nd8 * 2048), b.dev(ns8 * 4)) for _ in range(OUT_RING)]
+        for i, (a, d) in enumerate(fin):
+            codec.fill_residual_dev(a.ptr, nd8 * 1024, DCT_SEED, i * 100000007, b.stream)
+            codec.fill_residual_dev(d.ptr, ns8 * 64, SATD_SEED, i * 100000007, b.stream)
+    b.hip.device_sync()
+    st8 = node.frame_stream(fw8, fh8)
+    # one foreign call per frame: the argument arrays of every (input ring, output ring) pairing are built once
+    prep8 = ([st8.prepare([fin[i % IN_RING][0].ptr, fin[i % IN_RING][1].ptr], [fout[i % OUT_RING][0].ptr, fout[i % OUT_RING][1].ptr])
+              for i in range(IN_RING * OUT_RING)] if rank == 0 else None)
+    raw_next = node.L.xNodeStreamNextSlotStream
+
+    def push8(f):
+        if rank == 0:                                                    # resident inputs: "produced" on the frame's own slot stream, so the push needs no producer event
+            st8.push_prepared(prep8[f % (IN_RING * OUT_RING)], raw_next(st8.s))
+        else:
+            st8.push()
+    F = b.args.stream8k
+    # clocks: ~0.1 s of frames before the timed ones (200 frames are 7 ms); a fixed count, the same on every rank
+    for f in range(2500 if world == 1 else 64):
+        push8(f)
+    st8.flush()
+    b.barrier()
+    t0 = time.perf_counter()
+    for f in range(F):
+        push8(f)
+    st8.flush()
+    b.barrier()
+    wall8 = b.max_over_ranks(time.perf_counter() - t0)
+    exact8 = kernel_us = None
+    if rank == 0:                                                        # last frame against the plain single-device calls
+        a, d = fin[(F - 1) % IN_RING]
+        c, e = fout[(F - 1) % OUT_RING]
+        c1, e1 = b.dev(nd8 * 2048), b.dev(ns8 * 4)
+        codec.dct32_fwd_dev(a.ptr, c1.ptr, nd8, b.stream)
+        codec.satd8x8_dev(d.ptr, e1.ptr, ns8, b.stream)
+        b.hip.device_sync()
+        exact8 = b.same_on_device(c, c1, nd8 * 2048) and b.same_on_device(e, e1, ns8 * 4)
+    if rank == 0 and world == 1:                                         # what the frame's one launch costs by itself, back to back on one stream
+        a, d = fin[0]
+        c, e = fout[0]
+        for phase in (0, 1):
+            for _ in range(200):
+                codec.frame_lanes_dev(a.ptr, c.ptr, nd8, d.ptr, e.ptr, ns8, b.stream)
+            codec.event_record(b.events[phase], b.stream)
+        kernel_us = codec.event_elapsed_ms(b.events[0], b.events[1]) / 200 * 1e3
+    link_bytes = (nd8 * 2048 + ns8 * 128) / world                        # one peer's input shard of a frame, over one link
+    also["stream8k"] = {
+        "frames_per_s": F / wall8, "ms_per_frame": wall8 / F * 1e3, "frames": F,
+        "kernel_us": kernel_us, "launches_per_frame_and_rank": 1,
+        "kernel_share_of_frame_time": (kernel_us * 1e-6 / (wall8 / F)) if kernel_us else None,
+        "dct32_blocks_per_s": nd8 * F / wall8, "satd8x8_blocks_per_s": ns8 * F / wall8,
+        "frame": "7680x4320: %d DCT32 blocks (66.4 MB) + %d SATD blocks (66.4 MB)" % (nd8, ns8),
+        "path": "C ABI node layer (xNodeStreamPush / Flush): per step one RCCL group carries frame t's shards root -> peers and "
+                "frame t-2's coefficients and costs peers -> root on a communication stream while every rank transforms frame t"
+                if world > 1 else "C ABI node layer, one rank: the root transforms the frame in place, no transfer (RCCL only in the self-test)",
+        "bit_exact_vs_single_device": exact8,
+        "link_bound_frames_per_s": (XGMI_LINK_BYTES_PER_S / link_bytes) if world > 1 else None,
+        "link_bound": "each peer's input shard crosses ONE xGMI link (~153 GB/s per direction): <= 7.5e7 DCT32 blocks/s per peer (SURVEY.md 8e)"}
+    st8.close()
+
+
+def leg_node_batch_and_search(b, node, also, x, z, me):
+    """one resident batch scattered and gathered (SURVEY 8e "end-to-end scatter -> compute -> gather"), and the sharded motion search"""
+    from x266_amd.node import OP_DCT32_FWD
+    rank, world = b.rank, b.world
+    nsg = min(1 << 18, b.n_dct)
+    pin, pout = (x.ptr, z.ptr) if rank == 0 else (0, 0)
+    b.hip.device_sync()
+    node.batch_scatter_gather(OP_DCT32_FWD, pin, pout, nsg, 0)
+    b.barrier()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        node.batch_scatter_gather(OP_DCT32_FWD, pin, pout, nsg, 0)
+    b.barrier()
+    wall_sg = b.max_over_ranks(time.perf_counter() - t0) / 4
+    also["dct32_scatter_gather"] = {"value": nsg / wall_sg, "unit": "blocks/s", "blocks": nsg,
+                                    "link_bound_blocks_per_s": (world * XGMI_LINK_BYTES_PER_S / 2048.0) if world > 1 else None,
+                                    "link_bound": "every peer's shard crosses ONE xGMI link (~153 GB/s per direction, inputs one way, results the other): "
+                                                  "<= 153e9 / 2048 = 7.5e7 blocks/s per peer, i.e. world x 7.5e7 with the root computing its own shard in place"
+                                                  if world > 1 else None,
+                                    "note": "root-resident batch cut into chunks (8 MiB of input per rank), pipelined through the node stream "
+                                            "(xNodeBatchScatterGather); at N = 1 no transfer"}
+    if not me:
+        return
+    # sharded motion search: stripes + halo from the root, records back (xNodeSatd8x8Search)
+    nstr = max(world, 1)
+    cur, origin, best = (me["cur"].ptr, me["origin"], me["best"].ptr) if rank == 0 else (0, 0, 0)
+    nb8 = (3840 // 8) * (2160 // 8) * 8
+
+    def search():
+        node.satd_search(cur, 3840, origin, me["rstride"], 3840, 2160, 64, nstr, best)
+    search()
+    ref_best = me["best"].download(np.uint8, nb8) if rank == 0 else None
+    b.barrier()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        search()
+    b.barrier()
+    wall_ms = b.max_over_ranks(time.perf_counter() - t0) / 3
+    same = None
+    if rank == 0:
+        b.codec.satd_search_dev(cur, 3840, origin, me["rstride"], 3840, 2160, 64, best, 0, b.stream)
+        same = bool(np.array_equal(me["best"].download(np.uint8, nb8), ref_best))
+    also["satd8x8_me_search_sharded"] = {"ms_per_frame": wall_ms * 1e3, "stripes": nstr, "identical_to_single_device": same,
+                                         "note": "synchronous call incl. scatter of cur stripes + reference halo and gather of (mv, cost)"}
+
+
+def node_legs(b, also, x, z, me):
+    """The node layer of the C ABI: BASELINE configs[4] and the other end-to-end scatter / gather figures -- the only legs that talk RCCL."""
+    from x266_amd.node import Node
+    uid = [Node.unique_id() if b.rank == 0 else None]
+    if b.dist is not None:
+        b.dist.broadcast_object_list(uid, src=0)
+    node = Node.for_rank(b.local_rank, b.rank, b.world, uid[0])      # xHipNodeInitRank: one process per GPU, also at N = 1
+    node.self_test()                                                    # RCCL ring send/recv + all-reduce, checked
+    ver, path = Node.rccl_info()
+    infos = ["%s (version %d)" % (path, ver)]
+    if b.dist is not None:
+        infos = [None] * b.world
+        b.dist.all_gather_object(infos, "%s (version %d)" % (path, ver))
+    also["rccl_by_rank"] = infos                                        # which library each rank's node layer talks to
+    leg_node_stream8k(b, node, also)
+    leg_node_batch_and_search(b, node, also, x, z, me)
+    node.close()
+
+
+def run_node_legs_under_watchdog(b, result, also, x, z, me, json_fd):
+    """A communication hang must not cost the whole line: past --node-timeout seconds rank 0 prints the JSON with what it has
+    (the legs marked as timed out) and every rank leaves."""
+    def node_timed_out():
+        also["node_layer_error"] = "node-layer legs did not finish within %.0f s (RCCL hang?); line printed without them" % b.args.node_timeout
+        if b.rank == 0:
+            result.setdefault("cpu_baseline", None)
+            result["device"] = b.info["name"].strip()
+            os.write(json_fd, (json.dumps(result) + "\n").encode())
+        os._exit(0)
+    watchdog = threading.Timer(b.args.node_timeout, node_timed_out)
+    watchdog.daemon = True
+    watchdog.start()
+    try:
+        node_legs(b, also, x, z, me)
+    except Exception as e:                                              # e.g. RCCL missing: keep the rest of the line
+        also["node_layer_error"] = "%s: %s" % (type(e).__name__, e)
+    watchdog.cancel()
+
+
+def spawn_ranks(args):
+    """plain `python bench.py --gpus N`: become the launcher -- the command line the driver uses, one rank per GPU; torchrun picks and
+    HOLDS the rendezvous port itself (--standalone: no bind-close-reuse race); rank 0's JSON line goes to this
+    process's stdout, the exit status is the job's"""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")))
+
+
+def headline(b, x, z, same_box):
+    head = b.timed_leg(lambda: b.codec.dct32_fwd_dev(x.ptr, z.ptr, b.n_dct, b.stream))
+    pmc, pmc_src = traffic_of_headline(b)
+    result = {
+        "metric": "dct32_fwd_blocks_per_s", "value": b.rate(head, b.n_dct), "unit": "blocks/s", "n_gpus": b.world,
+        "steps": b.K, "warmup": b.W, "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: batched 32x32 forward DCT, %d random 9-bit residual blocks per GPU "
+                               "resident in HBM (inverse, fused fwd+inv, 8x8 SATD and the other configs under 'also')" % b.n_dct,
+                   "blocks_per_gpu": b.n_dct, "block_bytes_in_plus_out": DCT_BYTES_PER_BLOCK,
+                   "arithmetic": "int16 data as two int8 planes x int8 coefficients on v_mfma_i32_32x32x32_i8, int32 accumulate",
+                   "sharding": "contiguous shard per rank, no data-path collective",
+                   "clock_prewarm_launches": head["clock_prewarm_launches"],
+                   "timing": "every leg: own clock pre-warm, W warm-up launches, K launches barrier-to-barrier; kernel_ms = 10 % trimmed mean of the HIP-event "
+                             "durations recorded on the launching stream around those same K launches (mean and median next to it)"},
+        "roofline": b.roofline(head, DCT_BYTES_PER_BLOCK, b.n_dct, pmc.get("dct32_fwd_bytes_per_launch"), pmc_src),
+        "hip_runtime": {"version": b.hip.version(), "path": b.hip.paths[0], "copies_in_process": len(loaded_libraries("libamdhip64.so")),
+                        "torch_imported": "torch" in sys.modules},
+    }
+    result["roofline"]["same_box"] = same_box
+    return result, pmc, pmc_src
 
 
 def main():
@@ -455,604 +1085,50 @@ def main():
         traffic_child(args)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: become the launcher -- the same command line the driver uses, one rank per GPU;
-        # rank 0's JSON line goes to this process's stdout, the exit status is the job's
-        import socket
-        import subprocess
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.stdout.flush()
-        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")))
+        spawn_ranks(args)
     # stdout carries exactly ONE line, the JSON: libraries that chat on stdout (RCCL prints a version banner
     # when a communicator is created) are sent to stderr for the duration of the run
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    import torch
-    import x266_amd
-    from x266_amd.node import Node, OP_DCT32_FWD
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch one rank per GPU (or run without torch.distributed.run: bench.py spawns its own ranks)" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: libx266hip has no CPU path")
-    # Test hook (never set by the driver): X266_BENCH_SHARE_GPU=1 lets several ranks share the visible
-    # GPUs with the control-plane collectives on gloo, so that the N > 1 code path -- shard offsets,
-    # max-over-ranks timing, checksum reduction -- can be exercised on a one-GPU box.  RCCL refuses two ranks on
-    # one device, so the node-layer legs run there only when X266HIP_RCCL_LIB names the tests' RCCL model.
-    share = os.environ.get("X266_BENCH_SHARE_GPU") == "1"
-    if share:
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dist = None
-    ctrl = "cuda"
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo")
-            ctrl = "cpu"
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    codec = x266_amd.Codec(local_rank)
-    info_cu = codec.device_info()["cu_count"]
-    stream = torch.cuda.current_stream().cuda_stream           # the stream every launch and event uses
-    n_dct, n_satd = args.dct_blocks, args.satd_blocks
-    K, W = args.steps, args.warmup
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def max_over_ranks(seconds):
-        if dist is None:
-            return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device=ctrl)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def all_ranks(value):
-        """the value of every rank, in rank order (control-plane all-gather)"""
-        if dist is None:
-            return [value]
-        t = torch.zeros(world, dtype=torch.float64, device=ctrl)
-        t[rank] = value
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return [float(v) for v in t.tolist()]
-
-    events = [codec.event_create() for _ in range(max(K, 64) + 1)]
-
-    def timed_leg(fn, steps=None, warmup=None):
-        """fn() enqueues one step on `stream`.  Returns dict(wall_s, ms_per_step, kernel_ms_mean, kernel_ms_median)."""
-        steps = K if steps is None else max(1, min(steps, len(events) - 1))
-        warmup = W if warmup is None else warmup
-        # clock pre-warm: a few launches to size one step, then ~PREWARM_SECONDS of load
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            fn()
-        torch.cuda.synchronize()
-        per = max((time.perf_counter() - t0) / 2, 1e-6)
-        pre = min(2000, int(PREWARM_SECONDS / per))
-        for _ in range(pre + warmup):
-            fn()
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            codec.event_record(events[i], stream)
-            fn()
-        codec.event_record(events[steps], stream)
-        barrier()
-        wall = max_over_ranks(time.perf_counter() - t0)
-        d = [codec.event_elapsed_ms(events[i], events[i + 1]) for i in range(steps)]
-        # kernel time like wall time: the slowest rank's (every rank runs the same launches on its own shard)
-        mean_all = all_ranks(sum(d) / steps)
-        med_all = all_ranks(statistics.median(d))
-        return {"wall_s": wall, "steps": steps, "ms_per_step": wall / steps * 1e3, "kernel_ms_mean": max(mean_all),
-                "kernel_ms_median": max(med_all), "kernel_ms_mean_by_rank": mean_all if world > 1 else None, "clock_prewarm_launches": pre}
-
-    def rate(leg, units_per_step):
-        return world * units_per_step * leg["steps"] / leg["wall_s"]
-
-    def hbm(leg, bytes_per_step):
-        """fraction of the HBM peak from the mean launch duration of the timed launches"""
-        return bytes_per_step / (leg["kernel_ms_mean"] * 1e-3) / HBM_PEAK_BYTES_PER_S
-
-    def roofline(leg, bytes_per_unit, n_units, traffic=None, traffic_source=None, box_kind="copy"):
-        achieved = bytes_per_unit * n_units / (leg["kernel_ms_mean"] * 1e-3)
-        return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_BYTES_PER_S, "frac_of_same_box_%s" % box_kind: of_box(achieved, box_kind),
-                "traffic": traffic, "traffic_source": traffic_source,
-                "kernel_ms_per_launch": leg["kernel_ms_mean"], "kernel_ms_median": leg["kernel_ms_median"],
-                "kernel_ms_per_launch_is": "HIP events on the launching stream around the timed launches; with several ranks the slowest rank's mean",
-                "frac_by_rank": [bytes_per_unit * n_units / (m * 1e-3) / HBM_PEAK_BYTES_PER_S for m in leg["kernel_ms_mean_by_rank"]] if leg.get("kernel_ms_mean_by_rank") else None,
-                "frac_at_median": bytes_per_unit * n_units / (leg["kernel_ms_median"] * 1e-3) / HBM_PEAK_BYTES_PER_S,
-                "algorithmic_bytes_per_launch": bytes_per_unit * n_units}
-
-    def hbm2(leg, bytes_per_step, box_kind="copy"):
-        """{hbm_frac, frac_of_same_box_<kind>} of a leg"""
-        achieved = bytes_per_step / (leg["kernel_ms_mean"] * 1e-3)
-        return {"hbm_frac": achieved / HBM_PEAK_BYTES_PER_S, "frac_of_same_box_%s" % box_kind: of_box(achieved, box_kind)}
-
-    def brief(leg):
-        return {k: leg[k] for k in ("ms_per_step", "kernel_ms_mean", "kernel_ms_median")}
+    b = Bench(args)
+    rank, world, codec = b.rank, b.world, b.codec
 
     # ---- inputs resident in HBM: this rank's slice of the one seeded stream -----------------
-    x = torch.empty(n_dct * 1024, dtype=torch.int16, device="cuda")
-    z = torch.empty_like(x)
-    codec.fill_residual_dev(x.data_ptr(), n_dct * 1024, DCT_SEED, rank * n_dct * 1024, stream)
-    torch.cuda.synchronize()
-
-    # ---- what THIS box's memory system gives the streaming launch shape, with no arithmetic (xHipMemCeilingDev): the same-run
-    # reference every HBM-bound leg is also expressed in, because boxes of the pool differ by 3-10 % in what a plain stream reaches
-    ceil_bytes = n_dct * 2048
-    ceil_legs = {}
-    for kind, name, moved in ((0, "copy", 2 * ceil_bytes), (1, "read", ceil_bytes), (3, "read_probe", ceil_bytes), (2, "write", ceil_bytes)):
-        leg = timed_leg(lambda k=kind: codec.mem_ceiling_dev(k, x.data_ptr(), z.data_ptr(), ceil_bytes, stream), steps=min(K, 40), warmup=min(W, 10))
-        ceil_legs[name] = moved / (leg["kernel_ms_mean"] * 1e-3)
-    same_box = {"copy_TBps": ceil_legs["copy"] / 1e12, "read_TBps": ceil_legs["read"] / 1e12, "read_no_store_TBps": ceil_legs["read_probe"] / 1e12,
-                "write_TBps": ceil_legs["write"] / 1e12,
-                "how": "xHipMemCeilingDev on the headline input / output buffers (%d MiB), HIP-event mean of the timed launches, slowest rank: nontemporal 16 B/lane "
-                       "streams in the launch shape that measured fastest for each (copy = the transform kernels' pattern, read = one XOR checksum per 2 KiB, "
-                       "read_no_store = the same loads with nothing flowing back, write = the intra predictor's pattern)" % (ceil_bytes >> 20)}
-
-    def of_box(achieved_bytes_per_s, kind):
-        """fraction of this box's own stream of that kind"""
-        return achieved_bytes_per_s / ceil_legs[kind]
-
-    head = timed_leg(lambda: codec.dct32_fwd_dev(x.data_ptr(), z.data_ptr(), n_dct, stream))
-    value = rate(head, n_dct)
-
-    # HBM bytes per launch: NOT measured in this run -- replayed from the rocprofv3 PMC passes committed under
-    # profiles/ (same command, same workload size; FETCH_SIZE x2 gfx950 correction applied there), and labelled so.
-    pmc, pmc_src = {}, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and n_dct == DCT_BLOCKS_PER_GPU and n_satd == SATD_BLOCKS_PER_GPU:
-        try:
-            pmc = json.load(open(tpath))
-            pmc_src = "replayed from %s (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command); not measured in this run" % pmc.get("_source", "profiles/traffic.json")
-        except Exception:
-            pmc = {}
-    if world == 1 and not args.no_live_traffic:
-        torch.cuda.synchronize()
-        live, how = measure_traffic_live(n_dct)
-        if live is not None:
-            pmc = dict(pmc, dct32_fwd_bytes_per_launch=live)
-            pmc_src = how
-        elif pmc_src:
-            pmc_src += " (live passes: %s)" % how
-        else:
-            pmc_src = "not measured: " + how
-
-    result = {
-        "metric": "dct32_fwd_blocks_per_s", "value": value, "unit": "blocks/s", "n_gpus": world,
-        "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "i32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: batched 32x32 forward DCT, %d random 9-bit residual blocks per GPU "
-                               "resident in HBM (inverse, fused fwd+inv, 8x8 SATD and the other configs under 'also')" % n_dct,
-                   "blocks_per_gpu": n_dct, "block_bytes_in_plus_out": DCT_BYTES_PER_BLOCK,
-                   "arithmetic": "int16 data as two int8 planes x int8 coefficients on v_mfma_i32_32x32x32_i8, int32 accumulate",
-                   "sharding": "contiguous shard per rank, no data-path collective",
-                   "clock_prewarm_launches": head["clock_prewarm_launches"],
-                   "timing": "every leg: own clock pre-warm, W warm-up launches, K launches barrier-to-barrier; kernel_ms_* from HIP "
-                             "events recorded on the launching stream around those same K launches"},
-        "roofline": roofline(head, DCT_BYTES_PER_BLOCK, n_dct, pmc.get("dct32_fwd_bytes_per_launch"), pmc_src),
-    }
-    result["roofline"]["same_box"] = same_box
-
+    x, z = b.dev(b.n_dct * 2048), b.dev(b.n_dct * 2048)
+    codec.fill_residual_dev(x.ptr, b.n_dct * 1024, DCT_SEED, rank * b.n_dct * 1024, b.stream)
+    b.hip.device_sync()
+    same_box = leg_same_box(b, x, z)
+    result, pmc, pmc_src = headline(b, x, z, same_box)
     # ---- checksum of the forward output across ranks (validates the sharded run) ----------------
-    csum = int(z.view(torch.int16).to(torch.int64).sum().item())
-    if dist is not None:
-        t = torch.tensor([csum], dtype=torch.int64, device=ctrl)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        csum = int(t.item())
-    result["output_checksum_sum_i16"] = csum
+    z_host = z.download(np.int16, b.n_dct * 1024)
+    result["output_checksum_sum_i16"] = b.sum_over_ranks_i64(int(z_host.astype(np.int64).sum()))
 
     if not args.no_also:
-        also = {}
-        # ---- inverse DCT32 ----------------------------------------------------------------------------
-        r = torch.empty_like(x)
-        leg = timed_leg(lambda: codec.dct32_inv_dev(z.data_ptr(), r.data_ptr(), n_dct, stream))
-        also["dct32_inv"] = dict(value=rate(leg, n_dct), unit="blocks/s", **brief(leg),
-                                 roofline=roofline(leg, DCT_BYTES_PER_BLOCK, n_dct, pmc.get("dct32_inv_bytes_per_launch"), pmc_src),
-                                 parity="unpinned (no inverse in the reference); bit-exact vs this repo's oracle")
-        err = (r[: 4096 * 1024].to(torch.int32) - x[: 4096 * 1024].to(torch.int32)).abs().max().item()
-        also["dct32_inv"]["roundtrip_max_abs_err"] = int(err)
-        # ---- fused forward + inverse: coefficients and reconstruction from one pass (6144 B per block)
-        z2 = torch.empty_like(x)
-        leg = timed_leg(lambda: codec.dct32_fwd_inv_dev(x.data_ptr(), z2.data_ptr(), r.data_ptr(), n_dct, stream))
-        also["dct32_fwd_inv_fused"] = dict(value=rate(leg, n_dct), unit="blocks/s", **brief(leg), **hbm2(leg, 6144.0 * n_dct),
-                                           same_bytes_as_two_kernels=bool(torch.equal(z2, z)),
-                                           note="2 KiB in, 2 + 2 KiB out per block; hbm_frac from the HIP-event mean of the timed launches")
-        del r, z2
-        # ---- 8x8 SATD residual batch ----------------------------------------------------------------
-        d = torch.empty(n_satd * 64, dtype=torch.int16, device="cuda")
-        s = torch.empty(n_satd, dtype=torch.int32, device="cuda")
-        codec.fill_residual_dev(d.data_ptr(), n_satd * 64, SATD_SEED, rank * n_satd * 64, stream)
-        leg = timed_leg(lambda: codec.satd8x8_dev(d.data_ptr(), s.data_ptr(), n_satd, stream))
-        also["satd8x8"] = dict(value=rate(leg, n_satd), unit="blocks/s", blocks_per_gpu=n_satd, **brief(leg),
-                               roofline=roofline(leg, SATD_BYTES_PER_BLOCK, n_satd, pmc.get("satd8x8_bytes_per_launch"), pmc_src, box_kind="read"))
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from _util import Oracle
-            orc = Oracle()
-            ns = min(n_satd, 1 << 23)
-            dh = d[: ns * 64].cpu().numpy().reshape(ns, 64)
-            gpu_s = s[:ns].cpu().numpy()
-
-            def satd_work(loc_in, loc_out, cnt):
-                orc.lib.orc_satd8x8_batch_mt(ctypes.c_void_p(loc_in.ctypes.data), ctypes.c_void_p(loc_out.ctypes.data), ctypes.c_size_t(cnt), 1)
-            mk = lambda b, e: (dh[b:e].copy(), np.zeros(e - b, np.uint32))
-            cores_s, _, _, _ = best_thread_count(ns, satd_work, mk)
-            dt, outs, bounds = run_pinned(ns, cores_s, satd_work, mk)
-            also["satd8x8"]["cpu_baseline"] = {
-                "value": ns / dt, "unit": "blocks/s", "cores": cores_s, "kind": "port",
-                "sample": "first %d blocks of the GPU batch, %d pinned threads, pre-touched thread-local buffers" % (ns, cores_s),
-                "gpu_output_bit_exact_vs_cpu": all(np.array_equal(outs[i].astype(np.int32), gpu_s[int(bounds[i]):int(bounds[i + 1])])
-                                                   for i in range(len(outs)))}
-            del dh, gpu_s
-        del d, s
-
-        # ---- BASELINE configs[2]: full-search SATD motion estimation, one 3840x2160 luma frame, window +-64
+        also, me = {}, {}
+        also.update(leg_dct32_inverse_and_fused(b, x, z, pmc, pmc_src))
+        also["satd8x8"] = leg_satd(b, pmc, pmc_src)
         if not args.no_me:
-            w, h, rng = 3840, 2160, 64
-            pad = rng
-            g = torch.Generator(device="cuda")
-            g.manual_seed(0x266 + rank)
-            big = torch.randint(0, 256, (h + 2 * pad + 16, w + 2 * pad + 16), generator=g, device="cuda", dtype=torch.int32)
-            # 5x5 box low-pass so that motion is findable (pooling, not conv: no MIOpen kernel search)
-            sm = torch.nn.functional.avg_pool2d(big.float()[None, None], 5, stride=1, padding=2, count_include_pad=False)[0, 0]
-            sm = ((sm - 128.0) * 3.0 + 128.0).clamp(0, 255).to(torch.uint8)
-            cur = sm[pad + 8:pad + 8 + h, pad + 8:pad + 8 + w].contiguous()
-            refp = sm[8 + 3:8 + 3 + h + 2 * pad, 8 - 5:8 - 5 + w + 2 * pad].contiguous()      # planted motion (5, -3)
-            nb = (w // 8) * (h // 8)
-            best = torch.empty(nb * 2, dtype=torch.int32, device="cuda")
-            origin = refp.data_ptr() + pad * refp.stride(0) + pad
-            ncand = nb * (2 * rng + 1) ** 2
-            me_steps = max(4, K // 4)
-            with SclkSampler(torch) as clk:
-                leg = timed_leg(lambda: codec.satd_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream),
-                                steps=max(me_steps, 40), warmup=2)
-            mv = best.view(torch.int16).view(nb, 4)[:, :2]
-            found = float(((mv[:, 0] == 5) & (mv[:, 1] == -3)).float().mean().item())
-            # VALU floor: 32 x v_sad_u16 (4 cycles per wave64 instruction, tools/alubench) per 64 candidates, at the 2.4 GHz the part is
-            # specified for and -- where sysfs shows it -- at the shader clock this box sustained during the leg
-            cycles = ncand / 64 * 32 * 4 / (4 * info_cu)
-            floor_s = cycles / 2.4e9
-            sclk = clk.mhz()
-            also["satd8x8_me_search"] = dict(
-                value=rate(leg, ncand), unit="SATD/s", ms_per_frame=leg["ms_per_step"], **brief(leg),
-                frame="%dx%d luma, 8x8 blocks, window +-%d (%d candidates per block)" % (w, h, rng, (2 * rng + 1) ** 2),
-                bound="VALU issue (v_sad_u16), not HBM: ~18 MB of compulsory traffic per frame",
-                frac_of_v_sad_u16_floor=floor_s / (leg["kernel_ms_mean"] * 1e-3),
-                sclk_mhz=sclk, frac_of_v_sad_u16_floor_at_sclk=(cycles / (sclk * 1e6) / (leg["kernel_ms_mean"] * 1e-3)) if sclk else None,
-                frac_of_v_sad_u16_floor_wallclock=floor_s / (leg["ms_per_step"] * 1e-3),
-                planted_mv_found_fraction=found,
-                parity="per-candidate cost pinned by satd8x8 (src_tb/satd.c); harness (order, tie-break, padding) unpinned")
-            # the same search with the SAD metric (SURVEY 8 f3)
-            with SclkSampler(torch) as clk:
-                leg = timed_leg(lambda: codec.sad_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), w, h, rng, best.data_ptr(), 0, stream),
-                                steps=max(me_steps, 60), warmup=2)
-            mv = best.view(torch.int16).view(nb, 4)[:, :2]
-            cycles_sad = ncand / 64 * 16 * 4 / (4 * info_cu)
-            floor_sad = cycles_sad / 2.4e9
-            sclk = clk.mhz()
-            also["sad8x8_me_search"] = dict(
-                value=rate(leg, ncand), unit="SAD/s", ms_per_frame=leg["ms_per_step"], **brief(leg),
-                frac_of_v_sad_u8_floor=floor_sad / (leg["kernel_ms_mean"] * 1e-3),
-                sclk_mhz=sclk, frac_of_v_sad_u8_floor_at_sclk=(cycles_sad / (sclk * 1e6) / (leg["kernel_ms_mean"] * 1e-3)) if sclk else None,
-                planted_mv_found_fraction=float(((mv[:, 0] == 5) & (mv[:, 1] == -3)).float().mean().item()),
-                parity="metric = sad() of riscv/programs/benchmarks/sad/sad.c at n = 8; harness unpinned, as for the SATD search")
-            del big, sm
-
-        # ---- BASELINE configs[3]: the mixed transform set (DCT-II 4..32 + closed-form DST-VII 4/8/16), 2 GiB of residual per class
+            also.update(leg_motion_search(b, me))
         if not args.no_transform_set:
-            ts = {}
-            zt = torch.empty_like(x)                       # own output buffer: z still holds the headline leg's result
-            short = max(4, K // 4)
-            for ttype, tname, inverse in ((0, "dct2", False), (1, "dst7", False), (0, "dct2_inv", True), (1, "dst7_inv", True)):
-                for n in (4, 8, 16):
-                    nblk = (n_dct * 1024) // (n * n)
-                    if inverse:
-                        fn = lambda tt=ttype, nn=n, cnt=nblk: codec.transform_inv_dev(tt, nn, x.data_ptr(), zt.data_ptr(), cnt, 0, stream)
-                    else:
-                        fn = lambda tt=ttype, nn=n, cnt=nblk: codec.transform_fwd_dev(tt, nn, x.data_ptr(), zt.data_ptr(), cnt, 0, stream)
-                    leg = timed_leg(fn, steps=short, warmup=3)
-                    ts["%s_%dx%d" % (tname, n, n)] = dict(value=rate(leg, nblk), unit="blocks/s", **hbm2(leg, 4.0 * n * n * nblk), **brief(leg))
-            # per-CTU mixed batch: every 64x64 CTU's 32x32 quadrants cycle through the seven (type, size) classes
-            n_ctu = (n_dct * 1024) // 4096
-            q = torch.arange(n_ctu * 4, device="cuda", dtype=torch.int64)
-            qbase, qkind = q * 1024, (q + q // 4) % 7          # quadrant -> one of the seven classes
-            cls_of_kind = torch.tensor([3, 2, 6, 1, 5, 0, 4], device="cuda", dtype=torch.uint8)   # kinds -> type*4 + log2N-2
-            tile_cls = cls_of_kind[qkind].contiguous()
-            per_ctu = {"layout": "64x64 CTUs whose 32x32 quadrants cycle through the seven classes (DCT-II 32/16/8/4, DST-VII 16/8/4), "
-                                 "TUs of a quadrant contiguous", "ctus": n_ctu}
-            # the whole CTU-ordered buffer in ONE launch: every quadrant is a tile with its own class (xTransformTilesDev)
-            for inv_flag, name in ((0, "per_ctu_one_launch"), (1, "per_ctu_one_launch_inverse")):
-                leg = timed_leg(lambda f=inv_flag: codec.transform_tiles_dev(f, x.data_ptr(), zt.data_ptr(), n_ctu * 4, 0, tile_cls.data_ptr(), stream),
-                                steps=short, warmup=3)
-                per_ctu[name] = dict(value=rate(leg, n_ctu), unit="CTUs/s", **hbm2(leg, 4.0 * n_ctu * 4096), **brief(leg))
-            # comparison only: the same buffer as seven per-class calls over offset tables
-            mixed = []
-            for kind, (tt, n) in enumerate(((0, 32), (0, 16), (1, 16), (0, 8), (1, 8), (0, 4), (1, 4))):
-                base = qbase[qkind == kind]
-                sub = torch.arange(1024 // (n * n), device="cuda", dtype=torch.int64) * (n * n)
-                mixed.append((tt, n, (base[:, None] + sub[None, :]).reshape(-1).to(torch.int32).contiguous()))
-            assert sum(o.numel() * nn * nn for _, nn, o in mixed) == n_ctu * 4096
-
-            def ctu_pass():
-                for tt, nn, o in mixed:
-                    codec.transform_fwd_dev(tt, nn, x.data_ptr(), zt.data_ptr(), o.numel(), o.data_ptr(), stream)
-            leg = timed_leg(ctu_pass, steps=short, warmup=3)
-            per_ctu["seven_calls_over_offset_tables"] = dict(value=rate(leg, n_ctu), unit="CTUs/s", **hbm2(leg, 4.0 * n_ctu * 4096),
-                                                             note="comparison only; the one-launch form above is the configs[3] path", **brief(leg))
-            del zt, mixed, q, qbase, qkind, tile_cls
-            also["transform_set"] = {"classes": ts, "per_ctu_mixed": per_ctu, "parity": "unpinned upstream except DCT-II 32; bit-exact vs this repo's oracle",
-                                     "note": "4*N*N algorithmic bytes per block; hbm_frac from the HIP-event mean of the timed launches"}
-
-            # ---- fused front end: tiled cur/pred frames -> coefficients / costs, residual never in HBM
-            # 32768^2 luma: exactly 2^20 DCT32 blocks and 2^24 SATD blocks, i.e. the two-kernel legs launch the
-            # headline kernels at the headline sizes (keeps rocprofv3's per-kernel averages comparable)
-            fw, fh = 32768, 32768
-            ntile = (fw // 16) * (fh // 16)
-            gq = torch.Generator(device="cuda")
-            gq.manual_seed(0x266)
-            tcur = torch.randint(0, 256, (ntile * 512,), generator=gq, device="cuda", dtype=torch.uint8)
-            tpred = torch.randint(0, 256, (ntile * 512,), generator=gq, device="cuda", dtype=torch.uint8)
-            fcoef = torch.empty(fw * fh, dtype=torch.int16, device="cuda")
-            fcost = torch.empty(fw * fh // 64, dtype=torch.int32, device="cuda")
-            fres = torch.empty(fw * fh, dtype=torch.int16, device="cuda")
-            fused = {}
-            legs = (
-                ("dct32_from_tiles", fw * fh // 1024, 4096,
-                 lambda: codec.dct32_fwd_from_tiles_dev(tcur.data_ptr(), tpred.data_ptr(), fw, fh, fcoef.data_ptr(), stream)),
-                ("dct32_residual_then_transform", fw * fh // 1024, None,
-                 lambda: (codec.residual_luma_dev(tcur.data_ptr(), tpred.data_ptr(), fw, fh, 32, fres.data_ptr(), stream),
-                          codec.dct32_fwd_dev(fres.data_ptr(), fcoef.data_ptr(), fw * fh // 1024, stream))),
-                ("satd8x8_from_tiles", fw * fh // 64, 132,
-                 lambda: codec.satd8x8_from_tiles_dev(tcur.data_ptr(), tpred.data_ptr(), fw, fh, fcost.data_ptr(), stream)),
-                ("satd8x8_residual_then_cost", fw * fh // 64, None,
-                 lambda: (codec.residual_luma_dev(tcur.data_ptr(), tpred.data_ptr(), fw, fh, 8, fres.data_ptr(), stream),
-                          codec.satd8x8_dev(fres.data_ptr(), fcost.data_ptr(), fw * fh // 64, stream))))
-            for name, units, bytes_per_unit, fn in legs:
-                leg = timed_leg(fn, steps=short, warmup=3)
-                fused[name] = dict(value=rate(leg, units), unit="blocks/s", **brief(leg))
-                if bytes_per_unit:
-                    fused[name].update(hbm2(leg, bytes_per_unit * units, "read" if name.startswith("satd") else "copy"))
-            fused["note"] = ("%dx%d tiled frame pair (x266.cpp ref_block_t); fused kernels are bit-identical to the two-kernel paths "
-                             "listed next to them (tests/test_gpu_tiles.py)" % (fw, fh))
-            also["fused_from_tiles"] = fused
-            del tcur, tpred, fcoef, fcost, fres
-
-            # ---- SURVEY 8 f2 / f3: frame container conversion, residual formation, SAD -- pure data movement, HBM-bound
-            fw2, fh2 = 16384, 16384                                      # 256 Mi luma samples
-            npx = fw2 * fh2
-            g = torch.Generator(device="cuda")
-            g.manual_seed(0x77 + rank)
-            ypl = torch.randint(0, 256, (npx,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
-            upl = ypl[: npx // 4].clone()
-            vpl = ypl[npx // 4: npx // 2].clone()
-            t_a = torch.zeros(npx * 2, dtype=torch.uint8, device="cuda")  # 512-byte tiles: 2 bytes per luma sample
-            t_b = torch.zeros(npx * 2, dtype=torch.uint8, device="cuda")
-            res2 = torch.empty(npx, dtype=torch.int16, device="cuda")
-            sad_o = torch.empty(npx // 64, dtype=torch.int32, device="cuda")
-            front = {}
-            for name, nbytes, fn in (
-                    ("conv_input_fmt", 3.0 * npx, lambda: codec.conv_input_fmt_dev(t_a.data_ptr(), ypl.data_ptr(), upl.data_ptr(), vpl.data_ptr(), fw2, fw2, fh2, stream)),
-                    ("conv_output_420", 3.0 * npx, lambda: codec.conv_output_420_dev(t_a.data_ptr(), ypl.data_ptr(), fw2, upl.data_ptr(), vpl.data_ptr(), fw2 // 2, fw2, fh2, stream)),
-                    ("residual_luma_32", 4.0 * npx, lambda: codec.residual_luma_dev(t_a.data_ptr(), t_b.data_ptr(), fw2, fh2, 32, res2.data_ptr(), stream)),
-                    ("sad_8x8", 2.0 * npx + 4.0 * (npx // 64), lambda: codec.sad_dev(8, ypl.data_ptr(), t_b.data_ptr(), sad_o.data_ptr(), npx // 64, stream)),
-                    ("sad_16x16", 2.0 * npx + 4.0 * (npx // 256), lambda: codec.sad_dev(16, ypl.data_ptr(), t_b.data_ptr(), sad_o.data_ptr(), npx // 256, stream)),
-                    ("sad_64x64", 2.0 * npx + 4.0 * (npx // 4096), lambda: codec.sad_dev(64, ypl.data_ptr(), t_b.data_ptr(), sad_o.data_ptr(), npx // 4096, stream))):
-                leg = timed_leg(fn, steps=short, warmup=3)
-                front[name] = dict(GBps=world * nbytes * leg["steps"] / leg["wall_s"] / 1e9, **hbm2(leg, nbytes, "read" if name.startswith("sad") else "copy"),
-                                   samples_per_s=world * npx * leg["steps"] / leg["wall_s"], **brief(leg))
-            front["note"] = ("%dx%d frame; bytes = planes read + tile bytes written (conv), luma of both tile frames + int16 residual "
-                             "(residual), both blocks + 4-byte result (sad)" % (fw2, fh2))
-            also["front_end_and_sad"] = front
-            del ypl, upl, vpl, t_a, t_b, res2, sad_o
-
-            # ---- SURVEY 8 f4: 32x32 intra prediction and mode decision (HEVC 35 modes; parity unpinned upstream)
-            g = torch.Generator(device="cuda")
-            g.manual_seed(0x32 + rank)
-            n_sets = 59918                                              # x 35 modes = 2 GiB of predictions
-            refs_t = torch.randint(0, 256, (n_sets, 144), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
-            modes_t = torch.arange(35, device="cuda", dtype=torch.uint8).repeat(n_sets)
-            index_t = torch.arange(n_sets, device="cuda", dtype=torch.int32).repeat_interleave(35)
-            pred_t = torch.empty(n_sets * 35 * 1024, dtype=torch.uint8, device="cuda")
-            n_dec = min(1 << 17, n_sets)
-            src_t = torch.randint(0, 256, (n_dec * 1024,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
-            cost_t = torch.empty(n_dec * 35, dtype=torch.int32, device="cuda")
-            bestm_t = torch.empty(n_dec, dtype=torch.uint8, device="cuda")
-            intra = {}
-            leg = timed_leg(lambda: codec.intra32_predict_dev(refs_t.data_ptr(), modes_t.data_ptr(), index_t.data_ptr(), pred_t.data_ptr(), n_sets * 35, stream),
-                            steps=short, warmup=3)
-            intra["predict"] = dict(value=rate(leg, n_sets * 35), unit="predictions/s", written_hbm_frac=hbm(leg, 1024.0 * n_sets * 35),
-                                    frac_of_same_box_write=of_box(1024.0 * n_sets * 35 / (leg["kernel_ms_mean"] * 1e-3), "write"), **brief(leg))
-            leg = timed_leg(lambda: codec.intra32_costs_dev(refs_t.data_ptr(), src_t.data_ptr(), cost_t.data_ptr(), bestm_t.data_ptr(), n_dec, stream),
-                            steps=short, warmup=3)
-            intra["decide_35_modes"] = dict(value=rate(leg, n_dec), unit="blocks/s", satd8x8_per_s=rate(leg, n_dec) * 35 * 16, **brief(leg))
-            intra["parity"] = "unpinned upstream (src/mkIntra32-wip.bsv is a sketch without a model); bit-exact vs this repo's oracle"
-            also["intra32"] = intra
-            del refs_t, modes_t, index_t, pred_t, src_t, cost_t, bestm_t
-
-        # ---- the literal drop-in path: host pointers in, host pointers out (xDct32FwdBatch, what INTEGRATION.md section 2 tells an
-        # x266.cpp maintainer to call, src/x266.cpp:526-555), PCIe-inclusive -- never `value`
+            also["transform_set"] = leg_transform_set(b, x)
+            also["fused_from_tiles"] = leg_fused_from_tiles(b)
+            also["front_end_and_sad"] = leg_front_end_and_sad(b)
+            also["intra32"] = leg_intra(b)
         if rank == 0 and world == 1 and not args.no_host_api:
-            also["host_api"] = host_api_leg(codec, torch, min(n_dct, 1 << 17))
-
-        # ---- the node layer of the C ABI: BASELINE configs[4] and the other end-to-end scatter/gather figures.
-        # These legs are the only ones that talk RCCL from this library; a communication hang must not cost the whole
-        # line, so they run under a watchdog: past --node-timeout seconds rank 0 prints the JSON with what it has
-        # (the legs marked as timed out) and every rank leaves.
+            also["host_api"] = leg_host_api(b, min(b.n_dct, 1 << 17))
         result["also"] = also
         result["secondary"] = {"metric": "satd8x8_blocks_per_s", "value": also["satd8x8"]["value"], "unit": "blocks/s",
                                "roofline_frac": also["satd8x8"]["roofline"]["frac"],
                                "frac_of_same_box_read": also["satd8x8"]["roofline"]["frac_of_same_box_read"]}
-        if (ctrl == "cuda" or os.environ.get("X266HIP_RCCL_LIB")) and args.stream8k > 0:
-            def node_timed_out():
-                also["node_layer_error"] = "node-layer legs did not finish within %.0f s (RCCL hang?); line printed without them" % args.node_timeout
-                if rank == 0:
-                    result.setdefault("cpu_baseline", None)
-                    result["device"] = codec.device_info()["name"].strip()
-                    os.write(json_fd, (json.dumps(result) + "\n").encode())
-                os._exit(0)
-            watchdog = threading.Timer(args.node_timeout, node_timed_out)
-            watchdog.daemon = True
-            watchdog.start()
-
-            def node_legs():
-                uid = [Node.unique_id() if rank == 0 else None]
-                if dist is not None:
-                    dist.broadcast_object_list(uid, src=0, device=torch.device("cuda", local_rank) if ctrl == "cuda" else None)
-                node = Node.for_rank(local_rank, rank, world, uid[0])      # xHipNodeInitRank: one process per GPU, also at N = 1
-                node.self_test()                                            # RCCL ring send/recv + all-reduce, checked
-                ver, path = Node.rccl_info()
-                infos = [None] * world
-                if dist is not None:
-                    dist.all_gather_object(infos, "%s (version %d)" % (path, ver))
-                else:
-                    infos = ["%s (version %d)" % (path, ver)]
-                also["rccl_by_rank"] = infos                                # which library each rank's node layer talks to (torch's bundled one or ROCm's)
-                fw8, fh8 = 7680, 4320
-                nd8, ns8 = (fw8 // 32) * (fh8 // 32), (fw8 // 8) * (fh8 // 8)
-                IN_RING, OUT_RING = 4, 5                                  # X266_STREAM_IN_RING / X266_STREAM_OUT_RING (include/x266hip.h)
-                fin = fout = None
-                if rank == 0:
-                    fin = [(torch.empty(nd8 * 1024, dtype=torch.int16, device="cuda"), torch.empty(ns8 * 64, dtype=torch.int16, device="cuda")) for _ in range(IN_RING)]
-                    fout = [(torch.zeros(nd8 * 1024, dtype=torch.int16, device="cuda"), torch.zeros(ns8, dtype=torch.int32, device="cuda")) for _ in range(OUT_RING)]
-                    for i, (a, b) in enumerate(fin):
-                        codec.fill_residual_dev(a.data_ptr(), a.numel(), DCT_SEED, i * 100000007, stream)
-                        codec.fill_residual_dev(b.data_ptr(), b.numel(), SATD_SEED, i * 100000007, stream)
-                torch.cuda.synchronize()
-                st8 = node.frame_stream(fw8, fh8)
-
-                # one foreign call per frame: the argument arrays of every (input ring, output ring) pairing are built once
-                prep8 = ([st8.prepare([fin[i % IN_RING][0].data_ptr(), fin[i % IN_RING][1].data_ptr()],
-                                      [fout[i % OUT_RING][0].data_ptr(), fout[i % OUT_RING][1].data_ptr()]) for i in range(IN_RING * OUT_RING)]
-                         if rank == 0 else None)
-                raw_next = node.L.xNodeStreamNextSlotStream
-
-                def push8(f):
-                    if rank == 0:
-                        # resident inputs: "produced" on the frame's own slot stream, so the push needs no producer event
-                        st8.push_prepared(prep8[f % (IN_RING * OUT_RING)], raw_next(st8.s))
-                    else:
-                        st8.push()
-                F = args.stream8k
-                # clocks: ~0.1 s of frames before the timed ones (200 frames are 7 ms); a fixed count, the same on every rank --
-                # every rank has to issue the same steps
-                for f in range(2500 if world == 1 else 64):
-                    push8(f)
-                st8.flush()
-                barrier()
-                t0 = time.perf_counter()
-                for f in range(F):
-                    push8(f)
-                st8.flush()
-                barrier()
-                wall8 = max_over_ranks(time.perf_counter() - t0)
-                exact8 = None
-                if rank == 0:                                               # last frame against the plain single-device calls
-                    a, b = fin[(F - 1) % IN_RING]
-                    c, e = fout[(F - 1) % OUT_RING]
-                    c1, e1 = torch.empty_like(c), torch.empty_like(e)
-                    codec.dct32_fwd_dev(a.data_ptr(), c1.data_ptr(), nd8, stream)
-                    codec.satd8x8_dev(b.data_ptr(), e1.data_ptr(), ns8, stream)
-                    torch.cuda.synchronize()
-                    exact8 = bool(torch.equal(c, c1) and torch.equal(e, e1))
-                kernel_us = None
-                if rank == 0 and world == 1:                                # what the frame's one launch costs by itself, back to back on one stream
-                    a, b = fin[0]
-                    c, e = fout[0]
-                    frame_fn = lambda: codec.frame_lanes_dev(a.data_ptr(), c.data_ptr(), nd8, b.data_ptr(), e.data_ptr(), ns8, stream)
-                    for _ in range(200):
-                        frame_fn()
-                    codec.event_record(events[0], stream)
-                    for _ in range(200):
-                        frame_fn()
-                    codec.event_record(events[1], stream)
-                    kernel_us = codec.event_elapsed_ms(events[0], events[1]) / 200 * 1e3
-                peers = world - 1
-                link_bytes = (nd8 * 2048 + ns8 * 128) / world              # one peer's input shard of a frame, over one link
-                also["stream8k"] = {
-                    "frames_per_s": F / wall8, "ms_per_frame": wall8 / F * 1e3, "frames": F,
-                    "kernel_us": kernel_us, "launches_per_frame_and_rank": 1,
-                    "kernel_share_of_frame_time": (kernel_us * 1e-6 / (wall8 / F)) if kernel_us else None,
-                    "dct32_blocks_per_s": nd8 * F / wall8, "satd8x8_blocks_per_s": ns8 * F / wall8,
-                    "frame": "7680x4320: %d DCT32 blocks (66.4 MB) + %d SATD blocks (66.4 MB)" % (nd8, ns8),
-                    "path": "C ABI node layer (xNodeStreamPush / Flush): per step one RCCL group carries frame t's shards root -> peers and "
-                            "frame t-2's coefficients and costs peers -> root on a communication stream while every rank transforms frame t"
-                            if world > 1 else "C ABI node layer, one rank: the root transforms the frame in place, no transfer (RCCL only in the self-test)",
-                    "bit_exact_vs_single_device": exact8,
-                    "link_bound_frames_per_s": (XGMI_LINK_BYTES_PER_S / link_bytes) if peers else None,
-                    "link_bound": "each peer's input shard crosses ONE xGMI link (~153 GB/s per direction): <= 7.5e7 DCT32 blocks/s per peer (SURVEY.md 8e)"}
-                st8.close()
-                # one resident batch, scattered and gathered (SURVEY 8e "end-to-end scatter -> compute -> gather")
-                nsg = min(1 << 18, n_dct)
-                xin = xout = None
-                if rank == 0:
-                    xin, xout = x[: nsg * 1024], z[: nsg * 1024]
-                torch.cuda.synchronize()
-                node.batch_scatter_gather(OP_DCT32_FWD, xin.data_ptr() if rank == 0 else 0, xout.data_ptr() if rank == 0 else 0, nsg, 0)
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(4):
-                    node.batch_scatter_gather(OP_DCT32_FWD, xin.data_ptr() if rank == 0 else 0, xout.data_ptr() if rank == 0 else 0, nsg, 0)
-                barrier()
-                wall_sg = max_over_ranks(time.perf_counter() - t0) / 4
-                also["dct32_scatter_gather"] = {"value": nsg / wall_sg, "unit": "blocks/s", "blocks": nsg,
-                                                "link_bound_blocks_per_s": (world * XGMI_LINK_BYTES_PER_S / 2048.0) if world > 1 else None,
-                                                "link_bound": "every peer's shard crosses ONE xGMI link (~153 GB/s per direction, inputs one way, results the other): "
-                                                              "<= 153e9 / 2048 = 7.5e7 blocks/s per peer, i.e. world x 7.5e7 with the root computing its own shard in place"
-                                                              if world > 1 else None,
-                                                "note": "root-resident batch cut into chunks (8 MiB of input per rank), pipelined through the node stream "
-                                                        "(xNodeBatchScatterGather); at N = 1 no transfer"}
-                if not args.no_me:
-                    # sharded motion search: stripes + halo from the root, records back (xNodeSatd8x8Search)
-                    nstr = max(world, 1)
-                    node.satd_search(cur.data_ptr() if rank == 0 else 0, cur.stride(0), origin if rank == 0 else 0, refp.stride(0), 3840, 2160, 64, nstr,
-                                     best.data_ptr() if rank == 0 else 0)
-                    ref_best = None
-                    if rank == 0:
-                        ref_best = best.clone()
-                    barrier()
-                    t0 = time.perf_counter()
-                    for _ in range(3):
-                        node.satd_search(cur.data_ptr() if rank == 0 else 0, cur.stride(0), origin if rank == 0 else 0, refp.stride(0), 3840, 2160, 64, nstr,
-                                         best.data_ptr() if rank == 0 else 0)
-                    barrier()
-                    wall_ms = max_over_ranks(time.perf_counter() - t0) / 3
-                    same = None
-                    if rank == 0:
-                        codec.satd_search_dev(cur.data_ptr(), cur.stride(0), origin, refp.stride(0), 3840, 2160, 64, best.data_ptr(), 0, stream)
-                        torch.cuda.synchronize()
-                        same = bool(torch.equal(best, ref_best))
-                    also["satd8x8_me_search_sharded"] = {"ms_per_frame": wall_ms * 1e3, "stripes": nstr, "identical_to_single_device": same,
-                                                         "note": "synchronous call incl. scatter of cur stripes + reference halo and gather of (mv, cost)"}
-                node.close()
-            try:
-                node_legs()
-            except Exception as e:                                      # e.g. RCCL missing: keep the rest of the line
-                also["node_layer_error"] = "%s: %s" % (type(e).__name__, e)
-            watchdog.cancel()
+        if (not b.share or os.environ.get("X266HIP_RCCL_LIB")) and args.stream8k > 0:
+            run_node_legs_under_watchdog(b, result, also, x, z, me, json_fd)
+        also["rccl_libraries_in_process"] = loaded_libraries("librccl")
 
     # ---- CPU baseline for the headline leg (rank 0, N = 1 only) ------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if not args.no_also:                                            # z was reused as scatter-gather output: same values, recompute to be explicit
-            codec.dct32_fwd_dev(x.data_ptr(), z.data_ptr(), n_dct, stream)
-            torch.cuda.synchronize()
-        base, exact = cpu_baseline_dct(x.cpu().numpy().reshape(n_dct, 1024), z.cpu().numpy().reshape(n_dct, 1024))
+        x_host = x.download(np.int16, b.n_dct * 1024).reshape(b.n_dct, 1024)
+        base, exact = cpu_baseline_dct(x_host, z_host.reshape(b.n_dct, 1024))
         result["cpu_baseline"] = base
         if not exact:
             result["error"] = "GPU output differs from the CPU reference"
@@ -1060,16 +1136,15 @@ def main():
         result["cpu_baseline"] = None
 
     if rank == 0:
-        info = codec.device_info()
-        result["device"] = info["name"].strip()
+        result["device"] = b.info["name"].strip()
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
-    if dist is not None:
-        if result.get("also", {}).get("node_layer_error"):           # peers may be stuck in a collective this rank left: no orderly shutdown
+    if b.dist is not None:
+        if result.get("also", {}).get("node_layer_error"):               # peers may be stuck in a collective this rank left: no orderly shutdown
             sys.stdout.flush()
             sys.stderr.flush()
             os._exit(0)
-        dist.destroy_process_group()
+        b.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

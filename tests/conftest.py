@@ -3,18 +3,22 @@ import sys
 
 import pytest
 
-# Some GPU tests use torch for device memory next to the library.  The torch wheel bundles its own HIP runtime with the
-# same SONAME as ROCm's, and torch only finds the GPU behind its own copy: whichever test
-# runs first, torch's copy has to be the one the process loads.
-try:
-    import torch  # noqa: F401
-except ImportError:
-    pass
+# No torch in a test process: device memory comes from the C ABI (tests/_dev.py), so the library is exercised on the HIP
+# runtime and RCCL it is built for and ships on (ROCm's /opt/rocm copies, what a plain-C host gets) -- the torch wheel bundles
+# an older libamdhip64 / librccl with the same SONAMEs, and whichever copy a process loads first serves everything in it
+# (tests/test_gpu_runtime.py asserts there is exactly one, and which).  Only tests/test_shard_gloo.py (CPU, gloo) and the
+# N > 1 control plane of bench.py import torch, the latter AFTER the library.
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+
+def pytest_collection_finish(session):
+    # a `-m gpu` session must reach its first test without torch in the process (see above); a CPU session may have it
+    if "gpu" == (session.config.getoption("-m") or "").strip():
+        assert "torch" not in sys.modules, "collecting the tests imported torch: its bundled HIP runtime / RCCL would serve the GPU test process"
 
 
 def pytest_configure(config):

@@ -54,8 +54,7 @@ def test_pack_helpers_match_reference_sequence(lib, oracle):
 
 def test_no_cpu_fallback(lib):
     """Without a GPU the context cannot be created and nothing computes."""
-    import torch
-    if torch.cuda.is_available():
+    if lib.xHipDeviceCount() > 0:
         pytest.skip("GPU present: covered by the -m gpu tests")
     with pytest.raises(x266_amd.X266Error):
         x266_amd.Codec(0)
@@ -95,15 +94,13 @@ def test_node_layer_without_a_gpu(lib):
     """The multi-GPU layer: planning functions are host-only; a node cannot be made without devices
     (no CPU path), NULL handles are rejected, and RCCL is NOT a link-time dependency of the drop-in."""
     import subprocess
-    import torch
     from x266_amd.node import Node, me_stripe_plan, shard_range
     assert shard_range(10, 0, 3) == (0, 4) and shard_range(10, 2, 3) == (7, 10)
     assert me_stripe_plan(2160, 64, 0, 8) == ((0, 34), (-64, 34 * 8 + 64))
     assert "rccl" not in subprocess.check_output(["ldd", x266_amd.lib_path()]).decode()
     assert lib.xNodeStreamFlush(None) < 0 and lib.xNodeStreamWait(None, 0) < 0
     assert lib.xHipNodeSelfTest(None) < 0 and lib.xNodeBatchScatterGather(None, 0, None, None, 4, 0) < 0
-    if not torch.cuda.is_available():
-        assert lib.xHipDeviceCount() == 0
+    if lib.xHipDeviceCount() == 0:
         with pytest.raises(x266_amd.X266Error):
             Node.single_process([0])
 

@@ -12,14 +12,27 @@ import sys
 
 import numpy as np
 import pytest
-import torch
 
 import x266_amd
 from x266_amd.node import Node, OP_DCT32_FWD, OP_DCT32_INV, OP_SATD8X8
+from _dev import Dev, hip_runtime
 from _util import me_frames
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Lazy:
+    """device memory on device 0 through the C ABI (tests/_dev.py); the context is created with the first allocation"""
+    _d = None
+
+    def __getattr__(self, name):
+        if _Lazy._d is None:
+            _Lazy._d = Dev(x266_amd.Codec(0))
+        return getattr(_Lazy._d, name)
+
+
+D = _Lazy()
 
 
 @pytest.fixture(scope="module")
@@ -51,11 +64,10 @@ def test_frame_stream_is_bit_exact(node, oracle, w, h, n_frames):
     (two frames in flight, slots reused), every frame compared whole with the oracle."""
     n_d, n_s = (w // 32) * (h // 32), (w // 8) * (h // 8)
     st = node.frame_stream(w, h)
-    dev = torch.device("cuda", 0)
-    xin = [(torch.from_numpy(_frame(oracle, n_d * 1024, 0x266, f)).to(dev), torch.from_numpy(_frame(oracle, n_s * 64, 0x267, f)).to(dev))
+    xin = [(D.from_numpy(_frame(oracle, n_d * 1024, 0x266, f)), D.from_numpy(_frame(oracle, n_s * 64, 0x267, f)))
            for f in range(n_frames)]
-    out = [(torch.zeros(n_d * 1024, dtype=torch.int16, device=dev), torch.zeros(n_s, dtype=torch.int32, device=dev)) for _ in range(n_frames)]
-    torch.cuda.synchronize()
+    out = [(D.zeros(n_d * 1024, np.int16), D.zeros(n_s, np.int32)) for _ in range(n_frames)]
+    D.synchronize()
     tickets = []
     for f in range(n_frames):
         tickets.append(st.push([xin[f][0].data_ptr(), xin[f][1].data_ptr()], [out[f][0].data_ptr(), out[f][1].data_ptr()]))
@@ -75,11 +87,10 @@ def test_output_buffer_of_a_frame_in_flight_is_refused(node, oracle):
     """buffer ownership is checked, not only documented -- an output buffer that overlaps the output of one of the previous
     X266_STREAM_OUT_RING - 1 frames still in flight is EINVAL (inputs may be shared: they are only read); a flush or a waited ticket
     gives the buffers back."""
-    dev = torch.device("cuda", 0)
     st = node.stream([OP_DCT32_FWD], [8])
-    x = torch.from_numpy(oracle.fill_residual(8 * 1024, 3)).to(dev)
-    outs = [torch.zeros(8 * 1024, dtype=torch.int16, device=dev) for _ in range(5)]
-    torch.cuda.synchronize()
+    x = D.from_numpy(oracle.fill_residual(8 * 1024, 3))
+    outs = [D.zeros(8 * 1024, np.int16) for _ in range(5)]
+    D.synchronize()
     t0 = st.push([x.data_ptr()], [outs[0].data_ptr()])
     for back in (1, 2, 3, 4):                                            # frame `back` steps later, same output: refused every time
         with pytest.raises(x266_amd.X266Error, match="in flight"):
@@ -99,15 +110,14 @@ def test_output_buffer_of_a_frame_in_flight_is_refused(node, oracle):
 
 
 def test_stream_takes_ragged_unit_counts_and_inverse_lane(node, oracle):
-    dev = torch.device("cuda", 0)
     st = node.stream([OP_DCT32_INV, OP_SATD8X8, OP_DCT32_FWD], [40, 1000, 40])
-    z = torch.from_numpy(oracle.fill_residual(40 * 1024, 5)).to(dev)
-    d = torch.from_numpy(oracle.fill_residual(1000 * 64, 6)).to(dev)
+    z = D.from_numpy(oracle.fill_residual(40 * 1024, 5))
+    d = D.from_numpy(oracle.fill_residual(1000 * 64, 6))
     for units in ([40, 1000, 40], [17, 999, 0], [1, 1, 40]):
-        o0 = torch.zeros(40 * 1024, dtype=torch.int16, device=dev)
-        o1 = torch.zeros(1000, dtype=torch.int32, device=dev)
-        o2 = torch.zeros(40 * 1024, dtype=torch.int16, device=dev)
-        torch.cuda.synchronize()
+        o0 = D.zeros(40 * 1024, np.int16)
+        o1 = D.zeros(1000, np.int32)
+        o2 = D.zeros(40 * 1024, np.int16)
+        D.synchronize()
         st.push([z.data_ptr(), d.data_ptr(), z.data_ptr()], [o0.data_ptr(), o1.data_ptr(), o2.data_ptr()], units)
         st.flush()
         a, b, c = units
@@ -122,12 +132,11 @@ def test_stream_takes_ragged_unit_counts_and_inverse_lane(node, oracle):
 
 @pytest.mark.parametrize("op,n,chunk", [(OP_DCT32_FWD, 10000, 0), (OP_SATD8X8, 200001, 4096), (OP_DCT32_INV, 5, 2)])
 def test_batch_scatter_gather(node, oracle, op, n, chunk):
-    dev = torch.device("cuda", 0)
     unit = 64 if op == OP_SATD8X8 else 1024
     x = oracle.fill_residual(n * unit, 77)
-    tin = torch.from_numpy(x).to(dev)
-    tout = torch.zeros(n if op == OP_SATD8X8 else n * 1024, dtype=torch.int32 if op == OP_SATD8X8 else torch.int16, device=dev)
-    torch.cuda.synchronize()
+    tin = D.from_numpy(x)
+    tout = D.zeros(n if op == OP_SATD8X8 else n * 1024, np.int32 if op == OP_SATD8X8 else np.int16)
+    D.synchronize()
     node.batch_scatter_gather(op, tin.data_ptr(), tout.data_ptr(), n, chunk)
     want = {OP_DCT32_FWD: lambda: oracle.dct32_fwd(x, threads=16).ravel(), OP_DCT32_INV: lambda: oracle.dct32_inv(x, threads=16).ravel(),
             OP_SATD8X8: lambda: oracle.satd8x8(x, threads=16).astype(np.int32)}[op]()
@@ -141,15 +150,14 @@ def test_sharded_motion_search_gives_identical_winners(node, codec, w, h, rng):
     would receive (stripe of cur, stripe +- range rows of the reference), so a wrong halo shows up."""
     cur, refp = me_frames(w, h, rng, 0x51, mv=(3, -2))
     mv0, cost0, _ = codec.satd_search(cur, refp, rng, rng)
-    dev = torch.device("cuda", 0)
-    tc, tr = torch.from_numpy(cur).to(dev), torch.from_numpy(refp).to(dev)
+    tc, tr = D.from_numpy(cur), D.from_numpy(refp)
     nb = (h // 8) * (w // 8)
     origin = tr.data_ptr() + rng * tr.stride(0) + rng
     for local_copy in (0, 1):
         node.set_option("me_local_copy", local_copy)
         for n_stripes in (0, 1, 2, 5, h // 8 + 3):
-            best = torch.zeros(nb * 2, dtype=torch.int32, device=dev)
-            torch.cuda.synchronize()
+            best = D.zeros(nb * 2, np.int32)
+            D.synchronize()
             node.satd_search(tc.data_ptr(), tc.stride(0), origin, tr.stride(0), w, h, rng, n_stripes, best.data_ptr())
             raw = best.cpu().numpy()
             mv = raw.view(np.int16).reshape(nb, 4)[:, :2]
@@ -176,11 +184,13 @@ def test_plain_c_host_stream8k():
 
 def test_calls_restore_the_callers_device(codec):
     """entry points run on the context's device and put the caller's current device back."""
-    assert torch.cuda.current_device() == 0
-    x = torch.zeros(1024, dtype=torch.int16, device="cuda")
+    import ctypes
+    hip, cur = hip_runtime(), ctypes.c_int(-1)
+    assert hip.hipGetDevice(ctypes.byref(cur)) == 0 and cur.value == 0
+    x = D.zeros(1024, np.int16)
     codec.dct32_fwd_dev(x.data_ptr(), x.clone().data_ptr(), 1)
-    torch.cuda.synchronize()
-    assert torch.cuda.current_device() == 0
+    D.synchronize()
+    assert hip.hipGetDevice(ctypes.byref(cur)) == 0 and cur.value == 0
 
 
 def test_searches_on_two_streams_do_not_share_scratch(codec, oracle):
@@ -189,13 +199,12 @@ def test_searches_on_two_streams_do_not_share_scratch(codec, oracle):
     rng = 8
     frames = [me_frames(512, 256, rng, seed, mv=(1 + seed % 3, -1)) for seed in (11, 12)]
     alone = [codec.satd_search(c, r, rng, rng)[:2] for c, r in frames]
-    dev = torch.device("cuda", 0)
     streams = [codec.stream_create() for _ in frames]
     bufs = []
     for c, r in frames:
-        tc, tr = torch.from_numpy(c).to(dev), torch.from_numpy(r).to(dev)
-        bufs.append((tc, tr, torch.zeros((256 // 8) * (512 // 8) * 2, dtype=torch.int32, device=dev)))
-    torch.cuda.synchronize()
+        tc, tr = D.from_numpy(c), D.from_numpy(r)
+        bufs.append((tc, tr, D.zeros((256 // 8) * (512 // 8) * 2, np.int32)))
+    D.synchronize()
     for _ in range(8):                                # interleaved launches, both streams busy at once
         for (tc, tr, best), s in zip(bufs, streams):
             codec.satd_search_dev(tc.data_ptr(), tc.stride(0), tr.data_ptr() + rng * tr.stride(0) + rng, tr.stride(0), 512, 256, rng,
@@ -230,11 +239,10 @@ def test_multi_rank_frame_stream_is_bit_exact(multi_node, oracle, w, h, n_frames
     two frames in flight; at 7680x4320 every rank transforms its 1/N of the frame and the root's buffers receive the rest."""
     n_d, n_s = (w // 32) * (h // 32), (w // 8) * (h // 8)
     st = multi_node.frame_stream(w, h)
-    dev = torch.device("cuda", 0)
-    xin = [(torch.from_numpy(_frame(oracle, n_d * 1024, 0x266, f)).to(dev), torch.from_numpy(_frame(oracle, n_s * 64, 0x267, f)).to(dev))
+    xin = [(D.from_numpy(_frame(oracle, n_d * 1024, 0x266, f)), D.from_numpy(_frame(oracle, n_s * 64, 0x267, f)))
            for f in range(n_frames)]
-    out = [(torch.zeros(n_d * 1024, dtype=torch.int16, device=dev), torch.zeros(n_s, dtype=torch.int32, device=dev)) for _ in range(n_frames)]
-    torch.cuda.synchronize()
+    out = [(D.zeros(n_d * 1024, np.int16), D.zeros(n_s, np.int32)) for _ in range(n_frames)]
+    D.synchronize()
     tickets = []
     for f in range(n_frames):
         tickets.append(st.push([xin[f][0].data_ptr(), xin[f][1].data_ptr()], [out[f][0].data_ptr(), out[f][1].data_ptr()]))
@@ -249,21 +257,20 @@ def test_multi_rank_frame_stream_is_bit_exact(multi_node, oracle, w, h, n_frames
 
 
 def test_multi_rank_batch_and_sharded_search(multi_node, codec, oracle):
-    dev = torch.device("cuda", 0)
     n = 10007
     x = oracle.fill_residual(n * 1024, 78)
-    tin, tout = torch.from_numpy(x).to(dev), torch.zeros(n * 1024, dtype=torch.int16, device=dev)
-    torch.cuda.synchronize()
+    tin, tout = D.from_numpy(x), D.zeros(n * 1024, np.int16)
+    D.synchronize()
     multi_node.batch_scatter_gather(OP_DCT32_FWD, tin.data_ptr(), tout.data_ptr(), n, 1000)
     assert np.array_equal(tout.cpu().numpy(), oracle.dct32_fwd(x, threads=16).ravel())
     w, h, rng = 200, 136, 24
     cur, refp = me_frames(w, h, rng, 0x52, mv=(-2, 3))
     mv0, cost0, _ = codec.satd_search(cur, refp, rng, rng)
-    tc, tr = torch.from_numpy(cur).to(dev), torch.from_numpy(refp).to(dev)
+    tc, tr = D.from_numpy(cur), D.from_numpy(refp)
     nb = (h // 8) * (w // 8)
     for n_stripes in (0, multi_node.world + 2):             # one stripe per rank; more stripes than ranks (contiguous runs)
-        best = torch.zeros(nb * 2, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        best = D.zeros(nb * 2, np.int32)
+        D.synchronize()
         multi_node.satd_search(tc.data_ptr(), tc.stride(0), tr.data_ptr() + rng * tr.stride(0) + rng, tr.stride(0), w, h, rng, n_stripes, best.data_ptr())
         raw = best.cpu().numpy()
         assert np.array_equal(raw.view(np.int16).reshape(nb, 4)[:, :2], mv0) and np.array_equal(raw.view(np.uint32).reshape(nb, 2)[:, 1], cost0), n_stripes
@@ -272,21 +279,20 @@ def test_multi_rank_batch_and_sharded_search(multi_node, codec, oracle):
 def test_multi_rank_stream_with_ragged_unit_counts(multi_node, oracle):
     """Unit counts that change from frame to frame -- zero, one, fewer than ranks, not divisible -- through the pipelined
     stream with 2, 3 and 5 ranks: every shard boundary and every skipped (empty) transfer must agree on both ends."""
-    dev = torch.device("cuda", 0)
     caps = [37, 1003, 37]
     st = multi_node.stream([OP_DCT32_INV, OP_SATD8X8, OP_DCT32_FWD], caps)
-    z = torch.from_numpy(oracle.fill_residual(caps[0] * 1024, 15)).to(dev)
-    d = torch.from_numpy(oracle.fill_residual(caps[1] * 64, 16)).to(dev)
+    z = D.from_numpy(oracle.fill_residual(caps[0] * 1024, 15))
+    d = D.from_numpy(oracle.fill_residual(caps[1] * 64, 16))
     zh, dh = z.cpu().numpy(), d.cpu().numpy()
     rs = np.random.RandomState(multi_node.world)
     plans = [[37, 1003, 37], [0, 0, 0], [1, 1, 1], [multi_node.world - 1, multi_node.world + 1, 0], [0, 7, 36]]
     plans += [[int(rs.randint(0, c + 1)) for c in caps] for _ in range(7)]
     outs = []
     for units in plans:                                              # all frames in flight back to back, distinct output buffers
-        o = (torch.zeros(caps[0] * 1024, dtype=torch.int16, device=dev), torch.zeros(caps[1], dtype=torch.int32, device=dev),
-             torch.zeros(caps[2] * 1024, dtype=torch.int16, device=dev))
+        o = (D.zeros(caps[0] * 1024, np.int16), D.zeros(caps[1], np.int32),
+             D.zeros(caps[2] * 1024, np.int16))
         outs.append(o)
-        torch.cuda.synchronize()
+        D.synchronize()
         st.push([z.data_ptr(), d.data_ptr(), z.data_ptr()], [t.data_ptr() for t in o], units)
     st.flush()
     for units, (o0, o1, o2) in zip(plans, outs):
@@ -396,58 +402,56 @@ def test_multi_device_frame_stream_over_rccl(real_node, codec, oracle, w, h, n_f
     first frame the oracle), tickets waited two steps later as documented."""
     real_node, _ = real_node
     n_d, n_s = (w // 32) * (h // 32), (w // 8) * (h // 8)
-    dev = torch.device("cuda", 0)
     st = real_node.frame_stream(w, h)
-    xin = [(torch.from_numpy(_frame(oracle, n_d * 1024, 0x266, f)).to(dev), torch.from_numpy(_frame(oracle, n_s * 64, 0x267, f)).to(dev)) for f in range(n_frames)]
+    xin = [(D.from_numpy(_frame(oracle, n_d * 1024, 0x266, f)), D.from_numpy(_frame(oracle, n_s * 64, 0x267, f))) for f in range(n_frames)]
     want = []
     for a, b in xin:
-        c, e = torch.empty_like(a), torch.empty(n_s, dtype=torch.int32, device=dev)
+        c, e = D.empty_like(a), D.empty(n_s, np.int32)
         codec.dct32_fwd_dev(a.data_ptr(), c.data_ptr(), n_d)
         codec.satd8x8_dev(b.data_ptr(), e.data_ptr(), n_s)
         want.append((c, e))
-    torch.cuda.synchronize()
+    D.synchronize()
     assert np.array_equal(want[0][0].cpu().numpy(), oracle.dct32_fwd(xin[0][0].cpu().numpy(), threads=32).ravel())
     assert np.array_equal(want[0][1].cpu().numpy(), oracle.satd8x8(xin[0][1].cpu().numpy(), threads=32).astype(np.int32))
-    out = [(torch.zeros(n_d * 1024, dtype=torch.int16, device=dev), torch.zeros(n_s, dtype=torch.int32, device=dev)) for _ in range(n_frames)]
-    torch.cuda.synchronize()
+    out = [(D.zeros(n_d * 1024, np.int16), D.zeros(n_s, np.int32)) for _ in range(n_frames)]
+    D.synchronize()
     tickets = []
     for f in range(n_frames):
         tickets.append(st.push([xin[f][0].data_ptr(), xin[f][1].data_ptr()], [out[f][0].data_ptr(), out[f][1].data_ptr()]))
         if f >= 2:
             st.wait(tickets[f - 2])
-            assert torch.equal(out[f - 2][0], want[f - 2][0]) and torch.equal(out[f - 2][1], want[f - 2][1]), f - 2
+            assert D.equal(out[f - 2][0], want[f - 2][0]) and D.equal(out[f - 2][1], want[f - 2][1]), f - 2
     st.flush()
     for f in range(n_frames):
-        assert torch.equal(out[f][0], want[f][0]) and torch.equal(out[f][1], want[f][1]), f
+        assert D.equal(out[f][0], want[f][0]) and D.equal(out[f][1], want[f][1]), f
     st.close()
 
 
 def test_multi_device_batch_scatter_gather_and_sharded_search(real_node, codec, oracle):
     real_node, _ = real_node
-    dev = torch.device("cuda", 0)
     for op, n, chunk in ((OP_DCT32_FWD, 100003, 0), (OP_SATD8X8, 2000001, 0), (OP_DCT32_INV, 4099, 1000)):
         unit = 64 if op == OP_SATD8X8 else 1024
-        tin = torch.empty(n * unit, dtype=torch.int16, device=dev)
+        tin = D.empty(n * unit, np.int16)
         codec.fill_residual_dev(tin.data_ptr(), tin.numel(), 0x300 + op)
-        tout = torch.zeros(n if op == OP_SATD8X8 else n * 1024, dtype=torch.int32 if op == OP_SATD8X8 else torch.int16, device=dev)
-        ref = torch.empty_like(tout)
+        tout = D.zeros(n if op == OP_SATD8X8 else n * 1024, np.int32 if op == OP_SATD8X8 else np.int16)
+        ref = D.empty_like(tout)
         {OP_DCT32_FWD: codec.dct32_fwd_dev, OP_DCT32_INV: codec.dct32_inv_dev, OP_SATD8X8: codec.satd8x8_dev}[op](tin.data_ptr(), ref.data_ptr(), n)
-        torch.cuda.synchronize()
+        D.synchronize()
         real_node.batch_scatter_gather(op, tin.data_ptr(), tout.data_ptr(), n, chunk)
-        assert torch.equal(tout, ref), op
+        assert D.equal(tout, ref), op
     w, h, rng = 1920, 1088, 32
     cur, refp = me_frames(w, h, rng, 0x53, mv=(4, -1))
-    tc, tr = torch.from_numpy(cur).to(dev), torch.from_numpy(refp).to(dev)
+    tc, tr = D.from_numpy(cur), D.from_numpy(refp)
     nb = (h // 8) * (w // 8)
     origin = tr.data_ptr() + rng * tr.stride(0) + rng
-    single = torch.zeros(nb * 2, dtype=torch.int32, device=dev)
+    single = D.zeros(nb * 2, np.int32)
     codec.satd_search_dev(tc.data_ptr(), tc.stride(0), origin, tr.stride(0), w, h, rng, single.data_ptr())
-    torch.cuda.synchronize()
+    D.synchronize()
     for n_stripes in (0, real_node.world + 3, 1):
-        best = torch.zeros(nb * 2, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        best = D.zeros(nb * 2, np.int32)
+        D.synchronize()
         real_node.satd_search(tc.data_ptr(), tc.stride(0), origin, tr.stride(0), w, h, rng, n_stripes, best.data_ptr())
-        assert torch.equal(best, single), n_stripes
+        assert D.equal(best, single), n_stripes
 
 
 def test_multi_device_slow_peer_and_input_ring_reuse(real_node, codec):
@@ -459,23 +463,22 @@ def test_multi_device_slow_peer_and_input_ring_reuse(real_node, codec):
     IN_RING, OUT_RING, n_frames = 4, 5, 40
     w, h = 7680, 4320
     n_d, n_s = (w // 32) * (h // 32), (w // 8) * (h // 8)
-    dev = torch.device("cuda", 0)
     peer_index = real_node.world - 1
     peer = real_node.rank_codec(peer_index)
-    pdev = torch.device("cuda", devices[peer_index])
+    DP = Dev(peer)                                    # memory on the peer's device, through the peer's context
     sw, sh, srng = 3840, 2160, 64
-    pc = torch.randint(0, 256, (sh, sw), device=pdev, dtype=torch.int32).to(torch.uint8)
-    pr = torch.randint(0, 256, (sh + 2 * srng, sw + 2 * srng), device=pdev, dtype=torch.int32).to(torch.uint8)
-    pbest = torch.empty((sh // 8) * (sw // 8) * 2, dtype=torch.int32, device=pdev)
+    pc = DP.random_u8((sh, sw), 1)
+    pr = DP.random_u8((sh + 2 * srng, sw + 2 * srng), 2)
+    pbest = DP.empty((sh // 8) * (sw // 8) * 2, np.int32)
     pstream = peer.stream_create()
-    torch.cuda.synchronize(pdev)
+    DP.synchronize()
 
     def frame_input(f, a, b, stream):
         codec.fill_residual_dev(a.data_ptr(), a.numel(), 0x266, f * 100000007, stream)
         codec.fill_residual_dev(b.data_ptr(), b.numel(), 0x267, f * 100000007, stream)
 
-    fin = [(torch.empty(n_d * 1024, dtype=torch.int16, device=dev), torch.empty(n_s * 64, dtype=torch.int16, device=dev)) for _ in range(IN_RING)]
-    fout = [(torch.zeros(n_d * 1024, dtype=torch.int16, device=dev), torch.zeros(n_s, dtype=torch.int32, device=dev)) for _ in range(OUT_RING)]
+    fin = [(D.empty(n_d * 1024, np.int16), D.empty(n_s * 64, np.int16)) for _ in range(IN_RING)]
+    fout = [(D.zeros(n_d * 1024, np.int16), D.zeros(n_s, np.int32)) for _ in range(OUT_RING)]
     producer = codec.stream_create()
     st = real_node.frame_stream(w, h)
     got = []
@@ -496,17 +499,17 @@ def test_multi_device_slow_peer_and_input_ring_reuse(real_node, codec):
     for f in (n_frames - 2, n_frames - 1):
         c2, e2 = fout[f % OUT_RING]
         got.append((c2.clone(), e2.clone()))
-    torch.cuda.synchronize()
+    D.synchronize()
     peer.stream_sync(pstream)
     st.close()
     a, b = fin[0]
-    c1, e1 = torch.empty_like(fout[0][0]), torch.empty_like(fout[0][1])
+    c1, e1 = D.empty_like(fout[0][0]), D.empty_like(fout[0][1])
     for f in range(n_frames):
         frame_input(f, a, b, 0)
         codec.dct32_fwd_dev(a.data_ptr(), c1.data_ptr(), n_d)
         codec.satd8x8_dev(b.data_ptr(), e1.data_ptr(), n_s)
-        torch.cuda.synchronize()
-        assert torch.equal(got[f][0], c1) and torch.equal(got[f][1], e1), f
+        D.synchronize()
+        assert D.equal(got[f][0], c1) and D.equal(got[f][1], e1), f
     codec.stream_destroy(producer)
     peer.stream_destroy(pstream)
 

@@ -5,13 +5,29 @@ import os
 import socket
 import sys
 
+import importlib
+
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from x266_amd.shard import combine_checksums, me_stripe, shard_range
+
+
+class _Lazy:
+    """torch is imported by the first test that USES it, not when pytest collects this file: a `-m gpu` session collects every
+    file, and torch's bundled HIP runtime / RCCL (same SONAMEs as ROCm's) would then serve the whole GPU test process
+    (tests/conftest.py, tests/test_gpu_runtime.py)."""
+
+    def __init__(self, name):
+        self._name = name
+
+    def __getattr__(self, attr):
+        if attr.startswith("__"):                                       # pytest's collector probes module globals (__test__, ...): not a use
+            raise AttributeError(attr)
+        return getattr(importlib.import_module(self._name), attr)
+
+
+torch, dist, mp = _Lazy("torch"), _Lazy("torch.distributed"), _Lazy("torch.multiprocessing")
 
 
 def test_shard_range_partitions():

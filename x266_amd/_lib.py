@@ -185,6 +185,9 @@ class Codec:
 
     def close(self):
         if getattr(self, "ctx", None):
+            if getattr(self, "_pinned_live", 0) > 0:       # pinned blocks of host_alloc are still referenced: the context goes with the last one
+                self._close_pending = True
+                return
             if not getattr(self, "_borrowed", False):
                 self.L.xHipCodecFree(self.ctx)
             self.ctx = None
@@ -482,32 +485,37 @@ class Codec:
 
     def host_alloc(self, shape, dtype):
         """A numpy array in page-locked host memory (xHipHostAlloc): the host-pointer batch calls move it by DMA (43 GB/s each way
-        instead of 27 from pageable memory).  The array owns the allocation through its base object."""
+        instead of 27 from pageable memory).  The allocation belongs to a buffer owner at the END of the base chain of the array
+        and of every view, slice or reshape of it: it is freed when the last of them is gone, never under a live view.  A context
+        closed while blocks are alive is freed with the last block."""
         dtype = np.dtype(dtype)
         n = int(np.prod(shape))
+        nbytes = max(n * dtype.itemsize, 1)
         p = _P()
-        self._check(self.L.xHipHostAlloc(self.ctx, ctypes.byref(p), max(n * dtype.itemsize, 1)), "xHipHostAlloc")
-        owner = _PinnedBlock(self, p.value, (ctypes.c_char * max(n * dtype.itemsize, 1)).from_address(p.value))
-        arr = np.frombuffer(owner.buf, dtype=dtype, count=n).reshape(shape)
-        owner.keep(arr)
-        return arr
+        self._check(self.L.xHipHostAlloc(self.ctx, ctypes.byref(p), nbytes), "xHipHostAlloc")
+        owner = _PinnedBlock(self, p.value, nbytes)
+        return np.asarray(owner)[: n * dtype.itemsize].view(dtype).reshape(shape)
 
 
 class _PinnedBlock:
-    """Frees a pinned allocation when the last numpy view of it is gone."""
-    _live = {}
+    """Owner of one pinned allocation: numpy takes the memory through __array_interface__ and keeps this object as the base of
+    the array it builds, so every view's base chain ends here (a finalizer on ONE ndarray fired under live views)."""
 
-    def __init__(self, codec, ptr, buf):
-        self.codec, self.ptr, self.buf = codec, ptr, buf
+    def __init__(self, codec, ptr, nbytes):
+        self.codec, self.ptr, self.nbytes = codec, ptr, nbytes
+        codec._pinned_live = getattr(codec, "_pinned_live", 0) + 1
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
 
-    def keep(self, arr):
-        import weakref
-        _PinnedBlock._live[self.ptr] = self
-        weakref.finalize(arr, _PinnedBlock._release, self.ptr)
-
-    @staticmethod
-    def _release(ptr):
-        blk = _PinnedBlock._live.pop(ptr, None)
-        if blk is not None and getattr(blk.codec, "ctx", None):
-            blk.buf = None
-            blk.codec.L.xHipHostFree(blk.codec.ctx, ptr)
+    def __del__(self):
+        codec, ptr = self.codec, self.ptr
+        self.ptr = 0
+        if not ptr or codec is None:
+            return
+        try:
+            if getattr(codec, "ctx", None):
+                codec.L.xHipHostFree(codec.ctx, ptr)
+            codec._pinned_live -= 1
+            if codec._pinned_live == 0 and getattr(codec, "_close_pending", False):
+                codec.close()
+        except Exception:
+            pass

@@ -276,6 +276,7 @@ int post_transfers(x266hip_node *node, const std::vector<Xfer> &xs)
     if (node->transport == 0) {
         if (!node->have_rccl) return nfail(node, X266HIP_ECOMM, "RCCL did not initialise on this node");
         Rccl *R = rccl();
+        (void)hipGetLastError();                                          // the host's stale error is not this group's (see xHipNodeInit)
         N_NCCL(node, R->GroupStart());
         for (const Xfer &x : xs) {
             LocalRank &lr = node->local[(size_t)x.local];
@@ -386,6 +387,9 @@ int xHipNodeInit(x266hip_node **out, const int *devices, int n_devices)
         for (int i = 0; i < n_devices; ++i) devs[(size_t)i] = node->local[(size_t)i].device;
         int prev = -1;
         (void)hipGetDevice(&prev);
+        // the runtime's sticky "last error" belongs to whatever call of the host failed last (a refused launch, a failed allocation):
+        // cleared here so that a library which polls hipGetLastError() cannot mistake it for its own failure
+        (void)hipGetLastError();
         const ncclResult_t r = R->CommInitAll(comms.data(), n_devices, devs.data());
         if (prev >= 0) (void)hipSetDevice(prev);
         if (r == ncclSuccess) {
@@ -443,6 +447,7 @@ int xHipNodeInitRank(x266hip_node **out, int device, int rank, int world, const 
     std::memcpy(&u, id, sizeof u);
     {
         DeviceScope dev(device);
+        (void)hipGetLastError();                                          // see xHipNodeInit: the host's stale error is not this call's
         const ncclResult_t r = R->CommInitRank(&node->local[0].comm, world, u, rank);
         if (r != ncclSuccess) {
             std::fprintf(stderr, "x266hip: ncclCommInitRank(rank %d of %d): %s\n", rank, world, R->GetErrorString(r));
