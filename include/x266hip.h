@@ -263,6 +263,13 @@ typedef struct x266_intra_ref_t {
 } x266_intra_ref_t;
 int xIntra32PredictDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const uint8_t *d_modes,
                        const uint32_t *d_ref_index, uint8_t *d_pred, size_t n, void *stream);
+/* The encoder loop's form of intra coding, in ONE kernel: d_coef[i] = forward DCT32 (xDct32FwdBatchDev's transform,
+ * src_tb/dct32.c:66-170,180-198) of the residual d_src[i] - prediction(mode d_modes[i] on set d_ref_index[i] (NULL: set i)).
+ * The prediction never reaches memory: 1 KiB of source samples (row-major 32x32 uint8) + 144 bytes of references in, 2 KiB of
+ * coefficients out per block.  Bit-identical to xIntra32PredictDev -> residual -> xDct32FwdBatchDev.  Modes above 34 are
+ * undefined input, as for xIntra32PredictDev. */
+int xIntra32ResidualDct32Dev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const uint8_t *d_modes, const uint32_t *d_ref_index,
+                             const uint8_t *d_src, int16_t *d_coef, size_t n, void *stream);
 /* Intra mode decision (the sketch's "Decide" channel, IntraChannel_t :41-44): for block b with reference
  * set d_refs[b] and source samples d_src[b*1024 ..] (row-major 32x32, 16-byte aligned),
  * d_costs[b*35 + m] = sum over the sixteen 8x8 sub-blocks of satd8x8(src - prediction m)

@@ -12,10 +12,12 @@ compiled in place as oracle/_ref/libx266ref.so) on deterministic inputs:
   dct32_fwd.npz   inputs  [N,1024] int16 + outputs [N,1024] int16 + names
   satd8x8.npz     inputs  [N,64]   int16 + outputs [N] uint32     + names
   bdpi_dct32.npz  the BDPI call sequence of src/mkDct32.bsv:430-470 for the
-                  first 3 dct32_genNew() blocks of a fresh process (glibc
-                  rand(), default seed): getDiff words [3,16,32] uint32,
-                  getDct words [3,256] uint64, plus the raw blocks
-  bdpi_satd.npz   same for src/mkSatd.bsv:215-252, first 8 blocks
+                  11 dct32_genNew() blocks the testbench runs before $finish
+                  (passed 0..10, src/mkDct32.bsv:472-478) in a fresh process
+                  (glibc rand(), default seed): getDiff words [11,16,32]
+                  uint32, getDct words [11,256] uint64, plus the raw blocks
+  bdpi_satd.npz   same for src/mkSatd.bsv:215-252 at the testbench's own
+                  length, 256 blocks (cnt 0..255, src/mkSatd.bsv:235-252)
 
 Fixtures are data (inputs + expected outputs); no reference source is stored.
 """
@@ -62,14 +64,18 @@ def gen_satd(ref):
     print("satd8x8.npz:", x.shape, "blocks; edge results:", dict(zip(names[-len(edge):], y[-len(edge):].tolist())))
 
 
+TB_DCT_BLOCKS, TB_SATD_BLOCKS = 11, 256          # what mkTb runs before $finish (src/mkDct32.bsv:472-478, src/mkSatd.bsv:235-252)
+
+
 def bdpi_dct_child():
     ref = Reference()
     L = ref.lib
-    diffs = np.zeros((3, 16, 32), np.uint32)
-    words = np.zeros((3, 256), np.uint64)
-    mats = np.zeros((3, 1024), np.int16)
-    dcts = np.zeros((3, 1024), np.int16)
-    for b in range(3):
+    n = TB_DCT_BLOCKS
+    diffs = np.zeros((n, 16, 32), np.uint32)
+    words = np.zeros((n, 256), np.uint64)
+    mats = np.zeros((n, 1024), np.int16)
+    dcts = np.zeros((n, 1024), np.int16)
+    for b in range(n):
         L.dct32_genNew()
         mats[b] = np.ctypeslib.as_array(L.ref_dct32_last_input(), (1024,))
         dcts[b] = np.ctypeslib.as_array(L.ref_dct32_last_output(), (1024,))
@@ -87,7 +93,7 @@ def bdpi_dct_child():
 def bdpi_satd_child():
     ref = Reference()
     L = ref.lib
-    n = 8
+    n = TB_SATD_BLOCKS
     diffs = np.zeros((n, 8, 4), np.uint32)
     satd = np.zeros(n, np.uint32)
     mats = np.zeros((n, 64), np.int16)
@@ -100,7 +106,7 @@ def bdpi_satd_child():
             diffs[b, i] = np.frombuffer(res, np.uint32)
         satd[b] = L.satd8x8_getSatd()
     np.savez_compressed(os.path.join(HERE, "bdpi_satd.npz"), diff_words=diffs, satd=satd, blocks=mats)
-    print("bdpi_satd.npz: satd", satd.tolist())
+    print("bdpi_satd.npz: %d blocks, satd" % n, satd[:8].tolist(), "...")
 
 
 if __name__ == "__main__":

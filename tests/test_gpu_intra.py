@@ -104,3 +104,57 @@ def test_mode_decision_is_prediction_plus_satd(codec, oracle):
     sub = diff.reshape(9, 35, 4, 8, 4, 8).transpose(0, 1, 2, 4, 3, 5).reshape(-1, 64)
     sat = codec.satd8x8(sub).reshape(9, 35, 16).sum(axis=2)
     assert np.array_equal(costs, sat.astype(np.uint32))
+
+
+# ---- prediction -> residual -> forward DCT32 in one kernel (xIntra32ResidualDct32Dev, round 5) -----------------------------------
+def _want_coefficients(oracle, refs, modes, src, idx=None):
+    """the composition it fuses, on the host: oracle predictor -> src - pred (9-bit) -> the pinned forward transform"""
+    pred = oracle.intra32_predict(refs, modes, idx)
+    return oracle.dct32_fwd(src.astype(np.int16) - pred.astype(np.int16), threads=8)
+
+
+def test_residual_dct32_every_mode_every_border(codec, oracle):
+    refs = intra_refs_np(40, 0x1357)
+    modes = np.tile(np.arange(35, dtype=np.uint8), refs.shape[0])
+    idx = np.repeat(np.arange(refs.shape[0], dtype=np.uint32), 35)
+    src = np.random.RandomState(5).randint(0, 256, (modes.shape[0], 1024)).astype(np.uint8)
+    src[::7] = 255                                                     # extremes of the 9-bit residual
+    src[3::7] = 0
+    got = codec.intra32_residual_dct32(refs, modes, src, idx)
+    want = _want_coefficients(oracle, refs, modes, src, idx)
+    bad = np.argwhere((got != want).any(axis=1)).ravel()
+    assert bad.size == 0, [(int(idx[b]), int(modes[b])) for b in bad[:10]]
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 6, 7, 9, 63, 258, 1003])
+def test_residual_dct32_ragged_counts(codec, oracle, n):
+    """a wave takes four blocks: every remainder, one set per block (no index table)"""
+    refs = intra_refs_np(max(n, 1), 99 + n)[:n]
+    modes = ((np.arange(n) * 11 + 2) % 35).astype(np.uint8)
+    src = np.random.RandomState(n).randint(0, 256, (n, 1024)).astype(np.uint8)
+    got = codec.intra32_residual_dct32(refs, modes, src) if n else np.zeros((0, 1024), np.int16)
+    assert got.shape == (n, 1024)
+    if n:
+        assert np.array_equal(got, _want_coefficients(oracle, refs, modes, src))
+
+
+def test_residual_dct32_equals_the_three_kernels_it_fuses(codec, oracle):
+    """xIntra32PredictDev -> xResidual (host subtraction here) -> xDct32FwdBatchDev on 20 k blocks, device to device"""
+    nref, n = 600, 21000
+    refs = intra_refs_np(nref, 777)
+    rs = np.random.RandomState(9)
+    modes = rs.randint(0, 35, n).astype(np.uint8)
+    idx = rs.randint(0, nref, n).astype(np.uint32)
+    src = rs.randint(0, 256, (n, 1024)).astype(np.uint8)
+    got = codec.intra32_residual_dct32(refs, modes, src, idx)
+    pred = codec.intra32_predict(refs, modes, idx)
+    assert np.array_equal(got, codec.dct32_fwd(src.astype(np.int16) - pred.astype(np.int16)))
+    assert np.array_equal(got[:2000], _want_coefficients(oracle, refs, modes[:2000], src[:2000], idx[:2000]))
+
+
+def test_residual_dct32_rejects_bad_arguments(codec):
+    d = codec.alloc(8192)
+    with pytest.raises(x266_amd.X266Error):
+        codec.intra32_residual_dct32_dev(d.ptr, d.ptr, 0, d.ptr + 1024 + 4, d.ptr + 4096, 1)   # misaligned source
+    with pytest.raises(x266_amd.X266Error):
+        codec.intra32_residual_dct32_dev(d.ptr, d.ptr, 0, d.ptr + 1024, 0, 1)                  # NULL coefficients

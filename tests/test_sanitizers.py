@@ -83,7 +83,7 @@ def test_one_process_per_rank_under_asan_ubsan(ranks):
 
 @pytest.mark.gpu
 def test_bdpi_and_batch_hosts_under_asan_ubsan():
-    _run_host(_built("tb_protocol_asan"), ["dct", 3])
-    _run_host(_built("tb_protocol_asan"), ["satd", 8])
+    _run_host(_built("tb_protocol_asan"), ["dct", 11])
+    _run_host(_built("tb_protocol_asan"), ["satd", 256])
     _run_host(_built("batch_example_asan"), [])
     _run_host(_built("batch_example_asan"), [30011])      # 61 MB each way: the host-pointer calls run their three-slot pipeline and its download thread

@@ -68,6 +68,7 @@ def load_library():
     L.xHipGraphFree.argtypes = [_P, _P]
     L.xHipGraphFree.restype = None
     L.xIntra32CostsDev.argtypes = [_P, _P, _P, _P, _P, _SZ, _P]
+    L.xIntra32ResidualDct32Dev.argtypes = [_P, _P, _P, _P, _P, _P, _SZ, _P]
     L.xTransformFwdBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
     L.xConvInputFmtDev.argtypes = [_P, _P, _P, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
     L.xConvOutput420Dev.argtypes = [_P, _P, _P, ctypes.c_ssize_t, _P, _P, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, _P]
@@ -268,6 +269,29 @@ class Codec:
         self.intra32_predict_dev(d_r.ptr, d_m.ptr, d_i.ptr if d_i else 0, d_p.ptr, n)
         self.stream_sync()
         return d_p.download(np.uint8, n * 1024).reshape(n, 1024)
+
+    def intra32_residual_dct32_dev(self, d_refs, d_modes, d_ref_index, d_src, d_coef, n, stream=0):
+        self._check(self.L.xIntra32ResidualDct32Dev(self.ctx, d_refs, d_modes, d_ref_index or None, d_src, d_coef, n, stream), "xIntra32ResidualDct32Dev")
+
+    def intra32_residual_dct32(self, refs, modes, src, ref_index=None):
+        """Host convenience: refs [n_refs,129] uint8, modes [n], src [n,1024] uint8 -> coefficients [n,1024] int16."""
+        refs = np.ascontiguousarray(refs, np.uint8).reshape(-1, 129)
+        modes = np.ascontiguousarray(modes, np.uint8)
+        src = np.ascontiguousarray(src, np.uint8).reshape(-1, 1024)
+        n = modes.shape[0]
+        padded = np.zeros((refs.shape[0], 144), np.uint8)
+        padded[:, :129] = refs
+        d_r, d_m, d_s, d_c = self.alloc(max(padded.nbytes, 16)), self.alloc(max(n, 16)), self.alloc(max(n * 1024, 16)), self.alloc(max(n * 2048, 16))
+        d_r.upload(padded)
+        d_m.upload(modes)
+        d_s.upload(src)
+        d_i = None
+        if ref_index is not None:
+            d_i = self.alloc(max(4 * n, 16))
+            d_i.upload(np.ascontiguousarray(ref_index, np.uint32))
+        self.intra32_residual_dct32_dev(d_r.ptr, d_m.ptr, d_i.ptr if d_i else 0, d_s.ptr, d_c.ptr, n)
+        self.stream_sync()
+        return d_c.download(np.int16, n * 1024).reshape(n, 1024)
 
     def intra32_costs_dev(self, d_refs, d_src, d_costs, d_best_mode, n, stream=0):
         self._check(self.L.xIntra32CostsDev(self.ctx, d_refs, d_src, d_costs, d_best_mode or None, n, stream), "xIntra32CostsDev")

@@ -20,6 +20,7 @@
 
 #include "x266_device.hpp"
 #include "x266_hadamard.hpp"
+#include "x266_mfma_blocks.hpp"
 
 namespace x266 {
 namespace {
@@ -87,13 +88,16 @@ __device__ __forceinline__ void interpolate16(const unsigned char *p, uint32_t f
     }
 }
 
-// This lane's 16 samples (16h .. 16h+15) of line k = lane >> 1 of the prediction.  Lines are ROWS for
+// This lane's 16 samples (16h .. 16h+15) of line k of the prediction.  Lines are ROWS for
 // planar, DC and the vertical family, COLUMNS for the horizontal family (return value true).
 // left / top: the reference set in LDS (top[0] = corner); ext: 128 bytes of wave-private LDS scratch.
+// FRAGMENT_LANES false: (k, h) = (lane >> 1, lane & 1), consecutive lanes = consecutive bytes of the 1 KiB prediction (the stores);
+// true: (lane & 31, lane >> 5), the lane IS the A-operand fragment of the 32x32 matrix core (row k, K-slots 16h ..).
+template <bool FRAGMENT_LANES = false>
 __device__ __forceinline__ bool predict_line16(int mode, const unsigned char *left, const unsigned char *top,
                                                unsigned char *ext, int lane, uint32_t (&px)[4])
 {
-    const int k = lane >> 1, h = lane & 1;
+    const int k = FRAGMENT_LANES ? lane & 31 : lane >> 1, h = FRAGMENT_LANES ? lane >> 5 : lane & 1;
     if (mode >= 2) {
         const int angle = intra_angle(mode);
         const bool vertical = mode >= 18;
@@ -259,6 +263,91 @@ __global__ __launch_bounds__(256) void intra32_predict_kernel(const x266_intra_r
     }
 }
 
+// ---- prediction -> residual -> forward DCT32 in one kernel (round 5) ------------------------------------------------------
+// coef[i] = DCT32(src[i] - prediction(refs[ref_index[i]], modes[i])): the encoder loop's form of intra coding -- the chosen mode's
+// prediction is consumed where it is made and never reaches HBM (1 KiB of source + 144 B of references in, 2 KiB of coefficients
+// out, against 144 B + 1 KiB out for the predictor, 2 + 2 KiB + 2 KiB for residual formation and 2 + 2 KiB for the transform).
+// predict_line16<true> makes the prediction directly as the A-operand fragment of the 32x32 matrix core (lane = row, 16 samples of
+// half h); the horizontal family's columns are turned by the transposing LDS read addressed so that the RECEIVING lane is the
+// fragment lane.  The transform is linear before its first rounding, so pass 1 is G * src + (-G) * pred on the 8-bit samples as
+// they are -- one byte plane per operand, the +128 of the signed-offset trick cancels (dct32_from_tiles_kernel's scheme).
+// A wave takes kFusedUnits consecutive blocks and fetches everything they need UP FRONT (modes, set indices, the sets, the source
+// fragments): no loop-carried prefetch, so the compiler's own wait counts stay exact (every load is older than every store).
+constexpr int fused_slot_bytes(int units) { return 16 + units * kRawBytes + kExtBytes + 1024 + 2048; }   // raw sets | ext | column tile | output converter
+
+// lane (k, h) = (lane & 31, lane >> 5) holds samples 16h.. of COLUMN k; afterwards rows: the same lane holds row k, columns 16h..
+// (ds_read_b64_tr_b8, see turn_columns: receiving lane 16q + 8p + e gets row R + e of the 8x8 byte block the source lanes 16q + 2j + p
+// address; here R = 16 (q & 1) + 8 p and the blocks' columns are 16 (q >> 1) + j [+ 8 for the second read])
+__device__ __forceinline__ void turn_columns_to_fragment(unsigned char *cm, int lane, uint32_t (&px)[4])
+{
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<v4i *>(cm + (lane & 31) * 32 + (lane >> 5) * 16) = v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]};   // column-major tile
+    const int q = lane >> 4, s = lane & 15;
+    const unsigned src = (unsigned)(uintptr_t)cm + (unsigned)((16 * (q >> 1) + (s >> 1)) * 32 + 16 * (q & 1) + 8 * (s & 1));
+    u2 a, b;
+    asm volatile("ds_read_b64_tr_b8 %0, %2\n\tds_read_b64_tr_b8 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(src) : "memory");
+    px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y;
+}
+
+template <int kFusedUnits>
+__global__ __launch_bounds__(256) void intra32_residual_dct32_kernel(const x266_intra_ref_t *__restrict__ refs,
+                                                                     const uint8_t *__restrict__ modes,
+                                                                     const uint32_t *__restrict__ ref_index,
+                                                                     const uint8_t *__restrict__ src, int16_t *__restrict__ coef,
+                                                                     size_t n, const DctOps *__restrict__ ops, unsigned lds_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t unit0 = ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_wg) * (size_t)kFusedUnits;
+    if (unit0 >= n) return;
+    unsigned char *slot = lds + wave_in_wg * lds_per_wave;
+    unsigned char *raw = slot + 16, *ext = raw + kFusedUnits * kRawBytes, *tile = ext + kExtBytes, *conv = tile + 1024;
+    const int count = n - unit0 < (size_t)kFusedUnits ? (int)(n - unit0) : kFusedUnits;
+
+    // everything the wave's blocks need, issued at once: modes + set indices (lanes 0..3), then the sets (4 x 9 pieces of 16 bytes)
+    // and every block's source fragment (row lane & 31, bytes 16 (lane >> 5) ..: the instruction covers the block's 1 KiB whole)
+    const int ju = lane < count ? lane : count - 1;
+    const int my_mode = modes[unit0 + ju];
+    const uint32_t my_ref = ref_index ? ref_index[unit0 + ju] : (uint32_t)(unit0 + ju);
+    v4i sv[kFusedUnits];
+    const unsigned char *sp = src + unit0 * 1024 + (size_t)(lane & 31) * 32 + (size_t)(lane >> 5) * 16;
+#pragma unroll
+    for (int j = 0; j < kFusedUnits; ++j) sv[j] = load16<true>(sp + (size_t)(j < count ? j : count - 1) * 1024);
+    {
+        const int set = lane / 9, piece = lane - 9 * set;
+        const uint32_t r = (uint32_t)__shfl((int)my_ref, set < count ? set : 0);
+        if (lane < 9 * count) *reinterpret_cast<v4i *>(raw + lane * 16) = load16<true>(reinterpret_cast<const unsigned char *>(refs + r) + piece * 16);
+    }
+    const LaneConsts k = load_consts(ops, lane);
+    __builtin_amdgcn_wave_barrier();
+    const v4i bias = {(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
+    const v16i round1 = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};
+    const unsigned c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < kFusedUnits; ++j) {
+        if (j >= count) break;
+        const int mode = __builtin_amdgcn_readlane(my_mode, j);
+        const unsigned char *left = raw + j * kRawBytes, *top = left + 64;
+        uint32_t px[4];
+        if (predict_line16<true>(mode, left, top, ext, lane, px)) turn_columns_to_fragment(tile, lane, px);
+        const v4i pv = {(int)px[0], (int)px[1], (int)px[2], (int)px[3]};
+        v16i acc = mfma(sv[j] ^ bias, k.p1, round1);
+        acc = mfma(pv ^ bias, k.tr, acc);                         // k.tr = -p1 in the forward tables
+        v4i o0, o1;
+        fwd_finish<4, 11>(acc, k, o0, o1);
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<v4i *>(conv + lds_slot(c, 2 * h)) = o0;
+        *reinterpret_cast<v4i *>(conv + lds_slot(c, 2 * h + 1)) = o1;
+        __builtin_amdgcn_wave_barrier();
+        const v4i s0 = *reinterpret_cast<const v4i *>(conv + lds_slot(lane >> 2, lane & 3));
+        const v4i s1 = *reinterpret_cast<const v4i *>(conv + lds_slot(16 + (lane >> 2), lane & 3));
+        char *dst = reinterpret_cast<char *>(coef) + (unit0 + j) * 2048 + lane * 16;
+        store16_sc1nt(dst, s0);
+        store16_sc1nt(dst + 1024, s1);
+    }
+}
+
 // ---- mode decision ("Decide" channel of the RTL sketch, IntraChannel_t :41-44) ------------------
 // costs[b][m] = sum over the sixteen 8x8 sub-blocks of satd8x8(src - prediction m), m = 0..34, without
 // the predictions ever leaving the CU.  The Hadamard transform is linear and a 9-bit difference cannot
@@ -369,6 +458,20 @@ hipError_t launch_intra32_predict(const x266_intra_ref_t *d_refs, const uint8_t 
     // (not write-bound: capping the resident waves the way the write-only stream likes it -- 10 per CU, 7.4 TB/s -- slows this
     //  kernel from 5.4 to 3.2-5.1 TB/s written; it is paced by its own VALU + LDS work, profiles/r04_intra_occupancy.txt)
     hipLaunchKernelGGL(intra32_predict_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, d_refs, d_modes, d_ref_index, d_pred, n, rounds);
+    return hipGetLastError();
+}
+
+hipError_t launch_intra32_residual_dct32(const x266_intra_ref_t *d_refs, const uint8_t *d_modes, const uint32_t *d_ref_index, const uint8_t *d_src,
+                                         int16_t *d_coef, size_t n, const DctOps *d_fwd_ops, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    // launch shape (tools/gpu_intra_fused.py over units 1 / 2 / 4 / 7 x workgroup 64 / 128 / 256 x LDS charge, profiles/r05_intra_fused.txt): everything
+    // from 2 units per wave up lies within 3 %, occupancy caps only cost -- the kernel is paced by its VALU work (predictor + pass-2 epilogue)
+    constexpr int kUnitsPerWave = 4;
+    const size_t waves = (n + kUnitsPerWave - 1) / kUnitsPerWave, wgs = (waves + 3) / 4;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    constexpr unsigned per_wave = (unsigned)((fused_slot_bytes(kUnitsPerWave) + 15) & ~15);
+    hipLaunchKernelGGL(intra32_residual_dct32_kernel<kUnitsPerWave>, dim3((unsigned)wgs), dim3(256), 4 * per_wave, stream, d_refs, d_modes, d_ref_index, d_src, d_coef, n, d_fwd_ops, per_wave);
     return hipGetLastError();
 }
 

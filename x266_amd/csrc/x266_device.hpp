@@ -96,6 +96,8 @@ inline unsigned units_per_wave_for(const LaunchCfg &cfg, size_t n_units)
 
 hipError_t launch_intra32_predict(const x266_intra_ref_t *d_refs, const uint8_t *d_modes, const uint32_t *d_ref_index,
                                   uint8_t *d_pred, size_t n, int rounds, hipStream_t stream);
+hipError_t launch_intra32_residual_dct32(const x266_intra_ref_t *d_refs, const uint8_t *d_modes, const uint32_t *d_ref_index, const uint8_t *d_src,
+                                         int16_t *d_coef, size_t n, const DctOps *d_fwd_ops, hipStream_t stream);
 hipError_t launch_intra32_costs(const x266_intra_ref_t *d_refs, const uint8_t *d_src, uint32_t *d_costs, uint8_t *d_best_mode,
                                 size_t n, hipStream_t stream);
 hipError_t launch_satd8x8_butterfly(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks, const LaunchCfg &cfg, hipStream_t stream);

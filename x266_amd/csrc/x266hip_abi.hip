@@ -526,6 +526,18 @@ int xIntra32PredictDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const u
     return X266HIP_OK;
 }
 
+int xIntra32ResidualDct32Dev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const uint8_t *d_modes, const uint32_t *d_ref_index,
+                             const uint8_t *d_src, int16_t *d_coef, size_t n, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (n && (!d_refs || !d_modes || !d_src || !d_coef || (((uintptr_t)d_refs | (uintptr_t)d_src | (uintptr_t)d_coef) & 15u) || ((uintptr_t)d_ref_index & 3u)))
+        return fail(ctx, X266HIP_EINVAL, "xIntra32ResidualDct32Dev: NULL or unaligned buffer");
+    X_DEV(ctx);
+    hipError_t e = launch_intra32_residual_dct32(d_refs, d_modes, d_ref_index, d_src, d_coef, n, ctx->d_fwd, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "intra residual + transform launch", e);
+    return X266HIP_OK;
+}
+
 int xIntra32CostsDev(x266hip_ctx *ctx, const x266_intra_ref_t *d_refs, const uint8_t *d_src,
                      uint32_t *d_costs, uint8_t *d_best_mode, size_t n, void *stream)
 {
