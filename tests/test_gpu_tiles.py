@@ -52,7 +52,7 @@ def test_pack_and_unpack(codec, oracle, w, h, strd):
     assert np.array_equal(ov.download(np.uint8, w * h // 4).reshape(h // 2, w // 2), v[:, :w // 2])
 
 
-@pytest.mark.parametrize("w,h", [(32, 32), (64, 96), (160, 96), (1920, 1088)])
+@pytest.mark.parametrize("w,h", [(32, 32), (64, 96), (160, 96), (224, 416), (1920, 1088), (3104, 1760)])
 def test_residual_then_transform_and_cost(codec, oracle, w, h):
     yc, uc, vc = _yuv(w, h, 21 + w)
     yp, up, vp = _yuv(w, h, 22 + w)
@@ -84,10 +84,14 @@ def test_residual_then_transform_and_cost(codec, oracle, w, h):
             codec.stream_sync()
             want = oracle.satd8x8(res, threads=8)
             assert np.array_equal(ds.download(np.uint32, n), want)
-            ds2 = codec.alloc(n * 4)                                   # fused: tiles -> costs in one kernel
-            codec.satd8x8_from_tiles_dev(dc.ptr, dp.ptr, w, h, ds2.ptr)
-            codec.stream_sync()
-            assert np.array_equal(ds2.download(np.uint32, n), want)
+            for variant in (0, 1, 3):                                  # fused: tiles -> costs in one kernel; by frame size / staged body / LDS-DMA body
+                codec.set_option("satd_variant", variant)
+                ds2 = codec.alloc(n * 4)
+                ds2.upload(np.full(n, 0xFFFFFFFF, np.uint32))
+                codec.satd8x8_from_tiles_dev(dc.ptr, dp.ptr, w, h, ds2.ptr)
+                codec.stream_sync()
+                assert np.array_equal(ds2.download(np.uint32, n), want), variant
+            codec.set_option("satd_variant", 0)
 
 
 def test_fused_transform_extreme_pixels(codec, oracle):

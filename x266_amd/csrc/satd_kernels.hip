@@ -372,6 +372,132 @@ __global__ __launch_bounds__(256) void satd8x8_from_tiles_kernel(const x266_ref_
     }
 }
 
+// ---- fused residual + SATD, large frames: the LDS-DMA body (round 5) -------------------------------------------------------
+// The same arithmetic fed the way satd8x8_dma_kernel is: the luma parts of a group's eight tiles of both frames go straight
+// from HBM into a 4 KiB LDS slot (global_load_lds_dwordx4, 4 instructions per group: 1 KiB = the 256 luma bytes of four
+// tiles, whole lines; the row swizzle of the slot is applied on the GLOBAL side), two slots per wave, a slot refilled as soon
+// as its fragments sit in registers, and the one wait per group counted by hand: a wave's vector memory operations retire in
+// issue order, so group i has landed when at most {the 4 DMA of the younger group + the cost stores issued since} are
+// outstanding.  The costs leave per group as before (two 64-byte runs of the raster): their store is counted, not avoided.
+template <bool CLAMP>
+__device__ __forceinline__ void tiles_dma_issue(const x266_ref_block_t *__restrict__ cur, const x266_ref_block_t *__restrict__ pred,
+                                                size_t first_tile, size_t n_tiles, const unsigned (&goff)[2], unsigned char *slot)
+{
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)slot;
+    if (!CLAMP) {
+        const char *c = reinterpret_cast<const char *>(cur + first_tile), *p = reinterpret_cast<const char *>(pred + first_tile);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\t"
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4 nt\n\t"
+                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4 nt\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(goff[0]), "v"(goff[1]), "s"(c), "s"(p), "s"(lds), "s"(lds + 1024u), "s"(lds + 2048u), "s"(lds + 3072u)
+                     : "memory");
+        return;
+    }
+    asm volatile("; ragged last group" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        size_t t = first_tile + goff[k] / 512u;                          // lanes past the frame's last tile re-read it (their costs are never stored)
+        if (t >= n_tiles) t = n_tiles - 1;
+        const unsigned in_tile = goff[k] & 511u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(cur + t) + in_tile),
+                                         (__attribute__((address_space(3))) void *)(slot + 1024 * k), 16, 0, 2 /* nt */);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(pred + t) + in_tile),
+                                         (__attribute__((address_space(3))) void *)(slot + 2048 + 1024 * k), 16, 0, 2 /* nt */);
+    }
+}
+
+__global__ __launch_bounds__(256) void satd8x8_from_tiles_dma_kernel(const x266_ref_block_t *__restrict__ cur,
+                                                                     const x266_ref_block_t *__restrict__ pred,
+                                                                     uint32_t *__restrict__ out, unsigned tiles_x, unsigned n_tiles,
+                                                                     unsigned groups_per_wave, unsigned lds_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 2 x 4 KiB per wave + occupancy padding
+    const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+    const unsigned wave_in_wg = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+    const unsigned n_groups = (n_tiles + 7) >> 3, full_groups = n_tiles >> 3;
+    const unsigned first = wave * groups_per_wave;
+    if (wave > 0xFFFFFFFFu / groups_per_wave || first >= n_groups) return;
+    const unsigned cnt = n_groups - first < groups_per_wave ? n_groups - first : groups_per_wave;
+    unsigned char *slots = stage + wave_in_wg * lds_per_wave;
+    // LDS position 16 * lane of 1 KiB instruction k holds row ((sr & 8) | ((sr & 7) ^ t)) of tile t = 4 k + (lane >> 4), sr = lane & 15
+    unsigned goff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const unsigned t = 4u * k + ((unsigned)lane >> 4), sr = (unsigned)lane & 15u;
+        goff[k] = t * 512u + ((sr & 8u) | ((sr & 7u) ^ t)) * 16u;
+    }
+    auto fetch = [&](unsigned g, unsigned char *slot) {
+        if (g < full_groups) tiles_dma_issue<false>(cur, pred, (size_t)g * 8, n_tiles, goff, slot);
+        else                 tiles_dma_issue<true>(cur, pred, (size_t)g * 8, n_tiles, goff, slot);
+    };
+    fetch(first, slots);
+    if (cnt > 1) fetch(first + 1, slots + 4096);
+    const SatdOperands H = make_satd_operands(lane);
+    const int sub_y = (n >> 1) & 1, sub_x = n & 1, lt8 = n >> 2;
+    unsigned frag[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = sub_y * 8 + 4 * half + r;
+        frag[r] = (unsigned)(lt8 * 256 + ((row & 8) | ((row & 7) ^ lt8)) * 16 + sub_x * 8);
+    }
+    const uint32_t S = 0x80808080u;                                     // pixels -> signed (offset cancels)
+    const v4i NEG = {(int)0xFEFEFEFEu, (int)0xFEFEFEFEu, (int)0xFEFEFEFEu, (int)0xFEFEFEFEu};
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (unsigned i = 0; i < cnt; ++i) {
+        unsigned char *slot = slots + (i & 1) * 4096;
+        // younger than group i's DMA: the 4 DMA of group i + 1 (when there is one) and the cost store of group i - 1 (issued after them)
+        if (i + 1 < cnt) { if (i) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else             { if (i) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_wave_barrier();
+        uint2 a[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[r] = *reinterpret_cast<const uint2 *>(slot + frag[r]);
+            b[r] = *reinterpret_cast<const uint2 *>(slot + 2048 + frag[r]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the fragments are in registers: the slot may be refilled
+        __builtin_amdgcn_wave_barrier();
+        if (i + 2 < cnt) fetch(first + i + 2, slot);
+        const v4i a0 = {(int)(a[0].x ^ S), (int)(a[0].y ^ S), (int)(a[1].x ^ S), (int)(a[1].y ^ S)};
+        const v4i a1 = {(int)(a[2].x ^ S), (int)(a[2].y ^ S), (int)(a[3].x ^ S), (int)(a[3].y ^ S)};
+        const v4i b0 = {(int)(b[0].x ^ S), (int)(b[0].y ^ S), (int)(b[1].x ^ S), (int)(b[1].y ^ S)};
+        const v4i b1 = {(int)(b[2].x ^ S), (int)(b[2].y ^ S), (int)(b[3].x ^ S), (int)(b[3].y ^ S)};
+        uint32_t sum = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const v4i h0 = t ? H.h10 : H.h00, h1 = t ? H.h11 : H.h01;
+            v16i acc = mfma(h0, a0, zero);
+            acc = mfma(h1, a1, acc);
+            acc = mfma(h0 ^ NEG, b0, acc);
+            acc = mfma(h1 ^ NEG, b1, acc);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const uint32_t pk = bperm((uint32_t)acc[2 * m + 1], (uint32_t)acc[2 * m], 0x05040100u) ^ 0x80008000u;
+                sum = __builtin_amdgcn_sad_u16(pk, 0x80008000u, sum);
+            }
+        }
+        sum += (uint32_t)__shfl_xor((int)sum, 32);
+        // raster position of the lane's block: the group's first tile by scalar division, the lane's own tile by a short walk
+        const unsigned t0 = (first + i) * 8u, ty0 = t0 / tiles_x, tx0 = t0 - ty0 * tiles_x;
+        unsigned tx = tx0 + (unsigned)lt8, ty = ty0;
+        while (tx >= tiles_x) { tx -= tiles_x; ++ty; }
+        const bool live = t0 + (unsigned)lt8 < n_tiles;
+        uint32_t *dst = out + ((size_t)ty * 2 + sub_y) * ((size_t)tiles_x * 2) + (size_t)tx * 2 + sub_x;
+        const uint32_t cost = (sum + 2) >> 2;
+        // ONE store instruction per group (some lane is always live: a group exists only with its first tile): the hand-counted waits rely on it
+        unsigned long long keep_exec;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(live && half == 0);
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tglobal_store_dword %1, %2, off\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep_exec) : "v"(dst), "v"(cost), "s"(mask) : "memory");
+    }
+}
+
 // ---- synthetic residual stream ---------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t index)
 {
@@ -452,13 +578,25 @@ hipError_t launch_frame_lanes(const int16_t *d_dct_in, int16_t *d_dct_out, size_
 }
 
 hipError_t launch_satd8x8_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, uint32_t *d_out,
-                                     int width, int height, hipStream_t stream)
+                                     int width, int height, int shape, hipStream_t stream)
 {
     const int tiles_x = width / 16;
     const size_t n_tiles = (size_t)tiles_x * (size_t)(height / 16);
     if (n_tiles == 0) return hipSuccess;
     const size_t groups = (n_tiles + 7) / 8;                            // one wave per 8 tiles, one-wave workgroups
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    // Large frames (the batch kernel's crossover): the LDS-DMA body, one group per one-wave workgroup, 8 KiB charged = 20 resident waves per CU --
+    // paired in one process it is 2.5 % faster than the staged body (0.350 against 0.359 ms for 2^24 blocks; two groups per wave 1.8 %, four-wave
+    // workgroups with deep pipelines 3-15 % SLOWER: the tile format reads 256 of every 512 bytes, the short-lived dispatch-ordered shape keeps
+    // the half-dense stream together; profiles/r05_from_tiles_dma.txt).  shape 1 / 3 force a body (tests).
+    const bool dma = shape == 3 || (shape == 0 && n_tiles * 4 >= kSatdDmaMinBlocks);
+    if (dma && n_tiles <= 0xFFFFFFFFull) {
+        constexpr unsigned kGroupsPerWave = 1, kLdsPerWave = 8192;
+        const size_t waves = (groups + kGroupsPerWave - 1) / kGroupsPerWave;
+        hipLaunchKernelGGL(satd8x8_from_tiles_dma_kernel, dim3((unsigned)waves), dim3(64), (size_t)kLdsPerWave, stream, d_cur, d_pred, d_out,
+                           (unsigned)tiles_x, (unsigned)n_tiles, kGroupsPerWave, kLdsPerWave);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(satd8x8_from_tiles_kernel, dim3((unsigned)groups), dim3(64), (size_t)6144, stream, d_cur, d_pred, d_out, tiles_x, n_tiles);
     return hipGetLastError();
 }

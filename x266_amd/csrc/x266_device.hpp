@@ -116,7 +116,7 @@ hipError_t launch_dct32_from_tiles(const x266_ref_block_t *d_cur, const x266_ref
 hipError_t launch_transform_small_inv(int log2n, const int16_t *d_in, int16_t *d_out, size_t n_blocks, const DctOps *d_ops,
                                       const uint32_t *d_offsets, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_satd8x8_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, uint32_t *d_out,
-                                     int width, int height, hipStream_t stream);
+                                     int width, int height, int shape, hipStream_t stream);
 hipError_t launch_frame_lanes(const int16_t *d_dct_in, int16_t *d_dct_out, size_t n_dct, const DctOps *d_fwd_ops,
                               const int16_t *d_diff, uint32_t *d_satd_out, size_t n_satd, const LaunchCfg &satd_cfg, hipStream_t stream);
 hipError_t launch_satd8x8(const int16_t *d_diff, uint32_t *d_out, size_t n_blocks,

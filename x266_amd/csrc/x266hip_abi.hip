@@ -737,7 +737,7 @@ int xSatd8x8FromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const 
     if (!d_cur || !d_pred || !d_out || ((((uintptr_t)d_cur | (uintptr_t)d_pred)) & 15u) || ((uintptr_t)d_out & 3u))
         return fail(ctx, X266HIP_EINVAL, "xSatd8x8FromTilesDev: NULL or unaligned buffer");
     X_DEV(ctx);
-    hipError_t e = launch_satd8x8_from_tiles(d_cur, d_pred, d_out, width, height, (hipStream_t)stream);
+    hipError_t e = launch_satd8x8_from_tiles(d_cur, d_pred, d_out, width, height, ctx->satd_variant == 1 || ctx->satd_variant == 3 ? ctx->satd_variant : 0, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fused satd launch", e);
     return X266HIP_OK;
 }
