@@ -700,7 +700,7 @@ def leg_motion_search(b, keep):
     ncand = nb * (2 * rng + 1) ** 2
     me_steps = max(4, b.K // 4)
     out = {}
-    # VALU floors: 32 x v_sad_u16 (SATD) / 16 x v_sad_u8 (SAD) per 64 candidates, 4 cycles per wave64 instruction (tools/alubench), at the
+    # VALU floors: 32 x v_sad_u16 (SATD) / 16 x v_sad_u8 (SAD) per 64 candidates, 4 cycles per wave64 instruction (tools/probes/alubench), at the
     # 2.4 GHz the part is specified for and -- where sysfs shows it -- at the shader clock this box sustained during the leg
     for key, fn, per64, unit, floor_name, steps in (("satd8x8_me_search", codec.satd_search_dev, 32, "SATD/s", "v_sad_u16", max(me_steps, 40)),
                                                     ("sad8x8_me_search", codec.sad_search_dev, 16, "SAD/s", "v_sad_u8", max(me_steps, 60))):

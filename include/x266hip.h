@@ -434,7 +434,10 @@ void xNodeStreamFree(x266hip_nstream *s);
  * output rings of five or more (X266_STREAM_IN_RING / X266_STREAM_OUT_RING; they grew by one when the stream went from two to three
  * frames in flight, so a host sizes its rings by the constants, not by a number).  Input buffers may be SHARED between frames (they
  * are only read); an output buffer that overlaps the output of one of the previous X266_STREAM_OUT_RING - 1 frames of this stream
- * -- frames not yet flushed -- is refused with X266HIP_EINVAL: two frames in flight would write it.  *ticket (may be NULL) receives t. */
+ * -- frames not yet flushed -- is refused with X266HIP_EINVAL: two frames in flight would write it.  *ticket (may be NULL) receives t. 
+ * One process per GPU (xHipNodeInitRank): a push is a collective step.  A call that fails on ONE rank -- including an argument
+ * error only the root can detect (its buffers) -- leaves the other ranks' step unmatched; the failing rank's node is marked
+ * failed (every later call returns X266HIP_ECOMM) and the host must free the node on every rank, as after any ECOMM. */
 #define X266_STREAM_IN_RING  4
 #define X266_STREAM_OUT_RING 5
 int  xNodeStreamPush(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units,

@@ -237,7 +237,7 @@ def test_argument_errors(codec):
     assert L.xSatd8x8Batch(codec.ctx, None, None, 3) < 0
     assert L.xHipSetOption(codec.ctx, b"no_such_option", 1) < 0
     for key, bad in ((b"dct32_wg_threads", 96), (b"dct32_wg_threads", 512), (b"dct32_blocks_per_wave", 0), (b"satd_variant", 4),
-                     (b"satd_lds_bytes_per_wave", 1 << 20), (b"me_tile_rows", 9), (b"nontemporal", 11), (b"dct32_lds_stage", 0)):   # the last two: keys of rounds 1-3, gone
+                     (b"satd_lds_bytes_per_wave", 1 << 20), (b"satd_lds_bytes_per_wave", 16400), (b"satd_lds_bytes_per_wave", 6150), (b"me_tile_rows", 9), (b"nontemporal", 11), (b"dct32_lds_stage", 0)):   # the last two: keys of rounds 1-3, gone
         assert L.xHipSetOption(codec.ctx, key, bad) < 0, key                     # out of range: rejected, value unchanged
     assert codec.get_option("dct32_wg_threads") == 0                             # 0 = automatic (the default)
     assert b"" != L.xHipLastError(codec.ctx)

@@ -172,7 +172,7 @@ __device__ __forceinline__ bool predict_line16(int mode, const unsigned char *le
 // lane (k, h) holds samples 16h..16h+15 of COLUMN k in px[]; afterwards it holds 16 consecutive samples of a ROW and the return value
 // is their byte offset in the row-major 32x32 prediction.  The columns go to LDS as they are (a column-major tile, one b128 write per
 // lane) and come back through gfx950's transposing read, which turns 8x8 byte blocks: ds_read_b64_tr_b8 hands lane 16q + 8p + e, as
-// byte j, element e of the 8 bytes lane 16q + 2j + p addressed (tools/lds_tr8_read_test.hip).  Source lane 16q + 2j + p addresses
+// byte j, element e of the 8 bytes lane 16q + 2j + p addressed (tools/probes/lds_tr8_read_test.hip).  Source lane 16q + 2j + p addresses
 // column 16H + j (second read: + 8), rows R..R+7 of block (R, H) = (8 ((2q + p) & 3), (2q + p) >> 2); the receiving lane holds row
 // R + e, columns 16H..16H+15.  (Round 3 scattered the column with sixteen ds_write_b8 per lane.)
 __device__ __forceinline__ unsigned turn_columns(unsigned char *cm, int lane, uint32_t (&px)[4])
@@ -465,7 +465,7 @@ hipError_t launch_intra32_residual_dct32(const x266_intra_ref_t *d_refs, const u
                                          int16_t *d_coef, size_t n, const DctOps *d_fwd_ops, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    // launch shape (tools/gpu_intra_fused.py over units 1 / 2 / 4 / 7 x workgroup 64 / 128 / 256 x LDS charge, profiles/r05_intra_fused.txt): everything
+    // launch shape (tools/probes/gpu_intra_fused.py over units 1 / 2 / 4 / 7 x workgroup 64 / 128 / 256 x LDS charge, profiles/r05_intra_fused.txt): everything
     // from 2 units per wave up lies within 3 %, occupancy caps only cost -- the kernel is paced by its VALU work (predictor + pass-2 epilogue)
     constexpr int kUnitsPerWave = 4;
     const size_t waves = (n + kUnitsPerWave - 1) / kUnitsPerWave, wgs = (waves + 3) / 4;

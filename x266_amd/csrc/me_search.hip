@@ -108,7 +108,7 @@ __device__ __forceinline__ void hadamard_lane(const LaneOps &O, const v4i (&px)[
 }
 
 // 8x8 bytes at (row, col) of the LDS window -> the four K-step operands: three aligned dwords per row and a funnel shift.
-// (gfx950 does serve unaligned ds_read_b64 -- tools/lds_unaligned_test.hip -- which would save the 16 v_alignbit_b32, but at a
+// (gfx950 does serve unaligned ds_read_b64 -- tools/probes/lds_unaligned_test.hip -- which would save the 16 v_alignbit_b32, but at a
 // fraction of the aligned rate: 2.34 -> 2.49 ms per 4K frame, profiles/r03_me_variants.txt.)  The row offsets are immediates (kPitch).
 __device__ __forceinline__ void load_window8(const unsigned char *lds0, int win_offset, int row, int col, v4i (&px)[4])
 {

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void residual_luma_kernel(const x266_ref_block
 
 }  // namespace
 
-// Units per wave, measured (tools/gpu_tilefmt_probe.py, 32768^2 frame): unpacking gains 13 % from two units per wave (its planar
+// Units per wave, measured (tools/probes/gpu_tilefmt_probe.py, 32768^2 frame): unpacking gains 13 % from two units per wave (its planar
 // stores are half lines per instruction; more of them in flight per wave), packing and the residual kernels lose 3-10 %.
 constexpr int kUnitsPack = 1, kUnitsUnpack = 2, kUnitsResidual = 1;
 

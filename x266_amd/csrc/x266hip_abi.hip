@@ -408,7 +408,7 @@ static const OptionDesc kOptions[] = {
     {"dct32_wg_threads", &x266hip_ctx::dct_wg_threads, 0, 256, 64},
     {"satd_groups_per_wave", &x266hip_ctx::satd_groups_per_wave, 0, 4096, 1},
     {"satd_wg_threads", &x266hip_ctx::satd_wg_threads, 0, 256, 64},
-    {"satd_lds_bytes_per_wave", &x266hip_ctx::satd_lds_per_wave, 0, 65536, 1},
+    {"satd_lds_bytes_per_wave", &x266hip_ctx::satd_lds_per_wave, 0, 16384, 16},      // whole 16-byte rows; 16 KiB x the four waves of the largest workgroup = the 64 KiB a launch may ask for
     {"tile_tiles_per_wave", &x266hip_ctx::tile_tiles_per_wave, 0, 64, 1},
     {"me_tile_rows", &x266hip_ctx::me_tile_rows, 0, 8, 1},
 };

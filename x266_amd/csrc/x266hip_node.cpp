@@ -811,8 +811,13 @@ int stream_step(x266hip_nstream *s, const void *const *d_in, void *const *d_out,
     bool posted = false;
     const int rc = stream_step_impl(s, d_in, d_out, units, producer_stream, has_frame, &posted);
     // a failure after the step's group was posted -- whatever its code: a per-rank launch can still refuse an argument there --
-    // or any non-argument failure before it: the other ranks will post a group this rank never joins
-    if (rc != X266HIP_OK && (posted || rc != X266HIP_EINVAL)) abort_comms(s->node);
+    // or any non-argument failure before it: the other ranks will post a group this rank never joins.  With one process per GPU that
+    // holds for ARGUMENT errors too: the checks that involve the root's buffers (NULL / unaligned / an output still in flight) run on
+    // the root only, the peers cannot see them and post step t regardless -- this rank's communicators are aborted and the
+    // node marked failed, so that every later call here says ECOMM instead of pairing step t+1 with the peers' step t; the peers learn
+    // of it the way they learn of any lost rank (their group never completes: the host tears the node down, include/x266hip.h).
+    const bool peers_elsewhere = !s->node->single_process && s->node->world > 1;
+    if (rc != X266HIP_OK && (posted || rc != X266HIP_EINVAL || peers_elsewhere)) abort_comms(s->node);
     return rc;
 }
 
