@@ -19,6 +19,11 @@ def e(x):
     return "%se%d" % (mant, int(ex))
 
 
+def km(leg):
+    """the leg's launch duration: the trimmed mean of round 5's lines, the mean of earlier ones"""
+    return leg.get("kernel_ms", leg.get("kernel_ms_mean"))
+
+
 def table(path):
     d = json.loads(open(path).read().strip().splitlines()[-1])
     a, r = d["also"], d["roofline"]
@@ -31,37 +36,44 @@ def table(path):
     add("---", "---", "---", "---", "---")
     add("`dct32_lds_kernel<fwd>` 2²⁰ blocks", f(r["kernel_ms_per_launch"]) + " ms", e(d["value"]) + " blocks", "**" + f(r["frac"]) + "**", "**" + f(r["frac_of_same_box_copy"]) + "** copy")
     i = a["dct32_inv"]
-    add("`dct32_lds_kernel<inv>`", f(i["kernel_ms_mean"]) + " ms", e(i["value"]), f(i["roofline"]["frac"]), f(i["roofline"]["frac_of_same_box_copy"]) + " copy")
+    add("`dct32_lds_kernel<inv>`", f(km(i)) + " ms", e(i["value"]), f(i["roofline"]["frac"]), f(i["roofline"]["frac_of_same_box_copy"]) + " copy")
     u = a["dct32_fwd_inv_fused"]
-    add("`dct32_fwdinv_lds_kernel` (6144 B/block)", f(u["kernel_ms_mean"]) + " ms", e(u["value"]), f(u["hbm_frac"]), f(u["frac_of_same_box_copy"]) + " copy")
+    add("`dct32_fwdinv_kernel` (6144 B/block)", f(km(u)) + " ms", e(u["value"]), f(u["hbm_frac"]), f(u["frac_of_same_box_copy"]) + " copy")
+    if "reconstruction_only" in u:
+        ro = u["reconstruction_only"]
+        add("… reconstruction only (`d_coef = NULL`, 4096 B/block)", f(km(ro)) + " ms", e(ro["value"]), f(ro["hbm_frac"]), f(ro["frac_of_same_box_copy"]) + " copy")
     s = a["satd8x8"]
-    add("`satd8x8_dma_kernel` 2²⁴ blocks", f(s["kernel_ms_mean"]) + " ms", e(s["value"]) + " blocks", "**" + f(s["roofline"]["frac"]) + "**", "**" + f(s["roofline"]["frac_of_same_box_read"]) + "** read")
+    add("`satd8x8_dma_kernel` 2²⁴ blocks", f(km(s)) + " ms", e(s["value"]) + " blocks", "**" + f(s["roofline"]["frac"]) + "**", "**" + f(s["roofline"]["frac_of_same_box_read"]) + "** read")
     for fam, tag in (("dct2", "`tr_fwd_small_lds_kernel` DCT-II"), ("dst7", "… DST-VII"), ("dct2_inv", "`tr_inv_small_lds_kernel` DCT-II"), ("dst7_inv", "… DST-VII")):
         c = [cl["%s_%dx%d" % (fam, n, n)] for n in (4, 8, 16)]
-        add(tag + " 4×4 / 8×8 / 16×16", " / ".join(f(x["kernel_ms_mean"]) for x in c) + " ms", " / ".join(e(x["value"]) for x in c), " / ".join(f(x["hbm_frac"], 2) for x in c),
+        add(tag + " 4×4 / 8×8 / 16×16", " / ".join(f(km(x)) for x in c) + " ms", " / ".join(e(x["value"]) for x in c), " / ".join(f(x["hbm_frac"], 2) for x in c),
             " / ".join(f(x["frac_of_same_box_copy"], 2) for x in c) + " copy")
-    o, oi, sv = mix["per_ctu_one_launch"], mix["per_ctu_one_launch_inverse"], mix["seven_calls_over_offset_tables"]
-    add("`tr_tiles_kernel` (configs[3], one launch) fwd / inv", f(o["kernel_ms_mean"]) + " / " + f(oi["kernel_ms_mean"]) + " ms", e(o["value"]) + " / " + e(oi["value"]) + " CTUs",
+    o, oi, sv = mix["per_ctu_one_launch"], mix["per_ctu_one_launch_inverse"], mix.get("seven_calls_over_offset_tables")
+    add("`tr_tiles_kernel` (configs[3], one launch) fwd / inv", f(km(o)) + " / " + f(km(oi)) + " ms", e(o["value"]) + " / " + e(oi["value"]) + " CTUs",
         f(o["hbm_frac"]) + " / " + f(oi["hbm_frac"]), f(o["frac_of_same_box_copy"]) + " / " + f(oi["frac_of_same_box_copy"]) + " copy")
-    add("seven calls over offset tables (comparison only)", f(sv["kernel_ms_mean"]) + " ms", e(sv["value"]) + " CTUs", f(sv["hbm_frac"]), f(sv["frac_of_same_box_copy"]))
+    if sv:
+        add("seven calls over offset tables (comparison only)", f(km(sv)) + " ms", e(sv["value"]) + " CTUs", f(sv["hbm_frac"]), f(sv["frac_of_same_box_copy"]))
     dt, st = ft["dct32_from_tiles"], ft["satd8x8_from_tiles"]
-    add("`dct32_from_tiles_kernel` / `satd8x8_from_tiles_kernel`", f(dt["kernel_ms_mean"]) + " / " + f(st["kernel_ms_mean"]) + " ms",
+    add("`dct32_from_tiles_kernel` / `satd8x8_from_tiles_kernel`", f(km(dt)) + " / " + f(km(st)) + " ms",
         e(dt["value"]) + " / " + e(st["value"]) + " blocks (two-kernel paths: " + e(ft["dct32_residual_then_transform"]["value"]) + " / " + e(ft["satd8x8_residual_then_cost"]["value"]) + ")",
         f(dt["hbm_frac"]) + " / " + f(st["hbm_frac"]), f(dt["frac_of_same_box_copy"]) + " copy / " + f(st["frac_of_same_box_read"]) + " read")
     cv = [fe[k] for k in ("conv_input_fmt", "conv_output_420", "residual_luma_32")]
-    add("`tile_convert_kernel` in / out, `residual_luma_kernel`", " / ".join(f(x["kernel_ms_mean"]) for x in cv) + " ms", " / ".join(f(x["GBps"] / 1e3, 2) for x in cv) + " TB/s",
+    add("`tile_convert_kernel` in / out, `residual_luma_kernel`", " / ".join(f(km(x)) for x in cv) + " ms", " / ".join(f(x["GBps"] / 1e3, 2) for x in cv) + " TB/s",
         " / ".join(f(x["hbm_frac"], 2) for x in cv), " / ".join(f(x["frac_of_same_box_copy"], 2) for x in cv) + " copy")
     sd = [fe[k] for k in ("sad_8x8", "sad_16x16", "sad_64x64")]
-    add("`sad_kernel` 8×8 / 16×16 / 64×64", " / ".join(f(x["kernel_ms_mean"]) for x in sd) + " ms", " / ".join(f(x["GBps"] / 1e3, 2) for x in sd) + " TB/s",
+    add("`sad_kernel` 8×8 / 16×16 / 64×64", " / ".join(f(km(x)) for x in sd) + " ms", " / ".join(f(x["GBps"] / 1e3, 2) for x in sd) + " TB/s",
         " / ".join(f(x["hbm_frac"], 2) for x in sd), " / ".join(f(x["frac_of_same_box_read"], 2) for x in sd) + " read")
     m, m2 = a["satd8x8_me_search"], a["sad8x8_me_search"]
-    add("`satd_search_kernel` one 4K frame, ±64", f(m["kernel_ms_mean"]) + " ms", e(m["value"]) + " SATD",
+    add("`satd_search_kernel` one 4K frame, ±64", f(km(m)) + " ms", e(m["value"]) + " SATD",
         f(m["frac_of_v_sad_u16_floor"]) + " of the `v_sad_u16` floor at 2.4 GHz, **" + f(m["frac_of_v_sad_u16_floor_at_sclk"]) + "** at the %d MHz sysfs showed during the leg" % m["sclk_mhz"], "–")
-    add("`sad_search_kernel`", f(m2["kernel_ms_mean"]) + " ms", e(m2["value"]) + " SAD",
+    add("`sad_search_kernel`", f(km(m2)) + " ms", e(m2["value"]) + " SAD",
         f(m2["frac_of_v_sad_u8_floor"]) + " of the `v_sad_u8` floor at 2.4 GHz, **" + f(m2["frac_of_v_sad_u8_floor_at_sclk"]) + "** at %d MHz" % m2["sclk_mhz"], "–")
     p, dc = it["predict"], it["decide_35_modes"]
-    add("`intra32_predict_kernel` 2.1e6 predictions", f(p["kernel_ms_mean"]) + " ms", e(p["value"]) + " predictions", f(p["written_hbm_frac"]) + " written", f(p["frac_of_same_box_write"]) + " write — NOT write-bound (§11)")
-    add("`intra32_costs_kernel` × 35 modes", f(dc["kernel_ms_mean"]) + " ms", e(dc["value"]) + " blocks = " + e(dc["satd8x8_per_s"]) + " SATD", "VALU-bound", "–")
+    add("`intra32_predict_kernel` 2.1e6 predictions", f(km(p)) + " ms", e(p["value"]) + " predictions", f(p["written_hbm_frac"]) + " written", f(p["frac_of_same_box_write"]) + " write — NOT write-bound (§11)")
+    add("`intra32_costs_kernel` × 35 modes", f(km(dc)) + " ms", e(dc["value"]) + " blocks = " + e(dc["satd8x8_per_s"]) + " SATD", "VALU-bound", "–")
+    if "predict_residual_dct32" in it:
+        pr = it["predict_residual_dct32"]
+        add("`intra32_residual_dct32_kernel` (predict → residual → DCT32, 3072 B/block)", f(km(pr)) + " ms", e(pr["value"]) + " blocks", f(pr["hbm_frac"]), f(pr["frac_of_same_box_copy"]) + " copy — VALU-paced (§11)")
     frame_bytes = 2 * (32400 * 2048) + 518400 * 128 + 518400 * 4
     add("node layer, one rank, 7680×4320 stream", "%.1f µs per frame (kernel %.1f)" % (s8["ms_per_frame"] * 1e3, s8["kernel_us"]),
         e(s8["frames_per_s"]) + " frames = " + e(s8["dct32_blocks_per_s"]) + " DCT32 + " + e(s8["satd8x8_blocks_per_s"]) + " SATD blocks",
@@ -79,14 +91,14 @@ def table(path):
 SQ_BEGIN, SQ_END = "<!-- sq-table:begin (tools/design_table.py) -->", "<!-- sq-table:end -->"
 SQ_ROWS = [  # (label, kernels of the derived section of <round>_pmc_sq_counters.csv)
     ("`dct32_lds_kernel` fwd / inv", ["dct32_lds_kernel<false>", "dct32_lds_kernel<true>"]),
-    ("`dct32_fwdinv_lds_kernel`", ["dct32_fwdinv_lds_kernel"]),
+    ("`dct32_fwdinv_kernel` with / without the coefficient output", ["dct32_fwdinv_kernel<2, true>", "dct32_fwdinv_kernel<2, false>"]),
     ("`satd8x8_dma_kernel` (round 3's staged kernel: 17.7 / 57 / 14 / 66)", ["satd8x8_dma_kernel"]),
-    ("`dct32_from_tiles_kernel` / `satd8x8_from_tiles_kernel`", ["dct32_from_tiles_kernel", "satd8x8_from_tiles_kernel"]),
+    ("`dct32_from_tiles_kernel` / `satd8x8_from_tiles_dma_kernel`", ["dct32_from_tiles_kernel", "satd8x8_from_tiles_dma_kernel"]),
     ("`tr_fwd_small_lds_kernel` 4×4 / 8×8 / 16×16", ["tr_fwd_small_lds_kernel<2>", "tr_fwd_small_lds_kernel<3>", "tr_fwd_small_lds_kernel<4>"]),
     ("`tr_inv_small_lds_kernel` 4×4 / 8×8 / 16×16", ["tr_inv_small_lds_kernel<2>", "tr_inv_small_lds_kernel<3>", "tr_inv_small_lds_kernel<4>"]),
     ("`tr_tiles_kernel` forward / inverse", ["tr_tiles_kernel<false>", "tr_tiles_kernel<true>"]),
     ("`satd_search_kernel` / `sad_search_kernel`", ["satd_search_kernel<8, false, 512, 4>", "sad_search_kernel<2, false>"]),
-    ("`intra32_predict_kernel` / `intra32_costs_kernel`", ["intra32_predict_kernel", "intra32_costs_kernel"]),
+    ("`intra32_predict_kernel` / `intra32_costs_kernel` / `intra32_residual_dct32_kernel`", ["intra32_predict_kernel", "intra32_costs_kernel", "intra32_residual_dct32_kernel<4>"]),
     ("`sad_kernel` 8×8 / 16×16 / 64×64", ["sad_kernel<2, 4>", "sad_kernel<4, 4>", "sad_kernel<8, 4>"]),
     ("`mem_ceiling_kernel` copy / read / write (the streams)", ["mem_ceiling_kernel<0, 2>", "mem_ceiling_kernel<1, 4>", "mem_ceiling_kernel<2, 2>"]),
 ]
