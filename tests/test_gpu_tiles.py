@@ -1,6 +1,8 @@
 """GPU (-m gpu): frame container conversion (xConvInputFmt / xConvOutput420 of src/x266.cpp on
 the device) and residual formation, against the oracle; plus the chain tiles -> residual ->
 DCT32 / SATD that an encoder would run."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -123,3 +125,35 @@ def test_argument_errors(codec):
     assert L.xConvInputFmtDev(codec.ctx, buf.ptr, None, buf.ptr, buf.ptr, 32, 32, 16, None) < 0
     assert L.xResidualLumaDev(codec.ctx, buf.ptr, buf.ptr, 48, 32, 32, buf.ptr, None) < 0                  # 48 % 32
     assert L.xResidualLumaDev(codec.ctx, buf.ptr, buf.ptr, 32, 32, 16, buf.ptr, None) < 0                  # edge
+
+
+def test_the_references_own_self_test_stimulus(codec, oracle):
+    """src/x266.cpp:614-643 (`#if TEST_xConvInputFmt`, compiled out upstream): tmp[i] = i over 32*16 + 2*32*16/4 bytes, two ref_block_t,
+    xConvInputFmt(blocks, &tmp[0], &tmp[256], &tmp[320], strd 32, 32 x 16) -- with the U and V planes deliberately INSIDE the luma
+    buffer -- then xConvOutput420 back.  The same call on the device: tiles equal the oracle's and a numpy statement of the layout
+    (ref_block_t, src/x266.cpp:56-63), the m_I part is not touched, and the round trip returns the planes."""
+    tmp = (np.arange(32 * 16 + 2 * 32 * 16 // 4) & 0xFF).astype(np.uint8)
+    d_tmp = codec.alloc(tmp.nbytes)
+    d_tmp.upload(tmp)
+    d_tiles = codec.alloc(2 * 512)
+    d_tiles.upload(np.full(2 * 512, 0xCD, np.uint8))                     # memset(blocks, 0xCD, sizeof(blocks)), :625
+    codec.conv_input_fmt_dev(d_tiles.ptr, d_tmp.ptr, d_tmp.ptr + 256, d_tmp.ptr + 320, 32, 32, 16)
+    codec.stream_sync()
+    tiles = d_tiles.download(np.uint8, 1024).reshape(2, 512)
+    y = tmp[:512].reshape(16, 32)
+    u = tmp[256:256 + 128].reshape(8, 16)
+    v = tmp[320:320 + 128].reshape(8, 16)
+    want = np.full((2, 512), 0xCD, np.uint8)
+    for t in range(2):
+        want[t, :256] = y[:, 16 * t:16 * t + 16].reshape(-1)
+        want[t, 256:384] = np.stack([u[:, 8 * t:8 * t + 8], v[:, 8 * t:8 * t + 8]], axis=-1).reshape(-1)
+    assert np.array_equal(tiles, want)
+    orc = np.full(1024, 0xCD, np.uint8)
+    oracle.lib.orc_conv_input_fmt(orc.ctypes.data_as(ctypes.c_void_p), tmp.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(tmp.ctypes.data + 256),
+                                  ctypes.c_void_p(tmp.ctypes.data + 320), ctypes.c_ssize_t(32), 32, 16)
+    assert np.array_equal(orc.reshape(2, 512)[:, :384], tiles[:, :384])
+    oy, ou, ov = codec.alloc(512), codec.alloc(128), codec.alloc(128)
+    codec.conv_output_420_dev(d_tiles.ptr, oy.ptr, 32, ou.ptr, ov.ptr, 16, 32, 16)
+    codec.stream_sync()
+    assert np.array_equal(oy.download(np.uint8, 512), y.reshape(-1))
+    assert np.array_equal(ou.download(np.uint8, 128), u.reshape(-1)) and np.array_equal(ov.download(np.uint8, 128), v.reshape(-1))

@@ -244,3 +244,25 @@ def test_search_harness_is_ten_lines_of_numpy(oracle):
                 b = by * (w // 8) + bx
                 assert np.array_equal(costs[b], c) and costs.shape[1] == span * span
                 assert cost[b] == c[first] and tuple(mv[b]) == (cands[first][1], cands[first][0])
+
+
+def test_tile_oracle_on_the_references_own_self_test_stimulus(oracle):
+    """The reference's only statement about its container is a compiled-out self-test (src/x266.cpp:614-643): tmp[i] = i, two
+    ref_block_t, xConvInputFmt(blocks, &tmp[0], &tmp[256], &tmp[320], 32, 32, 16), then xConvOutput420.  x266.cpp does not build here
+    (MSVC-isms), so the tile oracle stays pinned by reading; this runs the restatement on exactly that call -- chroma planes inside
+    the luma buffer included -- against a numpy statement of ref_block_t (src/x266.cpp:56-63) and checks the round trip."""
+    import ctypes
+    tmp = (np.arange(32 * 16 + 2 * 32 * 16 // 4) & 0xFF).astype(np.uint8)
+    blocks = np.full(1024, 0xCD, np.uint8)
+    P = ctypes.c_void_p
+    oracle.lib.orc_conv_input_fmt(P(blocks.ctypes.data), P(tmp.ctypes.data), P(tmp.ctypes.data + 256), P(tmp.ctypes.data + 320), ctypes.c_ssize_t(32), 32, 16)
+    y, u, v = tmp[:512].reshape(16, 32), tmp[256:384].reshape(8, 16), tmp[320:448].reshape(8, 16)
+    for t in range(2):
+        b = blocks[512 * t:512 * t + 512]
+        assert np.array_equal(b[:256].reshape(16, 16), y[:, 16 * t:16 * t + 16])                       # m_Y[16*16]
+        assert np.array_equal(b[256:384].reshape(8, 8, 2)[:, :, 0], u[:, 8 * t:8 * t + 8])             # m_C: U, V interleaved
+        assert np.array_equal(b[256:384].reshape(8, 8, 2)[:, :, 1], v[:, 8 * t:8 * t + 8])
+        assert np.all(b[384:] == 0xCD)                                                                 # m_I untouched
+    oy, ou, ov = np.zeros(512, np.uint8), np.zeros(128, np.uint8), np.zeros(128, np.uint8)
+    oracle.lib.orc_conv_output_420(P(blocks.ctypes.data), P(oy.ctypes.data), ctypes.c_ssize_t(32), P(ou.ctypes.data), P(ov.ctypes.data), ctypes.c_ssize_t(16), 32, 16)
+    assert np.array_equal(oy, y.reshape(-1)) and np.array_equal(ou, u.reshape(-1)) and np.array_equal(ov, v.reshape(-1))
