@@ -466,7 +466,7 @@ hipError_t launch_intra32_residual_dct32(const x266_intra_ref_t *d_refs, const u
 {
     if (n == 0) return hipSuccess;
     // launch shape (tools/probes/gpu_intra_fused.py over units 1 / 2 / 4 / 7 x workgroup 64 / 128 / 256 x LDS charge, profiles/r05_intra_fused.txt): everything
-    // from 2 units per wave up lies within 3 %, occupancy caps only cost -- the kernel is paced by its VALU work (predictor + pass-2 epilogue)
+    // from 2 units per wave up lies within 3 %, occupancy caps only cost -- the kernel runs at what its 1 : 2 read : write mix allows
     constexpr int kUnitsPerWave = 4;
     const size_t waves = (n + kUnitsPerWave - 1) / kUnitsPerWave, wgs = (waves + 3) / 4;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
