@@ -106,8 +106,10 @@ def test_headline_kernels_against_this_box(bench):
     assert rel["fused"] >= FLOORS["fused"] and rel["satd"] >= FLOORS["satd"], rel
 
 
-# fractions of the box's own copy / read / write stream; measured values and boxes in profiles/r04_perf_floor_calibration.txt
-FLOORS = {"fwd": 0.96, "inv": 0.92, "fused": 0.84, "satd": 0.88, "tiles_fwd": 0.91, "tiles_inv": 0.90, "intra_write": 0.64}
+# fractions of the box's own copy / read / write stream; measured values and boxes in profiles/r04_perf_floor_calibration.txt.  Round 5: where a process's buffers
+# land moves a kernel by 2-9 % against the stream on the same buffers (profiles/r05_placement.txt) and three attempts on the SAME buffers do not average that out:
+# the floors sit under the worst landing seen (forward 0.97-0.99, inverse 0.93-0.96, fused 0.86-0.90, SATD batch 0.87-0.94), a regression is still far below them
+FLOORS = {"fwd": 0.95, "inv": 0.90, "fused": 0.82, "satd": 0.85, "tiles_fwd": 0.91, "tiles_inv": 0.90, "intra_write": 0.64}
 
 
 def test_other_baseline_config_legs_against_this_box(bench):
