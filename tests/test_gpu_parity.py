@@ -141,7 +141,7 @@ def test_dct32_roundtrip_on_device(codec):
     assert err.max() <= 6 and err.mean() < 1.0                                      # same frozen bound as the oracle
 
 
-@pytest.mark.parametrize("n,per_wave,tpb,with_coef", [(1, 1, 64, True), (3, 2, 64, True), (257, 2, 256, False), (4099, 3, 128, True), (1500, 1, 64, False)])
+@pytest.mark.parametrize("n,per_wave,tpb,with_coef", [(1, 1, 64, True), (3, 2, 64, True), (257, 2, 256, False), (4099, 3, 128, True), (1500, 1, 64, False), (4101, 0, 0, False), (4101, 0, 0, True), (1001, 7, 192, False)])
 def test_dct32_fused_fwd_inv(codec, oracle, n, per_wave, tpb, with_coef):
     """xDct32FwdInvBatchDev == forward then inverse, bit for bit (coefficients and reconstruction),
     on realistic residuals and on full-range int16 (the inverse's clipping paths)."""

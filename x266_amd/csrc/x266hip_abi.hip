@@ -42,7 +42,7 @@ struct x266hip_ctx {
     // Launch options (xHipSetOption): A/B knobs, results never depend on them.  Defaults = the measured optimum.
     int dct_variant = 0;                            // 0 = matrix-core kernel, 2 = VALU butterfly (the comparison variant north_star asks for)
     int satd_variant = 0;                           // 0 = by batch size (staged kernel below 3 Mi blocks, LDS-DMA kernel from there), 1 = staged, 2 = VALU butterfly, 3 = LDS-DMA
-    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, dct_fwdinv_blocks_per_wave = 2;   // consecutive blocks one wave loops over (profiles/r01_launch_sweep.txt)
+    int dct_blocks_per_wave = 1, dct_inv_blocks_per_wave = 2, dct_fwdinv_blocks_per_wave = 0;   // consecutive blocks one wave loops over (profiles/r01_launch_sweep.txt)
     int satd_groups_per_wave = 0, satd_wg_threads = 0, satd_lds_per_wave = 0;                   // 0 = the chosen SATD kernel's own default (satd_kernels.hip, launch_satd8x8)
     int adaptive_per_wave = 1;                      // shrink the per-wave run on small batches
     int dct_wg_threads = 0;                         // workgroup size of the DCT32 / transform-set kernels; 0 = the measured best: one-wave workgroups (profiles/r01_wg_occupancy.txt), four-wave ones for the fused forward + inverse kernel (profiles/r05_fused_variants.txt)
@@ -404,7 +404,7 @@ static const OptionDesc kOptions[] = {
     {"satd_variant", &x266hip_ctx::satd_variant, 0, 3, 1},
     {"dct32_blocks_per_wave", &x266hip_ctx::dct_blocks_per_wave, 1, 4096, 1},
     {"dct32_inv_blocks_per_wave", &x266hip_ctx::dct_inv_blocks_per_wave, 1, 4096, 1},
-    {"dct32_fwdinv_blocks_per_wave", &x266hip_ctx::dct_fwdinv_blocks_per_wave, 1, 4096, 1},
+    {"dct32_fwdinv_blocks_per_wave", &x266hip_ctx::dct_fwdinv_blocks_per_wave, 0, 4096, 1},   // 0 = automatic: 2, and 4 when only the reconstruction is wanted
     {"dct32_wg_threads", &x266hip_ctx::dct_wg_threads, 0, 256, 64},
     {"satd_groups_per_wave", &x266hip_ctx::satd_groups_per_wave, 0, 4096, 1},
     {"satd_wg_threads", &x266hip_ctx::satd_wg_threads, 0, 256, 64},
@@ -486,7 +486,9 @@ int xDct32FwdInvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_coef,
         return fail(ctx, X266HIP_EINVAL, "xDct32FwdInvBatchDev: NULL or unaligned buffer");
     X_DEV(ctx);
     LaunchCfg cfg = cfg_for(ctx, 1);
-    cfg.units_per_wave = ctx->dct_fwdinv_blocks_per_wave;
+    // 2 blocks per wave with both outputs (the shape that held on every box); without the coefficient output the wave's traffic is a third less and
+    // its arithmetic the same: 4 blocks per wave, -7 % (profiles/r05_fused_variants.txt, last section)
+    cfg.units_per_wave = ctx->dct_fwdinv_blocks_per_wave ? ctx->dct_fwdinv_blocks_per_wave : (d_coef ? 2 : 4);
     if (!ctx->dct_wg_threads) cfg.wg_threads = 256;                     // the shape that held 0.73-0.76 of 8 TB/s on every box (profiles/r05_fused_variants.txt)
     cfg.lds_bytes_per_wave = x266hip_ctx::kFwdInvLdsPerWave;
     hipError_t e = launch_dct32_fwdinv(d_in, d_coef, d_recon, n, ctx->d_fwd, ctx->d_inv_acc, cfg, (hipStream_t)stream);
