@@ -1145,6 +1145,11 @@ def main():
             sys.stderr.flush()
             os._exit(0)
         b.dist.destroy_process_group()
+        # the library brought ROCm's HIP runtime, torch (control plane) was imported after it and bundles a second copy under the same SONAME: leave without
+        # running two sets of exit handlers over one runtime's state (a CPU session in that import order ended in "double free or corruption" at exit)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

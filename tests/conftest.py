@@ -16,9 +16,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 
 def pytest_collection_finish(session):
-    # a `-m gpu` session must reach its first test without torch in the process (see above); a CPU session may have it
-    if "gpu" == (session.config.getoption("-m") or "").strip():
-        assert "torch" not in sys.modules, "collecting the tests imported torch: its bundled HIP runtime / RCCL would serve the GPU test process"
+    # no session imports torch into pytest's own process (see above): the gloo tests use it in their worker processes only
+    assert "torch" not in sys.modules, "collecting the tests imported torch: its bundled HIP runtime / RCCL would serve the test process"
+
+
+def pytest_sessionfinish(session, exitstatus):
+    assert "torch" not in sys.modules, "a test imported torch into pytest's own process (see tests/conftest.py)"
 
 
 def pytest_configure(config):

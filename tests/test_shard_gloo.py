@@ -14,9 +14,10 @@ from x266_amd.shard import combine_checksums, me_stripe, shard_range
 
 
 class _Lazy:
-    """torch is imported by the first test that USES it, not when pytest collects this file: a `-m gpu` session collects every
-    file, and torch's bundled HIP runtime / RCCL (same SONAMEs as ROCm's) would then serve the whole GPU test process
-    (tests/conftest.py, tests/test_gpu_runtime.py)."""
+    """torch is imported where it is USED -- in the worker PROCESSES of these tests -- never by pytest's own process: a `-m gpu` session
+    collects every file, and torch's bundled HIP runtime / RCCL (same SONAMEs as ROCm's) would then serve the whole GPU test process
+    (tests/conftest.py, tests/test_gpu_runtime.py); and a CPU session that loaded libx266hip.so first (ROCm's runtime) and torch
+    afterwards ended in `double free or corruption` at interpreter exit (two owners of one runtime's state)."""
 
     def __init__(self, name):
         self._name = name
@@ -27,7 +28,20 @@ class _Lazy:
         return getattr(importlib.import_module(self._name), attr)
 
 
-torch, dist, mp = _Lazy("torch"), _Lazy("torch.distributed"), _Lazy("torch.multiprocessing")
+torch, dist = _Lazy("torch"), _Lazy("torch.distributed")
+
+
+def _spawn(fn, args, nprocs):
+    """torch.multiprocessing.spawn without torch in the parent: `nprocs` fresh interpreters (spawn context) run fn(rank, *args)"""
+    import multiprocessing
+    ctx = multiprocessing.get_context("spawn")
+    procs = [ctx.Process(target=fn, args=(r,) + tuple(args)) for r in range(nprocs)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    codes = [p.exitcode for p in procs]
+    assert codes == [0] * nprocs, "worker exit codes %r" % (codes,)
 
 
 def test_shard_range_partitions():
@@ -112,7 +126,7 @@ def _me_worker(rank, world, port, w, h, rng, n_stripes, tmpdir):
 def test_two_rank_sharded_motion_search_matches_whole_frame(oracle, tmp_path, world, n_stripes):
     from _util import me_frames
     w, h, rng = 48, 40, 6                             # 5 block rows: ragged stripes
-    mp.spawn(_me_worker, args=(world, _free_port(), w, h, rng, n_stripes, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_me_worker, (world, _free_port(), w, h, rng, n_stripes, str(tmp_path)), world)
     cur, refp = me_frames(w, h, rng, 0x3E, mv=(4, -3))
     mv, cost, _ = oracle.satd_search(cur, refp, rng, rng)
     assert np.array_equal(np.load(os.path.join(str(tmp_path), "me_mv.npy")), mv)
@@ -153,7 +167,7 @@ def _worker(rank, world, port, n_blocks, tmpdir):
 
 def test_two_rank_sharded_run_matches_single(oracle, tmp_path):
     n = 301                                                          # odd: ragged shards
-    mp.spawn(_worker, args=(2, _free_port(), n, str(tmp_path)), nprocs=2, join=True)
+    _spawn(_worker, (2, _free_port(), n, str(tmp_path)), 2)
     res = np.load(os.path.join(str(tmp_path), "res.npy"))
     z = oracle.dct32_fwd(oracle.fill_residual(n * 1024, 0x266))
     want = int(z.view(np.uint16).astype(np.uint64).sum())
@@ -184,8 +198,8 @@ def test_bench_spawns_its_own_ranks_when_run_plainly():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    import torch
-    if torch.cuda.is_available():
+    import x266_amd
+    if x266_amd.load_library().xHipDeviceCount() > 0:
         pytest.skip("a GPU box runs the real thing (tests/test_gpu_bench.py)")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-also"],
                        env=env, capture_output=True, text=True, timeout=300)
