@@ -103,6 +103,21 @@ def test_intra_random(codec, oracle, n, seed):
     assert np.all(costs[np.arange(m), modes[:m]] == 0)        # the block predicted by mode k costs nothing under mode k
 
 
+@fuzz(15)
+@given(n=st.integers(1, 200), n_sets=st.integers(1, 40), seed=st.integers(1, 1 << 30), indexed=st.booleans())
+def test_intra_residual_dct32_random(codec, oracle, n, n_sets, seed, indexed):
+    """xIntra32ResidualDct32Dev on random counts, modes, shared reference sets and sources against oracle predictor -> residual -> pinned transform"""
+    rs = np.random.RandomState(seed % (1 << 31))
+    refs = intra_refs_np(n_sets if indexed else n, seed)
+    modes = rs.randint(0, 35, n).astype(np.uint8)
+    idx = rs.randint(0, n_sets, n).astype(np.uint32) if indexed else None
+    src = rs.randint(0, 256, (n, 1024)).astype(np.uint8)
+    src[rs.randint(0, n)] = rs.choice([0, 255])                         # a flat extreme block: the residual's +-255 edge
+    got = codec.intra32_residual_dct32(refs, modes, src, idx)
+    pred = oracle.intra32_predict(refs, modes, idx)
+    assert np.array_equal(got, oracle.dct32_fwd(src.astype(np.int16) - pred.astype(np.int16)))
+
+
 @fuzz(30)
 @given(wb=st.integers(1, 14), hb=st.integers(1, 9), rng=st.integers(1, 24), tile_rows=st.sampled_from([0, 1, 2, 4, 8]),
        metric=st.sampled_from(["satd", "sad"]), seed=st.integers(1, 1 << 20))
