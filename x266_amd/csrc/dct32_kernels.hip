@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_kernel(const int16_t *__rest
     const unsigned lane_off = (unsigned)lane * 16u;
     const char *src = reinterpret_cast<const char *>(in) + first * 2048;
 
-    const LaneConsts kf = load_consts(fwd_ops, lane);
-    const LaneConsts ki = load_consts(inv_ops, lane);
+    LaneConsts kf = load_consts(fwd_ops, lane);
+    LaneConsts ki = load_consts(inv_ops, lane);
     v16i c2r;
     {
         const int *__restrict__ s0 = inv_ops->c2r[0], *__restrict__ s1 = inv_ops->c2r[32];
@@ -243,14 +243,9 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_kernel(const int16_t *__rest
 #pragma unroll
     for (unsigned j = 0; j < (unsigned)DEPTH; ++j)
         if (j < cnt) fetch(j, j);
-    // every compiler-visible load has landed before the loop: no s_waitcnt vmcnt of the compiler's inside it
-    {
-        v4i a = kf.p1, b = kf.p2, d = ki.p1, e = ki.p2;
-        int c1 = kf.c1, c2 = kf.c2, c3 = ki.c1;
-        asm volatile("" : "+v"(a), "+v"(b), "+v"(d), "+v"(e), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c2r));
-        const_cast<LaneConsts &>(kf).p1 = a; const_cast<LaneConsts &>(kf).p2 = b; const_cast<LaneConsts &>(ki).p1 = d; const_cast<LaneConsts &>(ki).p2 = e;
-        const_cast<LaneConsts &>(kf).c1 = c1; const_cast<LaneConsts &>(kf).c2 = c2; const_cast<LaneConsts &>(ki).c1 = c3;
-    }
+    // every compiler-visible load has landed before the loop (the empty asm reads the constants, so the compiler's wait sits HERE): no
+    // s_waitcnt vmcnt of the compiler's inside the loop
+    asm volatile("" : "+v"(kf.p1), "+v"(kf.p2), "+v"(kf.c1), "+v"(kf.c2), "+v"(ki.p1), "+v"(ki.p2), "+v"(ki.c1), "+v"(c2r));
     const int c2s0 = (1 << 10) + (h ? 0 : 128 * 2048);            // swapped pass 2: row v = acc_row(0, 0) = 0 carries the offset fix
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     constexpr unsigned kStoresPerBlock = COEF ? 4u : 2u;
