@@ -32,6 +32,8 @@ class FrameJob:
         self.res, self.coef2, self.recon = a(w * h * 2), a(w * h * 2), a(w * h * 2)
         self.refp = a((w + 2 * self.pad) * (h + 2 * self.pad))
         self.best = a((w // 8) * (h // 8) * 8)
+        self.n_blk = w * h // 1024                        # intra: one reference set and mode per 32x32 block, the cur plane's bytes as block-major source
+        self.irefs, self.imodes, self.icoef = a(self.n_blk * 144), a(self.n_blk), a(w * h * 2)
 
     def upload(self, seed):
         w, h, pad = self.w, self.h, self.pad
@@ -43,6 +45,9 @@ class FrameJob:
             self.u[i].upload(chroma[: w * h // 4])
             self.v[i].upload(chroma[w * h // 4:])
         self.refp.upload(refp)
+        rs = np.random.RandomState(seed)
+        self.irefs.upload(rs.randint(0, 256, self.n_blk * 144).astype(np.uint8))
+        self.imodes.upload(rs.randint(0, 35, self.n_blk).astype(np.uint8))
 
     def enqueue(self, st, with_search=True):
         cd, w, h = self.cd, self.w, self.h
@@ -52,6 +57,7 @@ class FrameJob:
         cd.satd8x8_from_tiles_dev(self.tiles[0].ptr, self.tiles[1].ptr, w, h, self.cost.ptr, st)
         cd.residual_luma_dev(self.tiles[0].ptr, self.tiles[1].ptr, w, h, 32, self.res.ptr, st)
         cd.dct32_fwd_inv_dev(self.res.ptr, self.coef2.ptr, self.recon.ptr, w * h // 1024, st)
+        cd.intra32_residual_dct32_dev(self.irefs.ptr, self.imodes.ptr, 0, self.y[0].ptr, self.icoef.ptr, self.n_blk, st)
         if not with_search:
             return
         stride = w + 2 * self.pad
@@ -60,7 +66,7 @@ class FrameJob:
     def results(self):
         w, h = self.w, self.h
         return [self.coef.download(np.int16, w * h), self.cost.download(np.uint32, w * h // 64), self.coef2.download(np.int16, w * h),
-                self.recon.download(np.int16, w * h), self.best.download(np.uint32, (w // 8) * (h // 8) * 2)]
+                self.recon.download(np.int16, w * h), self.best.download(np.uint32, (w // 8) * (h // 8) * 2), self.icoef.download(np.int16, w * h)]
 
 
 def test_graph_replay_equals_direct_calls(codec):
@@ -78,7 +84,7 @@ def test_graph_replay_equals_direct_calls(codec):
             job.enqueue(st)
             codec.stream_sync(st)
             direct = job.results()
-            for buf in (job.coef, job.cost, job.coef2, job.recon, job.best):   # wipe, then replay the graph
+            for buf in (job.coef, job.cost, job.coef2, job.recon, job.best, job.icoef):   # wipe, then replay the graph
                 buf.upload(np.zeros(buf.nbytes, np.uint8))
             codec.graph_launch(graph, st)
             codec.stream_sync(st)
