@@ -209,10 +209,15 @@ hipError_t launch_residual_luma(int block_edge, const x266_ref_block_t *d_cur, c
     const size_t n_units = (size_t)groups_x * (height / 16) * 2;
     if (n_units == 0) return hipSuccess;
     const size_t n_waves = (n_units + kUnitsResidual - 1) / kUnitsResidual;
-    if ((n_waves + 3) / 4 > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
-    if (block_edge == 32) hipLaunchKernelGGL((residual_luma_kernel<5, kUnitsResidual>), grid, block, 0, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
-    else                  hipLaunchKernelGGL((residual_luma_kernel<3, kUnitsResidual>), grid, block, 0, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
+    // two-wave workgroups, 20 KiB of LDS charged per workgroup = 16 resident waves per CU: paired in one process against round 4's shape (four-wave
+    // workgroups, no cap) 0.662 against 0.707 ms for the 32x32 order of a 32768^2 frame, 0.658 against 0.709 for the 8x8 order (-6.5 / -7 %:
+    // 0.81 of 8 TB/s, 0.97-0.98 of the box's copy stream; tools/probes/gpu_residual_shapes.py, profiles/r05_from_tiles_dma.txt)
+    constexpr unsigned kThreads = 128, kLdsPerWorkgroup = 20480;
+    const size_t wgs = (n_waves + 1) / 2;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)wgs), block(kThreads);
+    if (block_edge == 32) hipLaunchKernelGGL((residual_luma_kernel<5, kUnitsResidual>), grid, block, kLdsPerWorkgroup - 4 * 2048, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
+    else                  hipLaunchKernelGGL((residual_luma_kernel<3, kUnitsResidual>), grid, block, kLdsPerWorkgroup, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
     return hipGetLastError();
 }
 
