@@ -50,6 +50,7 @@ struct x266hip_ctx {
     int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (SATD search: 8, 4 or 2; SAD search: 2), else 2, 4, 8 (8: SATD search only; 1 is served by 2)
     // fixed launch shapes (options in rounds 1-3; their sweeps are frozen in profiles/r01_*.txt, r03_tiles_one_launch.txt)
     static constexpr int kDctLdsPerWave = 8192;     // 2 KiB used: at most 20 resident waves per CU
+    static constexpr int kDctInvLdsPerWave = 10240; // the DCT32 inverse: 16
     static constexpr int kFwdInvLdsPerWave = 12288; // fused forward + inverse: 6 KiB used (two DMA slots + the converter): 12 resident waves per CU
     static constexpr int kTileLdsPerWave = 8192;    // table + two tile slots = 6 KiB used
     static constexpr int kIntraRounds = 4;          // intra prediction: rounds of seven predictions per wave
@@ -136,6 +137,7 @@ LaunchCfg cfg_for(const x266hip_ctx *ctx, int op)
         c.units_per_wave = op == 1 ? ctx->dct_inv_blocks_per_wave : ctx->dct_blocks_per_wave;
         c.wg_threads = ctx->dct_wg_threads ? ctx->dct_wg_threads : 64;
         c.lds_bytes_per_wave = x266hip_ctx::kDctLdsPerWave;
+
         c.shape = 0;
     }
     return c;
@@ -149,7 +151,14 @@ int launch_op(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n,
         if (ctx->dct_variant == 2) e = launch_dct32_butterfly((const int16_t *)d_in, (int16_t *)d_out, n, s);   // VALU comparison variant
         else e = launch_dct32(false, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_fwd, cfg_for(ctx, 0), s);
         break;
-    case 1: e = launch_dct32(true, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_inv_lds, cfg_for(ctx, 1), s); break;
+    case 1: {
+        // the inverse does more arithmetic per tile than the forward: 10 KiB charged per wave = 16 resident waves per CU instead of 20 (paired sweep in one process: -1.8 %;
+        // the forward, the small transforms and their inverses keep 8 KiB, tools/probes/gpu_dct_family_shapes.py)
+        LaunchCfg cfg = cfg_for(ctx, 1);
+        cfg.lds_bytes_per_wave = x266hip_ctx::kDctInvLdsPerWave;
+        e = launch_dct32(true, (const int16_t *)d_in, (int16_t *)d_out, n, ctx->d_inv_lds, cfg, s);
+        break;
+    }
     case 2:
         if (ctx->satd_variant == 2) e = launch_satd8x8_butterfly((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s);   // VALU comparison variant
         else e = launch_satd8x8((const int16_t *)d_in, (uint32_t *)d_out, n, cfg_for(ctx, 2), s);
