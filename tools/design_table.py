@@ -73,7 +73,7 @@ def table(path):
     add("`intra32_costs_kernel` × 35 modes", f(km(dc)) + " ms", e(dc["value"]) + " blocks = " + e(dc["satd8x8_per_s"]) + " SATD", "VALU-bound", "–")
     if "predict_residual_dct32" in it:
         pr = it["predict_residual_dct32"]
-        add("`intra32_residual_dct32_kernel` (predict → residual → DCT32, 3072 B/block)", f(km(pr)) + " ms", e(pr["value"]) + " blocks", f(pr["hbm_frac"]), f(pr["frac_of_same_box_copy"]) + " copy — VALU-paced (§11)")
+        add("`intra32_residual_dct32_kernel` (predict → residual → DCT32, 3072 B/block)", f(km(pr)) + " ms", e(pr["value"]) + " blocks", f(pr["hbm_frac"]), f(pr["frac_of_same_box_copy"]) + " copy — bound by its 1 : 2 read : write mix (§11)")
     frame_bytes = 2 * (32400 * 2048) + 518400 * 128 + 518400 * 4
     add("node layer, one rank, 7680×4320 stream", "%.1f µs per frame (kernel %.1f)" % (s8["ms_per_frame"] * 1e3, s8["kernel_us"]),
         e(s8["frames_per_s"]) + " frames = " + e(s8["dct32_blocks_per_s"]) + " DCT32 + " + e(s8["satd8x8_blocks_per_s"]) + " SATD blocks",
