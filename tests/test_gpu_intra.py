@@ -158,3 +158,39 @@ def test_residual_dct32_rejects_bad_arguments(codec):
         codec.intra32_residual_dct32_dev(d.ptr, d.ptr, 0, d.ptr + 1024 + 4, d.ptr + 4096, 1)   # misaligned source
     with pytest.raises(x266_amd.X266Error):
         codec.intra32_residual_dct32_dev(d.ptr, d.ptr, 0, d.ptr + 1024, 0, 1)                  # NULL coefficients
+
+
+def test_intra_kernels_beyond_4_gib(codec, oracle):
+    """Maximum sizes: 2^22 + 5 predictions (4 GiB + of predicted pixels) and 2^21 + 5 fused blocks (4 GiB + of coefficients): samples at the start,
+    across the 2^32-byte boundary of the output and at the ragged end are bit-exact with the oracle."""
+    n_sets = 4096
+    n_pred, n_fused = (1 << 22) + 5, (1 << 21) + 5
+    d_refs = codec.alloc(n_sets * 144)
+    codec.fill_residual_dev(d_refs.ptr, n_sets * 72, 0x1A7)                      # any bytes are a valid reference set
+    refs = d_refs.download(np.uint8, n_sets * 144).reshape(n_sets, 144)[:, :129]
+    q = np.arange(n_pred, dtype=np.uint64)
+    modes = ((q * 13 + q // 35) % 35).astype(np.uint8)
+    idx = ((q * 2654435761) % n_sets).astype(np.uint32)
+    d_modes, d_idx = codec.alloc(n_pred), codec.alloc(n_pred * 4)
+    d_modes.upload(modes)
+    d_idx.upload(idx)
+    d_out = codec.alloc(max(n_pred * 1024, n_fused * 2048))                      # predictions, then (same bytes) the fused kernel's coefficients
+    d_src = codec.alloc(n_fused * 1024)
+    codec.fill_residual_dev(d_src.ptr, n_fused * 512, 0x51C)
+
+    def sample(buf, first, count, dtype, unit):
+        out = np.empty(count * unit, dtype)
+        codec._check(codec.L.xHipMemcpyD2H(codec.ctx, out.ctypes.data, buf.ptr + first * unit * out.itemsize, out.nbytes), "D2H")
+        return out.reshape(count, unit)
+
+    codec.intra32_predict_dev(d_refs.ptr, d_modes.ptr, d_idx.ptr, d_out.ptr, n_pred)
+    codec.stream_sync()
+    for first, count in [(0, 40), ((1 << 22) - 20, 25), (n_pred - 36, 36)]:     # prediction 2^22 starts at byte 2^32
+        want = oracle.intra32_predict(refs, modes[first:first + count], idx[first:first + count])
+        assert np.array_equal(sample(d_out, first, count, np.uint8, 1024), want), first
+    codec.intra32_residual_dct32_dev(d_refs.ptr, d_modes.ptr, d_idx.ptr, d_src.ptr, d_out.ptr, n_fused)
+    codec.stream_sync()
+    for first, count in [(0, 40), ((1 << 21) - 20, 25), (n_fused - 36, 36)]:    # block 2^21's coefficients start at byte 2^32
+        src = sample(d_src, first, count, np.uint8, 1024)
+        want = _want_coefficients(oracle, refs, modes[first:first + count], src, idx[first:first + count])
+        assert np.array_equal(sample(d_out, first, count, np.int16, 1024), want), first

@@ -157,3 +157,41 @@ def test_the_references_own_self_test_stimulus(codec, oracle):
     codec.stream_sync()
     assert np.array_equal(oy.download(np.uint8, 512), y.reshape(-1))
     assert np.array_equal(ou.download(np.uint8, 128), u.reshape(-1)) and np.array_equal(ov.download(np.uint8, 128), v.reshape(-1))
+
+
+def test_tile_frames_beyond_4_gib(codec, oracle):
+    """Maximum sizes: a 65568 x 32768 frame = 8 392 704 tiles = 4.3 GB per tile array and per int16 output (and more than 2^31 pixels): 32x32 regions at the
+    start, around the tile whose byte offset is 2^32 and at the frame's last corner -- residual in both orders, fused transform, fused cost (LDS-DMA body)."""
+    w, h = 65536 + 32, 32768
+    tiles_x, nt = w // 16, (w // 16) * (h // 16)
+    assert nt * 512 > (1 << 32) and w * h > (1 << 31)
+    d_cur, d_pred = codec.alloc(nt * 512), codec.alloc(nt * 512)
+    codec.fill_residual_dev(d_cur.ptr, nt * 256, 0xC0)                 # any bytes are a valid tile array
+    codec.fill_residual_dev(d_pred.ptr, nt * 256, 0xC1)
+    d_res32, d_res8, d_coef, d_cost = codec.alloc(w * h * 2), codec.alloc(w * h * 2), codec.alloc(w * h * 2), codec.alloc(w * h // 64 * 4)
+    codec.residual_luma_dev(d_cur.ptr, d_pred.ptr, w, h, 32, d_res32.ptr)
+    codec.residual_luma_dev(d_cur.ptr, d_pred.ptr, w, h, 8, d_res8.ptr)
+    codec.dct32_fwd_from_tiles_dev(d_cur.ptr, d_pred.ptr, w, h, d_coef.ptr)
+    codec.satd8x8_from_tiles_dev(d_cur.ptr, d_pred.ptr, w, h, d_cost.ptr)
+    codec.stream_sync()
+
+    def fetch(buf, byte_off, count, dtype):
+        out = np.empty(count, dtype)
+        codec._check(codec.L.xHipMemcpyD2H(codec.ctx, out.ctypes.data, buf.ptr + byte_off, out.nbytes), "D2H")
+        return out
+
+    t_edge = (1 << 32) // 512                                          # the tile that starts at byte 2^32
+    regions = [(0, 0), (t_edge // tiles_x // 2, (t_edge % tiles_x) // 2), (h // 32 - 1, w // 32 - 1), (h // 32 - 1, 0), (h // 64, w // 32 - 1)]
+    for by, bx in regions:
+        four = lambda buf: np.concatenate([fetch(buf, ((2 * by + j) * tiles_x + 2 * bx) * 512, 1024, np.uint8) for j in (0, 1)])   # the region's 2 x 2 tiles
+        tc, tp = four(d_cur), four(d_pred)
+        r32 = oracle.residual_luma(tc, tp, 32, 32, 32)
+        blk = by * (w // 32) + bx
+        assert np.array_equal(fetch(d_res32, blk * 2048, 1024, np.int16), r32), (by, bx)
+        assert np.array_equal(fetch(d_coef, blk * 2048, 1024, np.int16), oracle.dct32_fwd(r32).ravel()), (by, bx)
+        r8 = oracle.residual_luma(tc, tp, 32, 32, 8).reshape(4, 4, 64)
+        want_cost = oracle.satd8x8(r8.reshape(16, 64)).reshape(4, 4)
+        for j in range(4):
+            first = (4 * by + j) * (w // 8) + 4 * bx                   # four consecutive 8x8 blocks of block row 4 by + j
+            assert np.array_equal(fetch(d_res8, first * 128, 256, np.int16), r8[j].ravel()), (by, bx, j)
+            assert np.array_equal(fetch(d_cost, first * 4, 4, np.uint32), want_cost[j]), (by, bx, j)
