@@ -54,3 +54,24 @@ def test_extremes_and_errors(codec):
     assert codec.L.xSadBatchDev(codec.ctx, 12, buf.ptr, buf.ptr, buf.ptr, 1, None) < 0
     assert codec.L.xSadBatchDev(codec.ctx, 8, None, buf.ptr, buf.ptr, 1, None) < 0
     assert codec.L.xSadBatchDev(codec.ctx, 8, None, None, None, 0, None) == 0
+
+
+@pytest.mark.parametrize("edge", [8, 64])
+def test_sad_batches_beyond_4_gib(codec, edge):
+    """Maximum sizes: 4 GiB + a ragged tail per input; samples at the start, across the 2^32-byte boundary and at the end against numpy."""
+    n = ((1 << 32) // (edge * edge)) + 5
+    da, db, dout = codec.alloc(n * edge * edge), codec.alloc(n * edge * edge), codec.alloc(n * 4)
+    codec.fill_residual_dev(da.ptr, n * edge * edge // 2, 0x5AD)                 # any bytes
+    codec.fill_residual_dev(db.ptr, n * edge * edge // 2, 0x5AE)
+    codec.sad_dev(edge, da.ptr, db.ptr, dout.ptr, n)
+    codec.stream_sync()
+
+    def fetch(buf, byte_off, count, dtype):
+        out = np.empty(count, dtype)
+        codec._check(codec.L.xHipMemcpyD2H(codec.ctx, out.ctypes.data, buf.ptr + byte_off, out.nbytes), "D2H")
+        return out
+
+    for first, count in [(0, 9), (n - 5 - 4, 9), (n - 3, 3)]:                    # block n - 5 starts at byte 2^32
+        a = fetch(da, first * edge * edge, count * edge * edge, np.uint8).reshape(count, -1).astype(np.int64)
+        b = fetch(db, first * edge * edge, count * edge * edge, np.uint8).reshape(count, -1).astype(np.int64)
+        assert np.array_equal(fetch(dout, first * 4, count, np.uint32), np.abs(a - b).sum(axis=1).astype(np.uint32)), (edge, first)

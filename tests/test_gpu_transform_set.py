@@ -185,3 +185,43 @@ def test_argument_errors(codec):
     assert L.xTransformFwdBatchDev(codec.ctx, 2, 32, buf.ptr, buf.ptr + 4096, 1, None, None) < 0     # size 32 is DCT-II only
     assert L.xTransformFwdBatchDev(codec.ctx, 0, 8, None, buf.ptr, 4, None, None) < 0
     assert L.xTransformFwdBatchDev(codec.ctx, 0, 8, None, None, 0, None, None) == 0
+
+
+def test_transform_set_beyond_4_gib(codec, oracle):
+    """Maximum sizes: 2^21 + 3 regions of 1024 samples (4 GiB + 6 KiB per buffer) through every (type, size) class of the set, both directions, and through
+    the one-launch tile kernel with the classes cycling: samples at the start, across the 2^32-byte boundary and at the end are bit-exact with the oracle."""
+    n_tiles = (1 << 21) + 3
+    din, dco, dre = codec.alloc(n_tiles * 2048), codec.alloc(n_tiles * 2048), codec.alloc(n_tiles * 2048)
+    codec.fill_residual_dev(din.ptr, n_tiles * 1024, 0x7E5)
+
+    def tiles(buf, first, count):
+        out = np.empty(count * 1024, np.int16)
+        codec._check(codec.L.xHipMemcpyD2H(codec.ctx, out.ctypes.data, buf.ptr + first * 2048, out.nbytes), "D2H")
+        return out.reshape(count, 1024)
+
+    spots = [(0, 6), ((1 << 21) - 3, 6), (n_tiles - 5, 5)]                       # tile 2^21 starts at byte 2^32
+    for ttype, n in [(0, 4), (0, 8), (0, 16), (1, 4), (1, 8), (1, 16)]:
+        nb = n_tiles * (1024 // (n * n))
+        codec.transform_fwd_dev(ttype, n, din.ptr, dco.ptr, nb)
+        codec.transform_inv_dev(ttype, n, dco.ptr, dre.ptr, nb)
+        codec.stream_sync()
+        for first, count in spots:
+            f = oracle.transform_fwd(ttype, n, tiles(din, first, count).reshape(-1, n * n))
+            assert np.array_equal(tiles(dco, first, count).reshape(-1, n * n), f), (ttype, n, first)
+            assert np.array_equal(tiles(dre, first, count).reshape(-1, n * n), oracle.transform_inv(ttype, n, f)), (ttype, n, first)
+    q = np.arange(n_tiles)
+    pick = ((q * 5 + q // 7) % len(CLASSES)).astype(np.int64)
+    tile_class = np.array([t * 4 + {4: 0, 8: 1, 16: 2, 32: 3}[n] for t, n in CLASSES], np.uint8)[pick]
+    dcls = codec.alloc(n_tiles)
+    dcls.upload(tile_class)
+    codec.transform_tiles_dev(False, din.ptr, dco.ptr, n_tiles, 0, dcls.ptr)
+    codec.transform_tiles_dev(True, dco.ptr, dre.ptr, n_tiles, 0, dcls.ptr)
+    codec.stream_sync()
+    for first, count in spots:
+        x, got_f, got_i = tiles(din, first, count), tiles(dco, first, count), tiles(dre, first, count)
+        for k in range(count):
+            ttype, n = CLASSES[pick[first + k]]
+            blk = x[k].reshape(-1, n * n)
+            f = oracle.dct32_fwd(blk) if n == 32 else oracle.transform_fwd(ttype, n, blk)
+            inv = oracle.dct32_inv(f) if n == 32 else oracle.transform_inv(ttype, n, f)
+            assert np.array_equal(got_f[k], f.ravel()) and np.array_equal(got_i[k], inv.ravel()), (first + k, ttype, n)
