@@ -75,7 +75,7 @@ int  xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap,
  *   "satd_variant"           0 by batch size (staged kernel below 3 Mi blocks, LDS-DMA kernel from there on), 1 staged kernel,
  *                            2 radix-2 butterflies on the vector ALU, 3 LDS-DMA kernel
  *                            (2 = the one comparison variant per kernel family north_star asks for)
- *   "dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "dct32_fwdinv_blocks_per_wave" (1 / 2 / 0 = automatic: 2, or 4 when d_coef is NULL)
+ *   "dct32_blocks_per_wave", "dct32_inv_blocks_per_wave", "dct32_fwdinv_blocks_per_wave" (1 / 2 / 0 = automatic: 2, or 8 when d_coef is NULL)
  *                            consecutive blocks (tiles, for the transform set's inverses) one wave loops over
  *   "dct32_wg_threads"       workgroup size of the DCT32 / transform-set kernels (64, 128, 192, 256; default 0 = the measured
  *                            best: 64, and 256 for the fused forward + inverse kernel)

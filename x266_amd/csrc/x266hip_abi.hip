@@ -413,7 +413,7 @@ static const OptionDesc kOptions[] = {
     {"satd_variant", &x266hip_ctx::satd_variant, 0, 3, 1},
     {"dct32_blocks_per_wave", &x266hip_ctx::dct_blocks_per_wave, 1, 4096, 1},
     {"dct32_inv_blocks_per_wave", &x266hip_ctx::dct_inv_blocks_per_wave, 1, 4096, 1},
-    {"dct32_fwdinv_blocks_per_wave", &x266hip_ctx::dct_fwdinv_blocks_per_wave, 0, 4096, 1},   // 0 = automatic: 2, and 4 when only the reconstruction is wanted
+    {"dct32_fwdinv_blocks_per_wave", &x266hip_ctx::dct_fwdinv_blocks_per_wave, 0, 4096, 1},   // 0 = automatic: 2, and 8 when only the reconstruction is wanted
     {"dct32_wg_threads", &x266hip_ctx::dct_wg_threads, 0, 256, 64},
     {"satd_groups_per_wave", &x266hip_ctx::satd_groups_per_wave, 0, 4096, 1},
     {"satd_wg_threads", &x266hip_ctx::satd_wg_threads, 0, 256, 64},
@@ -497,7 +497,7 @@ int xDct32FwdInvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_coef,
     LaunchCfg cfg = cfg_for(ctx, 1);
     // 2 blocks per wave with both outputs (the shape that held on every box); without the coefficient output the wave's traffic is a third less and
     // its arithmetic the same: 4 blocks per wave, -7 % (profiles/r05_fused_variants.txt, last section)
-    cfg.units_per_wave = ctx->dct_fwdinv_blocks_per_wave ? ctx->dct_fwdinv_blocks_per_wave : (d_coef ? 2 : 4);
+    cfg.units_per_wave = ctx->dct_fwdinv_blocks_per_wave ? ctx->dct_fwdinv_blocks_per_wave : (d_coef ? 2 : 8);   // paired over four boxes x three allocations (profiles/r05_fused_variants.txt): reconstruction only 2 -> 4 blocks per wave -8 %, 4 -> 8 another -1 to -4 %; with coefficients 2 is the steady one
     if (!ctx->dct_wg_threads) cfg.wg_threads = 256;                     // the shape that held 0.73-0.76 of 8 TB/s on every box (profiles/r05_fused_variants.txt)
     cfg.lds_bytes_per_wave = x266hip_ctx::kFwdInvLdsPerWave;
     hipError_t e = launch_dct32_fwdinv(d_in, d_coef, d_recon, n, ctx->d_fwd, ctx->d_inv_acc, cfg, (hipStream_t)stream);
