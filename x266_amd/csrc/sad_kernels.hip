@@ -79,14 +79,19 @@ __global__ __launch_bounds__(256) void sad_kernel(const uint8_t *__restrict__ a,
             for (int i = 0; i < PER; ++i) s = sad_chunk(va[g * PER + i], vb[g * PER + i], s);
             s = span_sum<64>(s);
             const size_t blk = chunk0 / CPB + g;
-            if (lane == 0 && blk < n_blocks) out[blk] = s;
+            if (lane == 0 && blk < n_blocks) store_result4(out + blk, s);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < STEPS; ++i) {
             const uint32_t s = span_sum<SPAN>(sad_chunk(va[i], vb[i], 0));
             const size_t blk = (chunk0 + 64 * i + lane) / CPB;
-            if ((lane & (SPAN - 1)) == 0 && blk < n_blocks) out[blk] = s;
+            if ((lane & (SPAN - 1)) == 0 && blk < n_blocks) {
+                // agent-scope result stores (x266_device.hpp) where they pay, paired A/B on four boxes (tools/gpu_ab_sad.py): 4x4 -1 to -3 %, 8x8 -3 to -4.5 %,
+                // 64x64 (above) -1 to -2.5 %; 16x16 0 to +3 % and 32x32 +4 to +6.5 % keep the plain store
+                if (LOGC <= 2) store_result4(out + blk, s);
+                else           out[blk] = s;
+            }
         }
     }
 }

@@ -144,7 +144,12 @@ __device__ __forceinline__ void satd8x8_lds_wave(const int16_t *__restrict__ dif
         __builtin_amdgcn_wave_barrier();
         const uint32_t cost = satd_group(H, w0, w1, w2, w3);
         const size_t b = g * 32 + blk;
-        if (b < n_blocks && half == 0) out[b] = cost;
+        if (b < n_blocks && half == 0) {
+            // agent-scope result store (x266_device.hpp) from 2^18 blocks on: -1 % at the 8K frame's 518 400 blocks, -12 % at 2^21; launch-bound batches
+            // (4096 .. 65536 blocks in 4.3 us) keep the plain store -- the write-through's acknowledgement lengthens their one round by 0.25 us
+            if (n_blocks >= ((size_t)1 << 18)) store_result4(out + b, cost);
+            else                               out[b] = cost;
+        }
     }
 }
 
@@ -237,11 +242,11 @@ __device__ __forceinline__ void satd8x8_dma_wave(const int16_t *__restrict__ dif
             const v4i c = *reinterpret_cast<const v4i *>(costs + lane * 4);
             __builtin_amdgcn_wave_barrier();
             uint32_t *dst = out + b0 + lane * 4;
-            if ((size_t)lane * 4 + 4 <= have) __builtin_nontemporal_store(c, reinterpret_cast<v4i_unaligned *>(dst));
+            if ((size_t)lane * 4 + 4 <= have) store_result16(dst, c);
             else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if ((size_t)lane * 4 + k < have) dst[k] = (uint32_t)c[k];
+                    if ((size_t)lane * 4 + k < have) store_result4(dst + k, (uint32_t)c[k]);
             }
         }
     }
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(256) void satd8x8_from_tiles_kernel(const x266_ref_
     sum += (uint32_t)__shfl_xor((int)sum, 32);
     if (live && half == 0) {
         const size_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        out[(ty * 2 + sub_y) * (size_t)(tiles_x * 2) + tx * 2 + sub_x] = (sum + 2) >> 2;
+        store_result4(out + ((ty * 2 + sub_y) * (size_t)(tiles_x * 2) + tx * 2 + sub_x), (sum + 2) >> 2);
     }
 }
 
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(256) void satd8x8_from_tiles_dma_kernel(const x266_
         // ONE store instruction per group (some lane is always live: a group exists only with its first tile): the hand-counted waits rely on it
         unsigned long long keep_exec;
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(live && half == 0);
-        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tglobal_store_dword %1, %2, off\n\ts_mov_b64 exec, %0"
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tglobal_store_dword %1, %2, off sc1\n\ts_mov_b64 exec, %0"
                      : "=&s"(keep_exec) : "v"(dst), "v"(cost), "s"(mask) : "memory");
     }
 }

@@ -58,6 +58,18 @@ __device__ __forceinline__ uint32_t sum_over_row16(uint32_t x)
     return x;
 }
 
+// Result streams -- a few bytes written per hundred read (SATD / SAD costs): agent-scope "sc1" stores without the streaming hint.  Measured on
+// the SATD batch, paired over eight allocation sets (profiles/r05_result_stores.txt): plain or sc0 0.360 ms, nt 0.334-0.360, sc1 nt 0.329-0.339,
+// sc1 or sc0 sc1 0.325-0.330 -- and the kernel no longer follows where its small output buffer landed.
+__device__ __forceinline__ void store_result16(void *p, const v4i &v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_result4(uint32_t *p, uint32_t v)    // a relaxed agent-scope store IS "global_store_dword ... sc1", and the compiler still counts it
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // SM: 0 plain, 1 nontemporal, 2 "sc1 nt"
 template <int SM>
 __device__ __forceinline__ void store16m(void *p, const v4i &v)
