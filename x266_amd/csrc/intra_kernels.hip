@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void intra32_predict_kernel(const x266_intra_r
             uint32_t px[4];
             unsigned at = (unsigned)lane * 16;                       // rows: lane (k, h) holds samples 16h.. of row k
             if (predict_line16(mode, left, top, ext, lane, px)) at = turn_columns(tile, lane, px);   // columns: turned through the tile
-            store16_sc1nt(pred + unit * 1024 + at, v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]});
+            store16_sc1(pred + unit * 1024 + at, v4i{(int)px[0], (int)px[1], (int)px[2], (int)px[3]});
         }
         if (more) {
             if (lane < 9 * kUnits) *reinterpret_cast<v4i *>(raw2 + ((rd + 1) & 1) * (kUnits * kRawBytes) + lane * 16) = sets;

@@ -41,6 +41,14 @@ __device__ __forceinline__ void store16_sc1nt(void *p, const v4i &v)
     asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v));
 }
 
+// the same store with agent scope only (no streaming hint): what the WRITE-ONLY intra predictor (long-lived waves) wants -- -1 to -6 % paired on the same
+// buffers at 1.0e6 / 2.1e6 / 4.2e6 predictions (profiles/r05_result_stores.txt).  Every kernel with a read stream beside its writes (the transforms, the fused
+// intra kernel) and the arithmetic-free copy / write streams themselves are fastest with "sc1 nt"
+__device__ __forceinline__ void store16_sc1(void *p, const v4i &v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v));
+}
+
 // ---- cross-lane sums without LDS traffic (a __shfl_xor is a ds_bpermute: address arithmetic, an LDS instruction and its latency) ----
 // x + (lane ^ 32's x): gfx950's v_permlane32_swap exchanges the upper half of one register with the lower half of another
 __device__ __forceinline__ uint32_t sum_with_other_half(uint32_t x)
