@@ -28,6 +28,11 @@ elif [ "$1" = "dma-load" ]; then
     variant libx266hip_ld$k.so "s/\\(global_load_lds_dwordx4 %[0-9], %[0-9]\\) nt/\\1 $mods/g"
     k=$((k+1))
   done
+elif [ "$1" = "indexed" ]; then   # the offset-table paths of the transform set (plain loads and stores as shipped): 0 shipped, 1 nt loads + sc1 nt stores (also the tile kernel with offsets), 2 stores only, 3 loads only
+  variant libx266hip_ix0.so "s/XXXX/XXXX/"
+  variant libx266hip_ix1.so "s/load16<!INDEXED>/load16<true>/" "s/store16m<INDEXED ? 0 : 2>/store16m<2>/" "s/tr_tiles_body<INVERSE, false>/tr_tiles_body<INVERSE, true>/"
+  variant libx266hip_ix2.so "s/store16m<INDEXED ? 0 : 2>/store16m<2>/"
+  variant libx266hip_ix3.so "s/load16<!INDEXED>/load16<true>/"
 else
-  echo "usage: $0 store | dma-load"; exit 1
+  echo "usage: $0 store | dma-load | indexed"; exit 1
 fi

@@ -119,8 +119,8 @@ __device__ __forceinline__ void tr_fwd_small_body(unsigned char *stage, size_t w
             if (!live0) o0 = total_bytes - 16;                           // ragged tail: stay inside the buffer
             if (!live1) o1 = total_bytes - 16;
         }
-        const v4i g0 = load16<!INDEXED>(reinterpret_cast<const char *>(in) + o0);   // streaming hints for contiguous batches only
-        const v4i g1 = load16<!INDEXED>(reinterpret_cast<const char *>(in) + o1);
+        const v4i g0 = load16<true>(reinterpret_cast<const char *>(in) + o0);   // streaming hints, offset tables included (round 5: -8 % on the per-class calls over a CTU-ordered buffer, profiles/r05_result_stores.txt)
+        const v4i g1 = load16<true>(reinterpret_cast<const char *>(in) + o1);
         *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
         *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
         __builtin_amdgcn_wave_barrier();
@@ -129,8 +129,8 @@ __device__ __forceinline__ void tr_fwd_small_body(unsigned char *stage, size_t w
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
         __builtin_amdgcn_wave_barrier();
-        if (live0) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o0, s0);   // contiguous: "sc1 nt" (x266_device.hpp)
-        if (live1) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o1, s1);
+        if (live0) store16m<2>(reinterpret_cast<char *>(out) + o0, s0);   // "sc1 nt" (x266_device.hpp)
+        if (live1) store16m<2>(reinterpret_cast<char *>(out) + o1, s1);
     }
 }
 
@@ -259,8 +259,8 @@ __device__ __forceinline__ void tr_inv_small_body(unsigned char *stage, size_t w
             if (!live0) o0 = total_bytes - 16;
             if (!live1) o1 = total_bytes - 16;
         }
-        const v4i g0 = load16<!INDEXED>(reinterpret_cast<const char *>(in) + o0);   // streaming hints for contiguous batches only
-        const v4i g1 = load16<!INDEXED>(reinterpret_cast<const char *>(in) + o1);
+        const v4i g0 = load16<true>(reinterpret_cast<const char *>(in) + o0);   // streaming hints, offset tables included (round 5: -8 % on the per-class calls over a CTU-ordered buffer, profiles/r05_result_stores.txt)
+        const v4i g1 = load16<true>(reinterpret_cast<const char *>(in) + o1);
         *reinterpret_cast<v4i *>(slot + lane * 16) = g0;
         *reinterpret_cast<v4i *>(slot + 1024 + lane * 16) = g1;
         __builtin_amdgcn_wave_barrier();
@@ -269,8 +269,8 @@ __device__ __forceinline__ void tr_inv_small_body(unsigned char *stage, size_t w
         const v4i s0 = *reinterpret_cast<const v4i *>(slot + lane * 16);
         const v4i s1 = *reinterpret_cast<const v4i *>(slot + 1024 + lane * 16);
         __builtin_amdgcn_wave_barrier();
-        if (live0) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o0, s0);   // contiguous: "sc1 nt" (x266_device.hpp)
-        if (live1) store16m<INDEXED ? 0 : 2>(reinterpret_cast<char *>(out) + o1, s1);
+        if (live0) store16m<2>(reinterpret_cast<char *>(out) + o0, s0);   // "sc1 nt" (x266_device.hpp)
+        if (live1) store16m<2>(reinterpret_cast<char *>(out) + o1, s1);
     }
 }
 
@@ -421,7 +421,7 @@ __device__ __forceinline__ void tile_of_class(unsigned char *slot, const unsigne
 // A wave takes its tiles two at a time: both tiles' data, their class bytes and (once) the table are requested with the
 // wave's first instructions and parked in LDS as they arrive -- nothing is held in registers across a tile's passes.
 // LDS per wave: table 2 KiB, two tile slots of 2 KiB.
-template <bool INVERSE, bool NT>
+template <bool INVERSE>
 __device__ __forceinline__ void tr_tiles_body(unsigned char *stage, size_t wave, const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t n_tiles,
                                               const uint32_t *__restrict__ tile_offsets,
                                               const uint8_t *__restrict__ tile_class, const TileTab *__restrict__ T,
@@ -440,8 +440,8 @@ __device__ __forceinline__ void tr_tiles_body(unsigned char *stage, size_t wave,
         const int cls0 = tile_class_of(tile_class, t), cls1 = tile_class_of(tile_class, two ? t + 1 : t);
         const size_t base0 = (tile_offsets ? (size_t)tile_offsets[t] : t * 1024) * 2;
         const size_t base1 = two ? (tile_offsets ? (size_t)tile_offsets[t + 1] : (t + 1) * 1024) * 2 : base0;
-        const v4i a0 = load16<NT>(reinterpret_cast<const char *>(in) + base0 + lane * 16);
-        const v4i a1 = load16<NT>(reinterpret_cast<const char *>(in) + base0 + 1024 + lane * 16);
+        const v4i a0 = load16<true>(reinterpret_cast<const char *>(in) + base0 + lane * 16);
+        const v4i a1 = load16<true>(reinterpret_cast<const char *>(in) + base0 + 1024 + lane * 16);
         if (first) {
             const char *src = reinterpret_cast<const char *>(T->b) + lane * 16;
             const v4i q0 = *reinterpret_cast<const v4i *>(src), q1 = *reinterpret_cast<const v4i *>(src + 1024);
@@ -450,8 +450,8 @@ __device__ __forceinline__ void tr_tiles_body(unsigned char *stage, size_t wave,
             first = false;
         }
         if (two) {
-            const v4i b0 = load16<NT>(reinterpret_cast<const char *>(in) + base1 + lane * 16);
-            const v4i b1 = load16<NT>(reinterpret_cast<const char *>(in) + base1 + 1024 + lane * 16);
+            const v4i b0 = load16<true>(reinterpret_cast<const char *>(in) + base1 + lane * 16);
+            const v4i b1 = load16<true>(reinterpret_cast<const char *>(in) + base1 + 1024 + lane * 16);
             *reinterpret_cast<v4i *>(slot1 + lane * 16) = b0;
             *reinterpret_cast<v4i *>(slot1 + 1024 + lane * 16) = b1;
         }
@@ -464,8 +464,8 @@ __device__ __forceinline__ void tr_tiles_body(unsigned char *stage, size_t wave,
             const v4i s0 = *reinterpret_cast<const v4i *>(slot0 + lane * 16);
             const v4i s1 = *reinterpret_cast<const v4i *>(slot0 + 1024 + lane * 16);
             char *dst = reinterpret_cast<char *>(out) + base0 + lane * 16;
-            store16m<NT ? 2 : 0>(dst, s0);
-            store16m<NT ? 2 : 0>(dst + 1024, s1);
+            store16m<2>(dst, s0);
+            store16m<2>(dst + 1024, s1);
         }
         if (two) {
             tile_of_class<INVERSE>(slot1, tab, lane, cls1);
@@ -473,8 +473,8 @@ __device__ __forceinline__ void tr_tiles_body(unsigned char *stage, size_t wave,
             const v4i s0 = *reinterpret_cast<const v4i *>(slot1 + lane * 16);
             const v4i s1 = *reinterpret_cast<const v4i *>(slot1 + 1024 + lane * 16);
             char *dst = reinterpret_cast<char *>(out) + base1 + lane * 16;
-            store16m<NT ? 2 : 0>(dst, s0);
-            store16m<NT ? 2 : 0>(dst + 1024, s1);
+            store16m<2>(dst, s0);
+            store16m<2>(dst + 1024, s1);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -489,8 +489,7 @@ __global__ __launch_bounds__(256) void tr_tiles_kernel(const int16_t *__restrict
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;       // read before the branch
-    if (tile_offsets) tr_tiles_body<INVERSE, false>(stage, wave, in, out, n_tiles, tile_offsets, tile_class, T, tiles_per_wave, lds_per_wave);
-    else              tr_tiles_body<INVERSE, true>(stage, wave, in, out, n_tiles, tile_offsets, tile_class, T, tiles_per_wave, lds_per_wave);
+    tr_tiles_body<INVERSE>(stage, wave, in, out, n_tiles, tile_offsets, tile_class, T, tiles_per_wave, lds_per_wave);
 }
 
 }  // namespace
