@@ -15,18 +15,36 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 
 
-def _run(args):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]                      # exactly one JSON line
-    return json.loads(lines[0])
+def _line_and_full(out, cwd):
+    """stdout = exactly one compact JSON line (what the driver parses: < 8 KB, the contract's keys); the full record is the file it names"""
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.count("\n") == 1 and out.stdout.startswith("{"), out.stdout[-2000:]
+    assert len(out.stdout) < 8192, len(out.stdout)
+    line = json.loads(out.stdout)
+    for k in CONTRACT:
+        assert k in line, k
+    full = json.load(open(os.path.join(cwd, line["full_record"])))
+    for k in ("metric", "value", "n_gpus", "steps", "warmup", "ms_per_step", "output_checksum_sum_i16"):
+        assert line[k] == full[k], k
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-4
+    return line, full
 
 
-def test_bench_small_run_has_every_leg_and_field():
-    d = _run(["--steps", "3", "--warmup", "1", "--dct-blocks", "8192", "--satd-blocks", "131072"])
+def _run(args, tmp):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=tmp, capture_output=True, text=True, timeout=900)
+    return _line_and_full(out, tmp)
+
+
+def test_bench_small_run_has_every_leg_and_field(tmp_path):
+    line, d = _run(["--steps", "3", "--warmup", "1", "--dct-blocks", "8192", "--satd-blocks", "131072"], str(tmp_path))
     for k in CONTRACT:
         assert k in d, k
+    # the driver's line: numbers only, every leg as one scalar, every boolean check of the run green, the chip named
+    assert line["checks_failed"] == [] and "error" not in line and "MI355X" in line["device"]
+    assert line["roofline"]["traffic"] == pytest.approx(d["roofline"]["traffic"], rel=1e-4) if d["roofline"]["traffic"] else line["roofline"]["traffic"] is None
+    assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["gpu_output_bit_exact_vs_cpu"] is True
+    for leg in ("dct32_inv", "dct32_fwd_inv_fused", "satd8x8", "satd8x8_me_search", "stream8k", "per_ctu_one_launch"):
+        assert isinstance(line["also"][leg], float), leg
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["value"] > 0 and d["scaling"] == "weak" and d["vs_baseline"] is None
     r = d["roofline"]
@@ -62,12 +80,13 @@ def test_bench_small_run_has_every_leg_and_field():
     assert "error" not in d
 
 
-def test_bench_two_ranks_share_the_gpu_and_agree_with_one_rank():
+def test_bench_two_ranks_share_the_gpu_and_agree_with_one_rank(tmp_path):
     """The N > 1 path of bench.py on a one-GPU box (X266_BENCH_SHARE_GPU: ranks share the device, control plane on gloo):
     every rank transforms its own slice of the one seeded stream, so two ranks x n blocks must give the output checksum
     of one rank x 2n blocks; the JSON reports n_gpus = 2 and the whole-job rate."""
     n = 16384
-    one = _run(["--steps", "3", "--warmup", "1", "--dct-blocks", str(2 * n), "--no-also", "--no-cpu-baseline", "--no-live-traffic"])
+    tmp = str(tmp_path)
+    _, one = _run(["--steps", "3", "--warmup", "1", "--dct-blocks", str(2 * n), "--no-also", "--no-cpu-baseline", "--no-live-traffic"], tmp)
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -76,11 +95,9 @@ def test_bench_two_ranks_share_the_gpu_and_agree_with_one_rank():
     env = dict(os.environ, X266_BENCH_SHARE_GPU="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--dct-blocks", str(n), "--no-also", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 only
-    two = json.loads(lines[0])
+                          "--dct-blocks", str(n), "--no-also", "--no-cpu-baseline"], cwd=tmp, env=env, capture_output=True, text=True, timeout=900)
+    line2, two = _line_and_full(out, tmp)                           # rank 0 only
+    assert len(line2["roofline"]["frac_by_rank"]) == 2 and line2["cpu_baseline"] is None
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["cpu_baseline"] is None
     assert two["output_checksum_sum_i16"] == one["output_checksum_sum_i16"]
     assert two["config"]["blocks_per_gpu"] == n
@@ -89,42 +106,36 @@ def test_bench_two_ranks_share_the_gpu_and_agree_with_one_rank():
     # that re-uses the single-GPU command shape would call it)
     env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--dct-blocks", str(n), "--no-also", "--no-cpu-baseline"], cwd=ROOT, env=env2, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    self_spawned = json.loads(lines[0])
+                          "--dct-blocks", str(n), "--no-also", "--no-cpu-baseline"], cwd=tmp, env=env2, capture_output=True, text=True, timeout=900)
+    _, self_spawned = _line_and_full(out, tmp)
     assert self_spawned["n_gpus"] == 2 and self_spawned["output_checksum_sum_i16"] == one["output_checksum_sum_i16"]
 
 
-def test_bench_node_legs_with_two_processes_under_the_rccl_model():
-    """bench.py --gpus 2 with its node-layer legs (stream8k, scatter-gather, sharded search) in two processes on this one GPU:
+@pytest.mark.parametrize("ranks", [2, 4, 8])
+def test_bench_node_legs_with_one_process_per_rank_under_the_rccl_model(ranks, tmp_path):
+    """bench.py --gpus N with its node-layer legs (stream8k, scatter-gather, sharded search) in N processes on this one GPU:
     control plane on gloo, the library's RCCL calls served by tests/rccl_model (multi-process mode).  The rates mean
-    nothing here; the legs must complete, match the single-device results, and leave exactly one JSON line."""
-    import socket
+    nothing here; the legs must complete, match the single-device results, and leave exactly one compact JSON line --
+    the command shape the driver's 1/2/4/8 scaling run uses (no 8-GPU node has been available to any round)."""
     model = os.path.join(ROOT, "tests", "rccl_model", "librccl_model.so")
     assert os.path.exists(model)
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    tmp = str(tmp_path)
     env = dict(os.environ, X266_BENCH_SHARE_GPU="1", X266HIP_RCCL_LIB=model, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    # no torchrun on the command line: bench.py --gpus 2 spawns its own ranks
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    # no torchrun on the command line: bench.py --gpus N spawns its own ranks
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1",
                           "--dct-blocks", "16384", "--satd-blocks", "65536", "--stream8k", "6", "--no-transform-set", "--no-cpu-baseline"],
-                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+                         cwd=tmp, env=env, capture_output=True, text=True, timeout=1500)
+    line, d = _line_and_full(out, tmp)
     also = d["also"]
-    assert "node_layer_error" not in also, also.get("node_layer_error")
+    assert "node_layer_error" not in also and "node_layer_error" not in line, also.get("node_layer_error")
+    assert line["n_gpus"] == ranks and line["rccl_ranks"] == ranks and line["checks_failed"] == [] and line["cpu_baseline"] is None
+    assert len(line["roofline"]["frac_by_rank"]) == ranks
     assert also["stream8k"]["bit_exact_vs_single_device"] is True and also["stream8k"]["frames"] == 6
     assert also["dct32_scatter_gather"]["value"] > 0
-    # the N > 1 line carries what a reader needs to judge the multi-device numbers: per-rank roofline fractions, the RCCL every rank
+    # the N > 1 record carries what a reader needs to judge the multi-device numbers: per-rank roofline fractions, the RCCL every rank
     # talks to, and the measured end-to-end rates NEXT TO the per-link prediction (153 GB/s per direction and peer)
-    assert len(d["roofline"]["frac_by_rank"]) == 2 and len(also["rccl_by_rank"]) == 2
-    assert also["dct32_scatter_gather"]["link_bound_blocks_per_s"] == pytest.approx(2 * 153e9 / 2048)
-    assert also["stream8k"]["link_bound_frames_per_s"] == pytest.approx(153e9 / ((32400 * 2048 + 518400 * 128) / 2))
-    assert also["satd8x8_me_search_sharded"]["identical_to_single_device"] is True and also["satd8x8_me_search_sharded"]["stripes"] == 2
+    assert len(d["roofline"]["frac_by_rank"]) == ranks and len(also["rccl_by_rank"]) == ranks
+    assert also["dct32_scatter_gather"]["link_bound_blocks_per_s"] == pytest.approx(ranks * 153e9 / 2048)
+    assert also["stream8k"]["link_bound_frames_per_s"] == pytest.approx(153e9 / ((32400 * 2048 + 518400 * 128) / ranks))
+    assert also["satd8x8_me_search_sharded"]["identical_to_single_device"] is True and also["satd8x8_me_search_sharded"]["stripes"] == ranks

@@ -72,24 +72,56 @@ def test_argument_errors(codec):
     assert L.xSatd8x8SearchDev(codec.ctx, None, 64, buf.ptr, 200, 64, 32, 8, buf.ptr, None, None) < 0
 
 
-def test_full_frame_4k_sampled(codec, oracle):
-    """BASELINE configs[2] at full size: 3840x2160, window +-64.  The oracle scores 32 of the 270 block rows (12 %;
-    whole-frame brute force is ~2e9 SATDs): every row of the first tile (top edge), of an interior tile and of the last,
-    partial tile (the default tile height at this size is 8 block rows, so these are all tile-boundary row classes), the
-    rows either side of two interior tile boundaries, and a spread of others."""
+def test_full_frame_4k_every_block(codec, oracle):
+    """BASELINE configs[2] at full size, checked WHOLE: 3840x2160, window +-64 -- all 129 600 (mv, cost) records against the
+    oracle's brute force (2.16e9 SATDs; the oracle is built -O3 and runs on every host thread: tens of seconds).  Rounds 1-5
+    checked 32 of the 270 block rows."""
     w, h, rng, pad = 3840, 2160, 64, 64
     cur, refp = me_frames(w, h, pad, 2160, mv=(5, -3), noise=4)
     mv, cost, _ = codec.satd_search(cur, refp, pad, rng)
-    assert (mv == [5, -3]).all(axis=1).mean() > 0.9
-    bxn = w // 8
-    spans = [(0, 8), (128, 136), (264, 270), (39, 41), (71, 73), (77, 78), (200, 204), (251, 252)]   # [first, last) block rows
-    assert sum(b - a for a, b in spans) >= 27
-    for a, b in spans:                                                  # one oracle call per span: its threads split block rows
-        cs = cur[a * 8:b * 8]
-        rs = refp[a * 8:b * 8 + 2 * pad]                                # these block rows' padded reference stripe
-        omv, ocost, _ = oracle.satd_search(cs, rs, pad, rng, threads=oracle.hw_threads())
-        assert np.array_equal(mv[a * bxn:b * bxn], omv), (a, b)
-        assert np.array_equal(cost[a * bxn:b * bxn], ocost), (a, b)
+    assert mv.shape == (129600, 2) and (mv == [5, -3]).all(axis=1).mean() > 0.9
+    omv, ocost, _ = oracle.satd_search(cur, refp, pad, rng, threads=min(270, oracle.hw_threads()))
+    assert np.array_equal(cost, ocost)
+    assert np.array_equal(mv, omv)                                      # same winner everywhere => same tie-break everywhere
+
+
+def test_full_frame_4k_cost_maps(codec, oracle):
+    """The cost-map form of the same 4K search ("64 blocks, every candidate's cost"): the launch writes all
+    129 600 x 16 641 costs (8.6 GB, stays in HBM); 64 blocks spread over the frame -- corners, edges, tile boundaries,
+    interior -- are downloaded and compared candidate by candidate with the oracle, and for EVERY block of the frame the
+    map's first minimum must be the (mv, cost) record the search-only kernel returns."""
+    w, h, rng, pad = 3840, 2160, 64, 64
+    span, ncand, bxn = 2 * rng + 1, (2 * rng + 1) ** 2, w // 8
+    nb = bxn * (h // 8)
+    cur, refp = me_frames(w, h, pad, 2160, mv=(5, -3), noise=4)
+    dc, dr, db, dcost = codec.alloc(cur.nbytes), codec.alloc(refp.nbytes), codec.alloc(nb * 8), codec.alloc(nb * ncand * 4)
+    dc.upload(cur)
+    dr.upload(refp)
+    codec.satd_search_dev(dc.ptr, w, dr.ptr + pad * refp.shape[1] + pad, refp.shape[1], w, h, rng, db.ptr, dcost.ptr)
+    codec.stream_sync()
+    raw = db.download(np.uint8, nb * 8)
+    mv = raw.view(np.int16).reshape(nb, 4)[:, :2]
+    cost = raw.view(np.uint32).reshape(nb, 2)[:, 1]
+    mv0, cost0, _ = codec.satd_search(cur, refp, pad, rng)              # the search-only kernel
+    assert np.array_equal(mv, mv0) and np.array_equal(cost, cost0)
+
+    def maps(first_block, count):                                       # [count, ncand] of the device's cost map
+        out = np.empty((count, ncand), np.uint32)
+        codec._check(codec.L.xHipMemcpyD2H(codec.ctx, out.ctypes.data, dcost.ptr + first_block * ncand * 4, out.nbytes), "xHipMemcpyD2H")
+        return out
+    # (block row, first block column) of eight 8-block runs = 64 blocks
+    runs = [(0, 0), (0, bxn - 8), (269, 0), (269, bxn - 8), (7, 100), (8, 236), (135, 0), (201, 333)]
+    for by, bx in runs:
+        got = maps(by * bxn + bx, 8)
+        _, _, want = oracle.satd_search(cur[by * 8:by * 8 + 8, bx * 8:bx * 8 + 64],
+                                        refp[by * 8:by * 8 + 8 + 2 * pad, bx * 8:bx * 8 + 64 + 2 * pad], pad, rng, want_costs=True)
+        assert np.array_equal(got, want), (by, bx)
+    step = 2048                                                         # 136 MB of map per download
+    for b0 in range(0, nb, step):
+        m = maps(b0, min(step, nb - b0))
+        k = m.argmin(axis=1)                                            # numpy: first occurrence = raster order = the tie-break
+        assert np.array_equal(m[np.arange(len(k)), k], cost[b0:b0 + len(k)]), b0
+        assert np.array_equal(np.stack([k % span - rng, k // span - rng], axis=1), mv[b0:b0 + len(k)]), b0
 
 
 @pytest.mark.parametrize("w,h,rng", [(640, 360, 64), (1280, 136, 64), (3840, 136, 64), (3840, 544, 64), (200, 72, 20), (1920, 1080, 64)])

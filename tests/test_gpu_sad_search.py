@@ -57,17 +57,12 @@ def test_argument_errors(codec):
         codec.sad_search_dev(d.ptr, 64, d.ptr + 4096, 80, 64, 16, 65, d.ptr + 32768)      # range > 64
 
 
-def test_full_frame_4k_sampled(codec, oracle):
-    """The SAD search at BASELINE configs[2]'s size (3840x2160, window +-64): 20 of the 270 block rows against the oracle's
-    brute force -- top edge, an interior stretch across tile boundaries (2-row tiles by default), bottom edge."""
+def test_full_frame_4k_every_block(codec, oracle):
+    """The SAD search at BASELINE configs[2]'s size (3840x2160, window +-64): all 129 600 records against the oracle's
+    brute force (rounds 3-5: 20 of the 270 block rows)."""
     w, h, rng, pad = 3840, 2160, 64, 64
     cur, refp = me_frames(w, h, pad, 2161, mv=(-7, 4), noise=4)
     mv, cost, _ = codec.satd_search(cur, refp, pad, rng, metric="sad")
     assert (mv == [-7, 4]).all(axis=1).mean() > 0.9
-    bxn = w // 8
-    for a, b in [(0, 4), (131, 139), (77, 78), (200, 202), (250, 251), (266, 270)]:       # [first, last) block rows, one oracle call each
-        cs = cur[a * 8:b * 8]
-        rs = refp[a * 8:b * 8 + 2 * pad]
-        omv, ocost, _ = oracle.satd_search(cs, rs, pad, rng, threads=oracle.hw_threads(), metric="sad")
-        assert np.array_equal(mv[a * bxn:b * bxn], omv), (a, b)
-        assert np.array_equal(cost[a * bxn:b * bxn], ocost), (a, b)
+    omv, ocost, _ = oracle.satd_search(cur, refp, pad, rng, threads=min(270, oracle.hw_threads()), metric="sad")
+    assert np.array_equal(cost, ocost) and np.array_equal(mv, omv)

@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -386,12 +387,45 @@ void xHipCodecFree(x266hip_ctx *ctx)
 
 const char *xHipLastError(const x266hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+// The chip's name for humans.  hipDeviceProp_t::name is EMPTY on this pool's ROCm 7.2 boxes (BENCH_r05's "device" read
+// "(gfx950:sramecc+:xnack-)"), so ask in turn: the property, hipDeviceGetName, the amdgpu driver's product_name in sysfs,
+// and last a table keyed on what the property block does carry (arch, CU count, peak clock) -- marked as such.
+static std::string device_marketing_name(const x266hip_ctx *ctx)
+{
+    auto trimmed = [](const char *s) {
+        std::string t(s ? s : "");
+        while (!t.empty() && (t.back() == ' ' || t.back() == '\n' || t.back() == '\r' || t.back() == '\t')) t.pop_back();
+        size_t b = 0;
+        while (b < t.size() && t[b] == ' ') ++b;
+        return t.substr(b);
+    };
+    std::string n = trimmed(ctx->prop.name);
+    if (!n.empty()) return n;
+    char buf[256] = {0};
+    if (hipDeviceGetName(buf, sizeof buf - 1, ctx->device) == hipSuccess && !(n = trimmed(buf)).empty()) return n;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus - 1, ctx->device) == hipSuccess) {
+        for (char *c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
+        const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/product_name";
+        if (FILE *f = std::fopen(path.c_str(), "r")) {
+            const bool got = std::fgets(buf, sizeof buf, f) != nullptr;
+            std::fclose(f);
+            if (got && !(n = trimmed(buf)).empty()) return n;
+        }
+    }
+    const std::string arch(ctx->prop.gcnArchName);
+    if (arch.rfind("gfx950", 0) == 0 && ctx->prop.multiProcessorCount == 256)       // the two 256-CU gfx950 parts differ in peak clock
+        return ctx->prop.clockRate >= 2300000 ? "AMD Instinct MI355X [by arch/CU/clock table]" : "AMD Instinct MI350X [by arch/CU/clock table]";
+    return "unnamed AMD GPU";
+}
+
 int xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap, int *cu_count, int *clock_mhz,
                    size_t *hbm_bytes)
 {
     if (!ctx) return X266HIP_EINVAL;
     if (name && name_cap) {
-        std::snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+        const std::string chip = device_marketing_name(ctx);
+        std::snprintf(name, name_cap, "%s (%s)", chip.c_str(), ctx->prop.gcnArchName);
     }
     if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
     if (clock_mhz) *clock_mhz = ctx->prop.clockRate / 1000;
