@@ -40,7 +40,7 @@ def test_bench_small_run_has_every_leg_and_field(tmp_path):
     for k in CONTRACT:
         assert k in d, k
     # the driver's line: numbers only, every leg as one scalar, every boolean check of the run green, the chip named
-    assert line["checks_failed"] == [] and "error" not in line and "MI355X" in line["device"]
+    assert line["checks_failed"] == [] and "error" not in line and "MI355" in line["device"]
     assert line["roofline"]["traffic"] == pytest.approx(d["roofline"]["traffic"], rel=1e-4) if d["roofline"]["traffic"] else line["roofline"]["traffic"] is None
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["gpu_output_bit_exact_vs_cpu"] is True
     for leg in ("dct32_inv", "dct32_fwd_inv_fused", "satd8x8", "satd8x8_me_search", "stream8k", "per_ctu_one_launch"):

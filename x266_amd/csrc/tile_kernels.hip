@@ -181,6 +181,60 @@ __global__ __launch_bounds__(256) void residual_luma_kernel(const x266_ref_block
     }
 }
 
+
+// ---- chroma residual --------------------------------------------------------------------------------------------------
+// A tile's chroma is ONE 128-byte line (m_C, src/x266.cpp:60: 8 rows of 8 interleaved U,V pairs, packed at :441-449).  One lane
+// takes one 16-byte row of it from both frames and emits 8 U and 8 V residuals (16 bytes each) -- the de-interleave is two
+// masks and two packed 16-bit subtractions per dword pair.  A wave takes eight horizontally adjacent tiles x eight rows:
+//   LOGB = 3 (one 8x8 U and one 8x8 V block per tile): lane = 8 * tile + row, a tile's eight lanes read its line and write its
+//            two blocks' 128 bytes each -- with block_pitch 1 the wave's U (and V) store is 1 KiB linear;
+//   LOGB = 5 (one 32x32 U and V block per 64x64 CTU = 4 x 4 tiles): lane = 32 * block + 4 * row + tile-in-block, so the eight
+//            rows x 64 bytes a tile row contributes to a block are one 512-byte run -- two runs per store instruction.
+// No LDS, no second pass: both forms read whole lines and write whole lines.
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+template <int LOGB>
+__global__ __launch_bounds__(128) void residual_chroma_kernel(const x266_ref_block_t *__restrict__ cur,
+                                                              const x266_ref_block_t *__restrict__ pred,
+                                                              int16_t *__restrict__ res_u, int16_t *__restrict__ res_v,
+                                                              size_t block_pitch, int tiles_x, int groups_x, size_t n_units)
+{
+    const size_t unit = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (unit >= n_units) return;
+    const int lane = threadIdx.x & 63;
+    const size_t ty = unit / (size_t)groups_x, g = unit - ty * (size_t)groups_x;
+    const int t = LOGB == 3 ? lane >> 3 : (lane >> 5) * 4 + (lane & 3);
+    const int row = LOGB == 3 ? lane & 7 : (lane >> 2) & 7;
+    size_t tx = g * 8 + (size_t)t;
+    const bool live = tx < (size_t)tiles_x;
+    if (!live) tx = (size_t)tiles_x - 1;                                 // lanes past the frame edge re-read its last tile, store nothing
+    const size_t tile = ty * (size_t)tiles_x + tx;
+    const v4i a = load16<true>(reinterpret_cast<const uint8_t *>(cur + tile) + 256 + row * 16);
+    const v4i b = load16<true>(reinterpret_cast<const uint8_t *>(pred + tile) + 256 + row * 16);
+    v4i du, dv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t x = (uint32_t)a[q], z = (uint32_t)b[q];           // u v u v
+        const uint32_t xu = x & 0x00FF00FFu, zu = z & 0x00FF00FFu, xv = (x >> 8) & 0x00FF00FFu, zv = (z >> 8) & 0x00FF00FFu;
+        const v2s eu = __builtin_bit_cast(v2s, xu) - __builtin_bit_cast(v2s, zu);      // v_pk_sub_i16: two residuals at once
+        const v2s ev = __builtin_bit_cast(v2s, xv) - __builtin_bit_cast(v2s, zv);
+        du[q] = __builtin_bit_cast(int, eu);
+        dv[q] = __builtin_bit_cast(int, ev);
+    }
+    if (!live) return;
+    size_t blk, inside;                                                   // block in the chroma plane's raster, element offset inside it
+    if (LOGB == 3) {
+        blk = tile;
+        inside = (size_t)row * 8;
+    } else {
+        blk = (ty >> 2) * (size_t)(tiles_x >> 2) + (tx >> 2);
+        inside = ((ty & 3) * 8 + (size_t)row) * 32 + (tx & 3) * 8;
+    }
+    const size_t off = blk * block_pitch * (size_t)(1 << (2 * LOGB)) + inside;
+    store16_sc1nt(res_u + off, du);
+    store16_sc1nt(res_v + off, dv);
+}
+
 }  // namespace
 
 // Units per wave, measured (tools/probes/gpu_tilefmt_probe.py, 32768^2 frame): unpacking gains 13 % from two units per wave (its planar
@@ -218,6 +272,22 @@ hipError_t launch_residual_luma(int block_edge, const x266_ref_block_t *d_cur, c
     dim3 grid((unsigned)wgs), block(kThreads);
     if (block_edge == 32) hipLaunchKernelGGL((residual_luma_kernel<5, kUnitsResidual>), grid, block, kLdsPerWorkgroup - 4 * 2048, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
     else                  hipLaunchKernelGGL((residual_luma_kernel<3, kUnitsResidual>), grid, block, kLdsPerWorkgroup, stream, d_cur, d_pred, d_res, tiles_x, groups_x, n_units);
+    return hipGetLastError();
+}
+
+hipError_t launch_residual_chroma(int block_edge, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_res_u, int16_t *d_res_v,
+                                  size_t block_pitch, int width, int height, hipStream_t stream)
+{
+    const int tiles_x = width / 16, groups_x = (tiles_x + 7) / 8;
+    const size_t n_units = (size_t)groups_x * (size_t)(height / 16);      // unit = (tile row, 8 tiles): all eight chroma rows
+    if (n_units == 0) return hipSuccess;
+    // the luma kernel's shape: two-wave workgroups, LDS charged (not used) so that 16 waves are resident per CU
+    constexpr unsigned kThreads = 128, kLdsPerWorkgroup = 20480;
+    const size_t wgs = (n_units + 1) / 2;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)wgs), block(kThreads);
+    if (block_edge == 32) hipLaunchKernelGGL(residual_chroma_kernel<5>, grid, block, kLdsPerWorkgroup, stream, d_cur, d_pred, d_res_u, d_res_v, block_pitch, tiles_x, groups_x, n_units);
+    else                  hipLaunchKernelGGL(residual_chroma_kernel<3>, grid, block, kLdsPerWorkgroup, stream, d_cur, d_pred, d_res_u, d_res_v, block_pitch, tiles_x, groups_x, n_units);
     return hipGetLastError();
 }
 
