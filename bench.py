@@ -765,11 +765,22 @@ def leg_fused_from_tiles(b):
             ("satd8x8_from_tiles", fw * fh // 64, 132, lambda: codec.satd8x8_from_tiles_dev(tcur.ptr, tpred.ptr, fw, fh, fcost.ptr, b.stream)),
             ("satd8x8_residual_then_cost", fw * fh // 64, None,
              lambda: (codec.residual_luma_dev(tcur.ptr, tpred.ptr, fw, fh, 8, fres.ptr, b.stream), codec.satd8x8_dev(fres.ptr, fcost.ptr, fw * fh // 64, b.stream))))
+    # the chroma half (m_C of the same tiles, src/x266.cpp:60): per 64x64 CTU one 32x32 U and one 32x32 V block -> 2^19 DCT32 blocks; per tile
+    # one 8x8 U and V block -> 2^23 SATD blocks.  Planar U / V output streams.  The read side touches ONE 128-byte line of every 512-byte tile.
+    nc32, nc8 = fw * fh // 4096 * 2, ntile * 2
+    legs += (("chroma_dct32_from_tiles", nc32, 4096,
+              lambda: codec.dct32_fwd_chroma_from_tiles_dev(tcur.ptr, tpred.ptr, fw, fh, fcoef.ptr, fcoef.ptr + nc32 * 1024, 1, b.stream)),
+             ("chroma_satd8x8_from_tiles", nc8, 132,
+              lambda: codec.satd8x8_chroma_from_tiles_dev(tcur.ptr, tpred.ptr, fw, fh, fcost.ptr, fcost.ptr + ntile * 4, 1, b.stream)),
+             ("residual_chroma_32", nc32, 4096,
+              lambda: codec.residual_chroma_dev(tcur.ptr, tpred.ptr, fw, fh, 32, fres.ptr, fres.ptr + nc32 * 1024, 1, b.stream)),
+             ("residual_chroma_8", nc8, 256,
+              lambda: codec.residual_chroma_dev(tcur.ptr, tpred.ptr, fw, fh, 8, fres.ptr, fres.ptr + nc8 * 64, 1, b.stream)))
     for name, units, bytes_per_unit, fn in legs:
         leg = b.timed_leg(fn, steps=short, warmup=3)
         fused[name] = dict(value=b.rate(leg, units), unit="blocks/s", **b.brief(leg))
         if bytes_per_unit:
-            fused[name].update(b.hbm(leg, bytes_per_unit * units, "read" if name.startswith("satd") else "copy"))
+            fused[name].update(b.hbm(leg, bytes_per_unit * units, "read" if "satd" in name else "copy"))
     fused["note"] = ("%dx%d tiled frame pair (x266.cpp ref_block_t); fused kernels are bit-identical to the two-kernel paths "
                      "listed next to them (tests/test_gpu_tiles.py)" % (fw, fh))
     return fused

@@ -244,6 +244,28 @@ int xDct32FwdFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const
  * by xSatd8x8BatchDev.  width, height multiples of 16. */
 int xSatd8x8FromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred,
                          int width, int height, uint32_t *d_out, void *stream);
+/* The chroma half of the same stage.  A tile's chroma is m_C (src/x266.cpp:60): 8 rows of 8 interleaved (U, V) pairs, as
+ * xConvInputFmt packs them (src/x266.cpp:441-449); the chroma planes of a width x height (luma) 4:2:0 frame are
+ * (width / 2) x (height / 2).  block_edge 8: one 8x8 U and one 8x8 V block per tile (width, height multiples of 16),
+ * the inputs of xSatd8x8BatchDev; block_edge 32: one 32x32 U and one 32x32 V block per 64x64 CTU (multiples of 64), the
+ * inputs of xDct32FwdBatchDev.  Blocks are row-major int16, numbered in raster order within the chroma plane; block b of
+ * U goes to d_res_u + b * block_pitch * edge^2, of V to d_res_v + b * block_pitch * edge^2 (block_pitch >= 1, in blocks):
+ * block_pitch 1 with two buffers gives two planar block streams, block_pitch 2 with d_res_v = d_res_u + edge^2 gives
+ * the CTU-ordered stream U0 V0 U1 V1 ...  (No upstream counterpart, as for luma.) */
+int xResidualChromaDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred,
+                       int width, int height, int block_edge, int16_t *d_res_u, int16_t *d_res_v,
+                       size_t block_pitch, void *stream);
+/* Fused chroma residual + forward DCT32: both 32x32 chroma blocks of every 64x64 CTU, one wave per CTU -- bit-identical to
+ * xResidualChromaDev(.., 32, ..) followed by xDct32FwdBatchDev; coefficients of CTU b's U block at
+ * d_coef_u + b * block_pitch * 1024, V likewise.  width, height multiples of 64. */
+int xDct32FwdChromaFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred,
+                                int width, int height, int16_t *d_coef_u, int16_t *d_coef_v, size_t block_pitch,
+                                void *stream);
+/* Fused chroma residual + SATD: d_out_u[t * pitch] = satd8x8 of tile t's U residual, d_out_v[t * pitch] of its V residual
+ * (tiles in raster order) -- bit-identical to xResidualChromaDev(.., 8, ..) followed by xSatd8x8BatchDev.  pitch 2 with
+ * d_out_v = d_out_u + 1 interleaves the two costs.  width, height multiples of 16. */
+int xSatd8x8ChromaFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred,
+                               int width, int height, uint32_t *d_out_u, uint32_t *d_out_v, size_t pitch, void *stream);
 /* Sum of absolute differences of n_blocks pairs of edge x edge 8-bit blocks (edge in
  * {4, 8, 16, 32, 64}; each block edge*edge contiguous bytes, row-major; buffers 16-byte
  * aligned): d_out[b] = sum |a - b|, exactly sad() of

@@ -61,3 +61,21 @@ void orc_residual_luma(const uint8_t *cur_tiles, const uint8_t *pred_tiles, int 
             res[blk * edge * edge + (py % edge) * edge + px % edge] = (int16_t)((int)cur_tiles[o] - (int)pred_tiles[o]);
         }
 }
+
+/* residual blocks (edge 8 or 32) of cur - pred on the tiles' chroma: m_C holds row r of the tile's 8x8 U and V samples as
+ * the interleaved pairs t[256 + r*16 + 2*c] (U) and t[256 + r*16 + 2*c + 1] (V), x266.cpp:441-449.  Plane U's blocks go to
+ * res_u + blk * block_pitch * edge^2, V's to res_v likewise; blocks in raster order of the (width/2) x (height/2) plane. */
+void orc_residual_chroma(const uint8_t *cur_tiles, const uint8_t *pred_tiles, int width, int height, int edge,
+                         int16_t *res_u, int16_t *res_v, size_t block_pitch)
+{
+    const int tiles_x = width / TILE, cw = width / 2, ch = height / 2, bx_n = cw / edge;
+    for (int py = 0; py < ch; py++)
+        for (int px = 0; px < cw; px++) {
+            const size_t tile = (size_t)(py / 8) * tiles_x + px / 8;
+            const size_t o = tile * TILE_BYTES + Y_BYTES + (py % 8) * TILE + 2 * (px % 8);
+            const size_t blk = (size_t)(py / edge) * bx_n + px / edge;
+            const size_t e = blk * block_pitch * edge * edge + (py % edge) * edge + px % edge;
+            res_u[e] = (int16_t)((int)cur_tiles[o] - (int)pred_tiles[o]);
+            res_v[e] = (int16_t)((int)cur_tiles[o + 1] - (int)pred_tiles[o + 1]);
+        }
+}

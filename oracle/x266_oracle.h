@@ -82,6 +82,8 @@ void orc_conv_output_420(const uint8_t *tiles, uint8_t *y, ptrdiff_t strd_y, uin
                          ptrdiff_t strd_c, int width, int height);
 void orc_residual_luma(const uint8_t *cur_tiles, const uint8_t *pred_tiles, int width, int height, int edge,
                        int16_t *res);
+void orc_residual_chroma(const uint8_t *cur_tiles, const uint8_t *pred_tiles, int width, int height, int edge,
+                         int16_t *res_u, int16_t *res_v, size_t block_pitch);
 
 /* ---- 32x32 intra prediction (src/mkIntra32-wip.bsv is a WIP sketch) ---- UNPINNED */
 /* HEVC 35-mode scheme, nTbS = 32 (H.265 8.4.4.2.4-6): mode 0 planar, 1 DC, 2..34 angular, references

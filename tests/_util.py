@@ -93,6 +93,21 @@ class Oracle:
         self.lib.orc_residual_luma(_P(cur_tiles.ctypes.data), _P(pred_tiles.ctypes.data), w, h, edge, _P(res.ctypes.data))
         return res
 
+    def residual_chroma(self, cur_tiles, pred_tiles, w, h, edge, block_pitch=1):
+        """(res_u, res_v): block_pitch 1 -> two planar block streams; block_pitch 2 -> views into one CTU-ordered buffer U0 V0 U1 V1 ..."""
+        cur_tiles = np.ascontiguousarray(cur_tiles, np.uint8)
+        pred_tiles = np.ascontiguousarray(pred_tiles, np.uint8)
+        n = (w // 2) * (h // 2)
+        if block_pitch == 1:
+            res_u, res_v = np.empty(n, np.int16), np.empty(n, np.int16)
+            pu, pv = res_u.ctypes.data, res_v.ctypes.data
+        else:
+            both = np.full(n * block_pitch, 0x7777, np.int16)
+            res_u, res_v = both, both[edge * edge:]
+            pu, pv = both.ctypes.data, both.ctypes.data + edge * edge * 2
+        self.lib.orc_residual_chroma(_P(cur_tiles.ctypes.data), _P(pred_tiles.ctypes.data), w, h, edge, _P(pu), _P(pv), _SZ(block_pitch))
+        return res_u, res_v
+
     def transform_matrix(self, ttype, n):
         m = np.empty((n, n), np.int16)
         assert self.lib.orc_transform_matrix(ttype, n, _P(m.ctypes.data)) == 0

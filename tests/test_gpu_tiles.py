@@ -96,6 +96,111 @@ def test_residual_then_transform_and_cost(codec, oracle, w, h):
             codec.set_option("satd_variant", 0)
 
 
+@pytest.mark.parametrize("w,h", [(64, 64), (128, 192), (320, 64), (448, 832), (1920, 1088), (3136, 1792), (48, 16), (16, 16), (208, 112)])
+def test_chroma_residual_then_transform_and_cost(codec, oracle, w, h):
+    """The chroma half of the residual stage (m_C of ref_block_t, src/x266.cpp:56-63, 441-449): de-interleaved U / V int16 blocks in
+    both orders and both output layouts, the chain into the transform / the cost, and the fused one-kernel forms -- vs the oracle
+    and vs numpy on the planes the tiles were packed from.  Odd tile counts per row (ragged 8-tile groups) are among the sizes."""
+    yc, uc, vc = _yuv(w, h, 31 + w)
+    yp, up, vp = _yuv(w, h, 32 + w)
+    dc, nt = _pack(codec, yc, uc, vc, w, h)
+    dp, _ = _pack(codec, yp, up, vp, w, h)
+    tc, tp = dc.download(np.uint8, nt * 512), dp.download(np.uint8, nt * 512)
+    npl = (w // 2) * (h // 2)                                            # samples per chroma plane
+    du_np, dv_np = uc.astype(np.int16) - up.astype(np.int16), vc.astype(np.int16) - vp.astype(np.int16)
+    for edge in ((32, 8) if w % 64 == 0 and h % 64 == 0 else (8,)):
+        n = npl // (edge * edge)
+        blocks = lambda d: d.reshape(h // 2 // edge, edge, w // 2 // edge, edge).transpose(0, 2, 1, 3).reshape(-1, edge * edge)
+        # planar streams
+        dru, drv = codec.alloc(npl * 2), codec.alloc(npl * 2)
+        codec.residual_chroma_dev(dc.ptr, dp.ptr, w, h, edge, dru.ptr, drv.ptr)
+        codec.stream_sync()
+        ru, rv = dru.download(np.int16, npl), drv.download(np.int16, npl)
+        ou, ov = oracle.residual_chroma(tc, tp, w, h, edge)
+        assert np.array_equal(ru, ou) and np.array_equal(rv, ov)
+        assert np.array_equal(ru.reshape(n, -1), blocks(du_np)) and np.array_equal(rv.reshape(n, -1), blocks(dv_np))
+        # CTU order in one buffer: U0 V0 U1 V1 ... ; holes of a wider pitch stay untouched
+        for pitch in (2, 3):
+            dboth = codec.alloc(npl * 2 * pitch)
+            dboth.upload(np.full(npl * pitch, 0x7777, np.int16))
+            codec.residual_chroma_dev(dc.ptr, dp.ptr, w, h, edge, dboth.ptr, dboth.ptr + edge * edge * 2, pitch)
+            codec.stream_sync()
+            both = dboth.download(np.int16, npl * pitch).reshape(n, pitch, edge * edge)
+            assert np.array_equal(both[:, 0], blocks(du_np)) and np.array_equal(both[:, 1], blocks(dv_np))
+            assert pitch == 2 or np.all(both[:, 2] == 0x7777)
+        if edge == 32:
+            want_u, want_v = oracle.dct32_fwd(ru, threads=8), oracle.dct32_fwd(rv, threads=8)
+            dz = codec.alloc(npl * 2)                                  # chain: residual -> the pinned transform
+            codec.dct32_fwd_dev(dru.ptr, dz.ptr, n)
+            codec.stream_sync()
+            assert np.array_equal(dz.download(np.int16, npl).reshape(n, 1024), want_u)
+            dzu, dzv = codec.alloc(npl * 2), codec.alloc(npl * 2)       # fused: tiles -> both planes' coefficients in one kernel
+            codec.dct32_fwd_chroma_from_tiles_dev(dc.ptr, dp.ptr, w, h, dzu.ptr, dzv.ptr)
+            codec.stream_sync()
+            assert np.array_equal(dzu.download(np.int16, npl).reshape(n, 1024), want_u)
+            assert np.array_equal(dzv.download(np.int16, npl).reshape(n, 1024), want_v)
+            dzb = codec.alloc(npl * 4)                                 # ... CTU-ordered
+            codec.dct32_fwd_chroma_from_tiles_dev(dc.ptr, dp.ptr, w, h, dzb.ptr, dzb.ptr + 2048, 2)
+            codec.stream_sync()
+            zb = dzb.download(np.int16, npl * 2).reshape(n, 2, 1024)
+            assert np.array_equal(zb[:, 0], want_u) and np.array_equal(zb[:, 1], want_v)
+        else:
+            want_u, want_v = oracle.satd8x8(ru, threads=8), oracle.satd8x8(rv, threads=8)
+            ds = codec.alloc(n * 4)
+            codec.satd8x8_dev(drv.ptr, ds.ptr, n)
+            codec.stream_sync()
+            assert np.array_equal(ds.download(np.uint32, n), want_v)
+            dsu, dsv = codec.alloc(n * 4), codec.alloc(n * 4)
+            codec.satd8x8_chroma_from_tiles_dev(dc.ptr, dp.ptr, w, h, dsu.ptr, dsv.ptr)
+            codec.stream_sync()
+            assert np.array_equal(dsu.download(np.uint32, n), want_u) and np.array_equal(dsv.download(np.uint32, n), want_v)
+            dsb = codec.alloc(n * 8)
+            codec.satd8x8_chroma_from_tiles_dev(dc.ptr, dp.ptr, w, h, dsb.ptr, dsb.ptr + 4, 2)
+            codec.stream_sync()
+            sb = dsb.download(np.uint32, 2 * n).reshape(n, 2)
+            assert np.array_equal(sb[:, 0], want_u) and np.array_equal(sb[:, 1], want_v)
+
+
+def test_chroma_extreme_pixels(codec, oracle):
+    """0 / 255 chroma samples: differences of +-255 through the single-byte-plane fused paths"""
+    w, h = 128, 64
+    r = splitmix64(98, 0, w * h)
+    pl = lambda k: np.where((r[:w * h // 4] >> np.uint64(k)) & np.uint64(1), 255, 0).astype(np.uint8).reshape(h // 2, w // 2)
+    z = np.zeros((h, w), np.uint8)
+    dc, nt = _pack(codec, z, pl(0), pl(1), w, h)
+    dp, _ = _pack(codec, z, pl(2), pl(3), w, h)
+    tc, tp = dc.download(np.uint8, nt * 512), dp.download(np.uint8, nt * 512)
+    npl = w * h // 4
+    dzu, dzv = codec.alloc(npl * 2), codec.alloc(npl * 2)
+    codec.dct32_fwd_chroma_from_tiles_dev(dc.ptr, dp.ptr, w, h, dzu.ptr, dzv.ptr)
+    codec.stream_sync()
+    ou, ov = oracle.residual_chroma(tc, tp, w, h, 32)
+    assert np.abs(ou).max() == 255
+    assert np.array_equal(dzu.download(np.int16, npl), oracle.dct32_fwd(ou).ravel()) and np.array_equal(dzv.download(np.int16, npl), oracle.dct32_fwd(ov).ravel())
+    dsu, dsv = codec.alloc(npl // 64 * 4), codec.alloc(npl // 64 * 4)
+    codec.satd8x8_chroma_from_tiles_dev(dc.ptr, dp.ptr, w, h, dsu.ptr, dsv.ptr)
+    codec.stream_sync()
+    ou8, ov8 = oracle.residual_chroma(tc, tp, w, h, 8)
+    assert np.array_equal(dsu.download(np.uint32, npl // 64), oracle.satd8x8(ou8)) and np.array_equal(dsv.download(np.uint32, npl // 64), oracle.satd8x8(ov8))
+
+
+def test_chroma_argument_errors(codec):
+    L = codec.L
+    buf = codec.alloc(1 << 20)
+    p = buf.ptr
+    assert L.xResidualChromaDev(codec.ctx, p, p, 96, 64, 32, p + 65536, p + 131072, 1, None) < 0          # 96 % 64: a 32x32 chroma block is a CTU's
+    assert L.xResidualChromaDev(codec.ctx, p, p, 64, 64, 16, p + 65536, p + 131072, 1, None) < 0          # edge
+    assert L.xResidualChromaDev(codec.ctx, p, p, 64, 64, 8, p + 65536, p + 131072, 0, None) < 0           # pitch 0
+    assert L.xResidualChromaDev(codec.ctx, p, p, 64, 64, 8, p + 65536, p + 65536 + 128, 1, None) < 0      # V inside U's stream
+    assert L.xResidualChromaDev(codec.ctx, p, p, 64, 64, 8, p + 65536, p + 65536 + 256, 2, None) < 0      # V on U's next block
+    assert L.xResidualChromaDev(codec.ctx, p, p, 64, 64, 8, p + 65536, p + 65536 + 128, 2, None) == 0     # the interleaved form
+    assert L.xDct32FwdChromaFromTilesDev(codec.ctx, p, p, 64, 32, p + 65536, p + 131072, 1, None) < 0     # height % 64
+    assert L.xDct32FwdChromaFromTilesDev(codec.ctx, p, p, 64, 64, p + 65536, None, 1, None) < 0
+    assert L.xSatd8x8ChromaFromTilesDev(codec.ctx, p, p, 24, 16, p + 65536, p + 131072, 1, None) < 0      # width % 16
+    assert L.xSatd8x8ChromaFromTilesDev(codec.ctx, p, p, 32, 16, p + 65536, p + 65536, 2, None) < 0       # same pointer twice
+    codec.stream_sync()
+
+
 def test_fused_transform_extreme_pixels(codec, oracle):
     """0 / 255 pixels drive the differences to +-255, the edge of the single-byte-plane path."""
     w, h = 64, 64

@@ -203,6 +203,23 @@ def test_residual_blocks_definition(oracle):
         assert np.array_equal(oracle.residual_luma(tc, tp, w, h, edge), want)
 
 
+def test_chroma_residual_blocks_definition(oracle):
+    """chroma of the tiled pair, by its definition on the PLANES the tiles were packed from (numpy): block b of the
+    (w/2) x (h/2) plane, raster order; planar streams (pitch 1) and the CTU-ordered stream U0 V0 U1 V1 (pitch 2)"""
+    for w, h in ((64, 64), (192, 128)):
+        yc, uc, vc = _yuv(w, h, 16)
+        yp, up, vp = _yuv(w, h, 17)
+        tc, tp = oracle.conv_input_fmt(yc, uc, vc), oracle.conv_input_fmt(yp, up, vp)
+        du, dv = uc.astype(np.int16) - up.astype(np.int16), vc.astype(np.int16) - vp.astype(np.int16)
+        for edge in (8, 32):
+            blocks = lambda d: d.reshape(h // 2 // edge, edge, w // 2 // edge, edge).transpose(0, 2, 1, 3).reshape(-1, edge * edge)
+            ru, rv = oracle.residual_chroma(tc, tp, w, h, edge)
+            assert np.array_equal(ru.reshape(-1, edge * edge), blocks(du)) and np.array_equal(rv.reshape(-1, edge * edge), blocks(dv))
+            both, _ = oracle.residual_chroma(tc, tp, w, h, edge, block_pitch=2)
+            both = both.reshape(-1, 2, edge * edge)
+            assert np.array_equal(both[:, 0], blocks(du)) and np.array_equal(both[:, 1], blocks(dv))
+
+
 def test_transform_set_inverse_definition(oracle):
     x = np.concatenate([residual_np(30 * 1024, 81), fullrange_np(30 * 1024, 82)]).reshape(-1, 1024)
     assert np.array_equal(oracle.transform_inv(0, 32, x), oracle.dct32_inv(x))            # overlaps the DCT32 inverse

@@ -75,6 +75,9 @@ def load_library():
     L.xResidualLumaDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]
     L.xDct32FwdFromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
     L.xSatd8x8FromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
+    L.xResidualChromaDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_size_t, _P]
+    L.xDct32FwdChromaFromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_size_t, _P]
+    L.xSatd8x8ChromaFromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_size_t, _P]
     L.xSadBatchDev.argtypes = [_P, ctypes.c_int, _P, _P, _P, _SZ, _P]
     L.xTransformInvBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
     L.xTransformTilesDev.argtypes = [_P, ctypes.c_int, _P, _P, _SZ, _P, _P, _P]
@@ -356,6 +359,17 @@ class Codec:
 
     def satd8x8_from_tiles_dev(self, d_cur, d_pred, w, h, d_out, stream=0):
         self._check(self.L.xSatd8x8FromTilesDev(self.ctx, d_cur, d_pred, w, h, d_out, stream), "xSatd8x8FromTilesDev")
+
+    def residual_chroma_dev(self, d_cur, d_pred, w, h, edge, d_res_u, d_res_v, block_pitch=1, stream=0):
+        self._check(self.L.xResidualChromaDev(self.ctx, d_cur, d_pred, w, h, edge, d_res_u, d_res_v, block_pitch, stream), "xResidualChromaDev")
+
+    def dct32_fwd_chroma_from_tiles_dev(self, d_cur, d_pred, w, h, d_coef_u, d_coef_v, block_pitch=1, stream=0):
+        self._check(self.L.xDct32FwdChromaFromTilesDev(self.ctx, d_cur, d_pred, w, h, d_coef_u, d_coef_v, block_pitch, stream),
+                    "xDct32FwdChromaFromTilesDev")
+
+    def satd8x8_chroma_from_tiles_dev(self, d_cur, d_pred, w, h, d_out_u, d_out_v, pitch=1, stream=0):
+        self._check(self.L.xSatd8x8ChromaFromTilesDev(self.ctx, d_cur, d_pred, w, h, d_out_u, d_out_v, pitch, stream),
+                    "xSatd8x8ChromaFromTilesDev")
 
     def sad_dev(self, edge, d_a, d_b, d_out, n_blocks, stream=0):
         self._check(self.L.xSadBatchDev(self.ctx, edge, d_a, d_b, d_out, n_blocks, stream), "xSadBatchDev")

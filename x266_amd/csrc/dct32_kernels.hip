@@ -367,6 +367,58 @@ __global__ __launch_bounds__(256) void dct32_from_tiles_kernel(const x266_ref_bl
 }
 
 
+// ---- fused chroma residual + forward transform -------------------------------------------------
+// A 64x64 CTU in 4:2:0 carries one 32x32 U and one 32x32 V block -- the headline transform size -- spread over the m_C lines
+// of its 4 x 4 tiles (src/x266.cpp:60, packed at :441-449: 8 rows of 8 interleaved U,V pairs per tile).  One wave takes one
+// CTU and BOTH planes: a lane's fragment (row c, columns 16h .. 16h+15 of the block) is the chroma row (c & 7) of tile row
+// (c >> 3), tiles 2h and 2h+1 -- two 16-byte loads per frame, whose even bytes are the U fragment and odd bytes the V
+// fragment.  Eight lanes share a tile's line, so every load instruction consumes whole lines.  Arithmetic as for luma
+// (dct32_from_tiles_kernel): one byte plane per frame, G*cur + (-G)*pred, the +128 of the offset trick cancels.
+__global__ __launch_bounds__(256) void dct32_chroma_from_tiles_kernel(const x266_ref_block_t *__restrict__ cur,
+                                                                      const x266_ref_block_t *__restrict__ pred,
+                                                                      int16_t *__restrict__ out_u, int16_t *__restrict__ out_v,
+                                                                      size_t block_pitch, int ctus_x, int tiles_x, size_t n_ctus,
+                                                                      const DctOps *__restrict__ ops)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
+    const int lane = threadIdx.x & 63;
+    unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+    const size_t ctu = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (ctu >= n_ctus) return;
+    const unsigned c = lane & 31, h = lane >> 5;
+    const size_t cy = ctu / ctus_x, cx = ctu - cy * ctus_x;
+    const size_t tile = (cy * 4 + (c >> 3)) * (size_t)tiles_x + cx * 4 + 2 * h;
+    const unsigned char *pc = reinterpret_cast<const unsigned char *>(cur + tile) + 256 + (c & 7) * 16;
+    const unsigned char *pp = reinterpret_cast<const unsigned char *>(pred + tile) + 256 + (c & 7) * 16;
+    const v4i a0 = load16<true>(pc), a1 = load16<true>(pc + 512), b0 = load16<true>(pp), b1 = load16<true>(pp + 512);
+    const LaneConsts k = load_consts(ops, lane);
+    const uint32_t S = 0x80808080u;
+    const v16i round1 = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};
+    const unsigned lin0 = lds_slot(lane >> 2, lane & 3), lin1 = lds_slot(16 + (lane >> 2), lane & 3);
+    const unsigned frag0 = lds_slot(c, 2 * h), frag1 = lds_slot(c, 2 * h + 1);
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane) {
+        const uint32_t sel = plane ? 0x07050301u : 0x06040200u;           // odd bytes = V, even bytes = U
+        const v4i a = {(int)(bperm((uint32_t)a0[1], (uint32_t)a0[0], sel) ^ S), (int)(bperm((uint32_t)a0[3], (uint32_t)a0[2], sel) ^ S),
+                       (int)(bperm((uint32_t)a1[1], (uint32_t)a1[0], sel) ^ S), (int)(bperm((uint32_t)a1[3], (uint32_t)a1[2], sel) ^ S)};
+        const v4i b = {(int)(bperm((uint32_t)b0[1], (uint32_t)b0[0], sel) ^ S), (int)(bperm((uint32_t)b0[3], (uint32_t)b0[2], sel) ^ S),
+                       (int)(bperm((uint32_t)b1[1], (uint32_t)b1[0], sel) ^ S), (int)(bperm((uint32_t)b1[3], (uint32_t)b1[2], sel) ^ S)};
+        v16i acc = mfma(a, k.p1, round1);
+        acc = mfma(b, k.tr, acc);                                         // k.tr = -p1 in the forward tables
+        v4i o0, o1;
+        fwd_finish<4, 11>(acc, k, o0, o1);
+        if (plane) __builtin_amdgcn_wave_barrier();                       // the U tile has left the slot
+        *reinterpret_cast<v4i *>(slot + frag0) = o0;
+        *reinterpret_cast<v4i *>(slot + frag1) = o1;
+        __builtin_amdgcn_wave_barrier();
+        const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
+        const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
+        char *dst = reinterpret_cast<char *>((plane ? out_v : out_u) + ctu * block_pitch * 1024) + lane * 16;
+        store16_sc1nt(dst, s0);
+        store16_sc1nt(dst + 1024, s1);
+    }
+}
+
 // ---- the 1-D pass on its own (partialButterfly32, src_tb/dct32.c:66-170; RTL stage src/mkDct32.bsv:213-284) --------
 // dst[k*32 + j] = (int16)((sum_n g[k][n] * src[j*32 + n] + (1 << (shift-1))) >> shift): one MFMA pass of the forward
 // kernel with the accumulators stored TRANSPOSED, as the reference does.  Lane (c, h) holds frequency kappa(c) for the 16
@@ -455,6 +507,21 @@ hipError_t launch_dct32_from_tiles(const x266_ref_block_t *d_cur, const x266_ref
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t lds = wpw * (size_t)cfg.lds_bytes_per_wave;
     hipLaunchKernelGGL(dct32_from_tiles_kernel, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_cur, d_pred, d_out, blocks_x, width / 16, n_blocks, d_fwd_ops);
+    return hipGetLastError();
+}
+
+hipError_t launch_dct32_chroma_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_out_u, int16_t *d_out_v,
+                                          size_t block_pitch, int width, int height, const DctOps *d_fwd_ops, const LaunchCfg &cfg, hipStream_t stream)
+{
+    const int ctus_x = width / 64;
+    const size_t n_ctus = (size_t)ctus_x * (size_t)(height / 64);
+    if (n_ctus == 0) return hipSuccess;
+    const unsigned tpb = (unsigned)cfg.wg_threads;
+    const size_t wpw = tpb / 64, wgs = (n_ctus + wpw - 1) / wpw;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const size_t lds = wpw * (size_t)cfg.lds_bytes_per_wave;
+    hipLaunchKernelGGL(dct32_chroma_from_tiles_kernel, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_cur, d_pred, d_out_u, d_out_v, block_pitch,
+                       ctus_x, width / 16, n_ctus, d_fwd_ops);
     return hipGetLastError();
 }
 

@@ -503,6 +503,68 @@ __global__ __launch_bounds__(256) void satd8x8_from_tiles_dma_kernel(const x266_
     }
 }
 
+// ---- fused chroma residual + SATD ----------------------------------------------------------------------------------------
+// cost = satd8x8(cur - pred) for the 8x8 U block and the 8x8 V block every tile carries in its m_C line (src/x266.cpp:60,
+// :441-449: 8 rows of 8 interleaved U,V pairs).  One wave takes 16 tiles = 32 blocks (lane n: tile n / 2, plane n % 2): two
+// line-dense load instructions per frame (lane = 8 * tile + row: a tile's eight lanes read its whole 128-byte line) into a
+// wave-private 4 KiB LDS slot, row r of tile t at t*128 + ((r ^ t) & 7)*16; the fragment reads fetch a row's 16 interleaved
+// bytes and keep the even (U) or odd (V) ones.  Arithmetic as for luma: H*cur + (-H)*pred on the pixels as they are.
+__global__ __launch_bounds__(256) void satd8x8_chroma_from_tiles_kernel(const x266_ref_block_t *__restrict__ cur,
+                                                                        const x266_ref_block_t *__restrict__ pred,
+                                                                        uint32_t *__restrict__ out_u, uint32_t *__restrict__ out_v,
+                                                                        size_t pitch, size_t n_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];   // 4 KiB per wave
+    const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+    const size_t group = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (group * 16 >= n_tiles) return;
+    unsigned char *slot = stage + (threadIdx.x >> 6) * 4096;
+    const int lt = lane >> 3, lr = lane & 7;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        size_t t = group * 16 + 8 * k + lt;
+        if (t >= n_tiles) t = n_tiles - 1;                                  // ragged tail: stay inside the frame
+        const unsigned dst = (unsigned)((8 * k + lt) * 128 + ((lr ^ (8 * k + lt)) & 7) * 16);
+        *reinterpret_cast<v4i *>(slot + dst) = load16<true>(reinterpret_cast<const unsigned char *>(cur + t) + 256 + lr * 16);
+        *reinterpret_cast<v4i *>(slot + 2048 + dst) = load16<true>(reinterpret_cast<const unsigned char *>(pred + t) + 256 + lr * 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int tl = n >> 1;
+    const uint32_t sel = (n & 1) ? 0x07050301u : 0x06040200u;
+    const uint32_t S = 0x80808080u;                                         // pixels -> signed (offset cancels)
+    uint2 a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * half + r;
+        const unsigned src = (unsigned)(tl * 128 + ((row ^ tl) & 7) * 16);
+        const v4i wa = *reinterpret_cast<const v4i *>(slot + src), wb = *reinterpret_cast<const v4i *>(slot + 2048 + src);
+        a[r] = make_uint2(bperm((uint32_t)wa[1], (uint32_t)wa[0], sel) ^ S, bperm((uint32_t)wa[3], (uint32_t)wa[2], sel) ^ S);
+        b[r] = make_uint2(bperm((uint32_t)wb[1], (uint32_t)wb[0], sel) ^ S, bperm((uint32_t)wb[3], (uint32_t)wb[2], sel) ^ S);
+    }
+    const SatdOperands H = make_satd_operands(lane);
+    const v4i a0 = {(int)a[0].x, (int)a[0].y, (int)a[1].x, (int)a[1].y}, a1 = {(int)a[2].x, (int)a[2].y, (int)a[3].x, (int)a[3].y};
+    const v4i b0 = {(int)b[0].x, (int)b[0].y, (int)b[1].x, (int)b[1].y}, b1 = {(int)b[2].x, (int)b[2].y, (int)b[3].x, (int)b[3].y};
+    const v4i NEG = {(int)0xFEFEFEFEu, (int)0xFEFEFEFEu, (int)0xFEFEFEFEu, (int)0xFEFEFEFEu};
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t sum = 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const v4i h0 = t ? H.h10 : H.h00, h1 = t ? H.h11 : H.h01;
+        v16i acc = mfma(h0, a0, zero);
+        acc = mfma(h1, a1, acc);
+        acc = mfma(h0 ^ NEG, b0, acc);
+        acc = mfma(h1 ^ NEG, b1, acc);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const uint32_t pk = bperm((uint32_t)acc[2 * m + 1], (uint32_t)acc[2 * m], 0x05040100u) ^ 0x80008000u;
+            sum = __builtin_amdgcn_sad_u16(pk, 0x80008000u, sum);
+        }
+    }
+    sum += (uint32_t)__shfl_xor((int)sum, 32);
+    const size_t tile = group * 16 + (size_t)tl;
+    if (tile < n_tiles && half == 0) store_result4(((n & 1) ? out_v : out_u) + tile * pitch, (sum + 2) >> 2);
+}
+
 // ---- synthetic residual stream ---------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t index)
 {
@@ -603,6 +665,17 @@ hipError_t launch_satd8x8_from_tiles(const x266_ref_block_t *d_cur, const x266_r
         return hipGetLastError();
     }
     hipLaunchKernelGGL(satd8x8_from_tiles_kernel, dim3((unsigned)groups), dim3(64), (size_t)6144, stream, d_cur, d_pred, d_out, tiles_x, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_satd8x8_chroma_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, uint32_t *d_out_u, uint32_t *d_out_v,
+                                            size_t pitch, int width, int height, hipStream_t stream)
+{
+    const size_t n_tiles = (size_t)(width / 16) * (size_t)(height / 16);
+    if (n_tiles == 0) return hipSuccess;
+    const size_t groups = (n_tiles + 15) / 16;                          // one wave per 16 tiles, one-wave workgroups (the luma kernel's shape)
+    if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(satd8x8_chroma_from_tiles_kernel, dim3((unsigned)groups), dim3(64), (size_t)6144, stream, d_cur, d_pred, d_out_u, d_out_v, pitch, n_tiles);
     return hipGetLastError();
 }
 

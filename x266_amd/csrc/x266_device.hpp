@@ -152,6 +152,12 @@ hipError_t launch_tile_convert(bool pack, x266_ref_block_t *d_tiles, uint8_t *d_
                                long long strd_y, long long strd_c, int width, int height, hipStream_t stream);
 hipError_t launch_residual_luma(int block_edge, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_res,
                                 int width, int height, hipStream_t stream);
+hipError_t launch_residual_chroma(int block_edge, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_res_u, int16_t *d_res_v,
+                                  size_t block_pitch, int width, int height, hipStream_t stream);
+hipError_t launch_dct32_chroma_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_out_u, int16_t *d_out_v,
+                                          size_t block_pitch, int width, int height, const DctOps *d_fwd_ops, const LaunchCfg &cfg, hipStream_t stream);
+hipError_t launch_satd8x8_chroma_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, uint32_t *d_out_u, uint32_t *d_out_v,
+                                            size_t pitch, int width, int height, hipStream_t stream);
 hipError_t launch_mem_ceiling(int kind, const void *d_src, void *d_dst, size_t bytes, hipStream_t stream);
 hipError_t launch_fill_residual(int16_t *d_dst, size_t n_samples, uint64_t seed,
                                 uint64_t first_index, const LaunchCfg &cfg, hipStream_t stream);

@@ -787,6 +787,67 @@ int xSatd8x8FromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const 
     return X266HIP_OK;
 }
 
+// the two output streams of a chroma call must not overlap: plane V starts at or after U's first block ends (interleaved
+// form) or anywhere else outside [U, U + span)
+static bool chroma_outputs_ok(const void *u, const void *v, size_t block_bytes, size_t n_blocks, size_t pitch)
+{
+    if (!u || !v || pitch < 1 || n_blocks == 0) return u && v && pitch >= 1;
+    const uintptr_t a = (uintptr_t)u, b = (uintptr_t)v;
+    const uintptr_t lo = a < b ? a : b, hi = a < b ? b : a;
+    const size_t gap = (size_t)(hi - lo);
+    if (gap >= ((n_blocks - 1) * pitch + 1) * block_bytes) return true;     // disjoint spans
+    // interleaved: the other plane's blocks sit in the holes of this one's pitch
+    return pitch >= 2 && gap % block_bytes == 0 && gap / block_bytes >= 1 && gap / block_bytes <= pitch - 1;
+}
+
+int xResidualChromaDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int width, int height,
+                       int block_edge, int16_t *d_res_u, int16_t *d_res_v, size_t block_pitch, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (block_edge != 8 && block_edge != 32) return fail(ctx, X266HIP_EINVAL, "xResidualChromaDev: block_edge must be 8 or 32");
+    const int mask = block_edge == 32 ? 63 : 15;                             // luma dimensions: a 32x32 chroma block is a 64x64 CTU's
+    if (width <= 0 || height <= 0 || (width & mask) || (height & mask)) return fail(ctx, X266HIP_EINVAL, "xResidualChromaDev: frame size");
+    if (!d_cur || !d_pred || !d_res_u || !d_res_v || ((((uintptr_t)d_cur | (uintptr_t)d_pred | (uintptr_t)d_res_u | (uintptr_t)d_res_v)) & 15u))
+        return fail(ctx, X266HIP_EINVAL, "xResidualChromaDev: NULL or unaligned buffer");
+    const size_t n_blocks = (size_t)(width / 2 / block_edge) * (size_t)(height / 2 / block_edge);
+    if (!chroma_outputs_ok(d_res_u, d_res_v, (size_t)block_edge * block_edge * 2, n_blocks, block_pitch))
+        return fail(ctx, X266HIP_EINVAL, "xResidualChromaDev: block_pitch < 1 or overlapping U / V outputs");
+    X_DEV(ctx);
+    hipError_t e = launch_residual_chroma(block_edge, d_cur, d_pred, d_res_u, d_res_v, block_pitch, width, height, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "chroma residual launch", e);
+    return X266HIP_OK;
+}
+
+int xDct32FwdChromaFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int width, int height,
+                                int16_t *d_coef_u, int16_t *d_coef_v, size_t block_pitch, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (width <= 0 || height <= 0 || (width & 63) || (height & 63)) return fail(ctx, X266HIP_EINVAL, "xDct32FwdChromaFromTilesDev: width/height must be multiples of 64");
+    if (!d_cur || !d_pred || !d_coef_u || !d_coef_v || ((((uintptr_t)d_cur | (uintptr_t)d_pred | (uintptr_t)d_coef_u | (uintptr_t)d_coef_v)) & 15u))
+        return fail(ctx, X266HIP_EINVAL, "xDct32FwdChromaFromTilesDev: NULL or unaligned buffer");
+    if (!chroma_outputs_ok(d_coef_u, d_coef_v, 2048, (size_t)(width / 64) * (size_t)(height / 64), block_pitch))
+        return fail(ctx, X266HIP_EINVAL, "xDct32FwdChromaFromTilesDev: block_pitch < 1 or overlapping U / V outputs");
+    X_DEV(ctx);
+    hipError_t e = launch_dct32_chroma_from_tiles(d_cur, d_pred, d_coef_u, d_coef_v, block_pitch, width, height, ctx->d_fwd, cfg_for(ctx, 0), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fused chroma transform launch", e);
+    return X266HIP_OK;
+}
+
+int xSatd8x8ChromaFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int width, int height,
+                               uint32_t *d_out_u, uint32_t *d_out_v, size_t pitch, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (width <= 0 || height <= 0 || (width & 15) || (height & 15)) return fail(ctx, X266HIP_EINVAL, "xSatd8x8ChromaFromTilesDev: width/height must be multiples of 16");
+    if (!d_cur || !d_pred || !d_out_u || !d_out_v || ((((uintptr_t)d_cur | (uintptr_t)d_pred)) & 15u) || (((uintptr_t)d_out_u | (uintptr_t)d_out_v) & 3u))
+        return fail(ctx, X266HIP_EINVAL, "xSatd8x8ChromaFromTilesDev: NULL or unaligned buffer");
+    if (!chroma_outputs_ok(d_out_u, d_out_v, 4, (size_t)(width / 16) * (size_t)(height / 16), pitch))
+        return fail(ctx, X266HIP_EINVAL, "xSatd8x8ChromaFromTilesDev: pitch < 1 or overlapping U / V outputs");
+    X_DEV(ctx);
+    hipError_t e = launch_satd8x8_chroma_from_tiles(d_cur, d_pred, d_out_u, d_out_v, pitch, width, height, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fused chroma satd launch", e);
+    return X266HIP_OK;
+}
+
 int xSadBatchDev(x266hip_ctx *ctx, int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out, size_t n, void *stream)
 {
     if (!ctx) return X266HIP_EINVAL;
