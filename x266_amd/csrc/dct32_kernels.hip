@@ -378,11 +378,11 @@ __global__ __launch_bounds__(256) void dct32_chroma_from_tiles_kernel(const x266
                                                                       const x266_ref_block_t *__restrict__ pred,
                                                                       int16_t *__restrict__ out_u, int16_t *__restrict__ out_v,
                                                                       size_t block_pitch, int ctus_x, int tiles_x, size_t n_ctus,
-                                                                      const DctOps *__restrict__ ops)
+                                                                      const DctOps *__restrict__ ops, unsigned lds_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
     const int lane = threadIdx.x & 63;
-    unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+    unsigned char *slot = stage + (threadIdx.x >> 6) * lds_per_wave;
     const size_t ctu = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (ctu >= n_ctus) return;
     const unsigned c = lane & 31, h = lane >> 5;
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256) void dct32_chroma_from_tiles_kernel(const x266
     const v16i round1 = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};
     const unsigned lin0 = lds_slot(lane >> 2, lane & 3), lin1 = lds_slot(16 + (lane >> 2), lane & 3);
     const unsigned frag0 = lds_slot(c, 2 * h), frag1 = lds_slot(c, 2 * h + 1);
+    // U, then V through the same slot (both planes computed first and converted through two slots: 1-2 % slower, profiles/r06_chroma_shapes.txt)
 #pragma unroll
     for (int plane = 0; plane < 2; ++plane) {
         const uint32_t sel = plane ? 0x07050301u : 0x06040200u;           // odd bytes = V, even bytes = U
@@ -519,9 +520,11 @@ hipError_t launch_dct32_chroma_from_tiles(const x266_ref_block_t *d_cur, const x
     const unsigned tpb = (unsigned)cfg.wg_threads;
     const size_t wpw = tpb / 64, wgs = (n_ctus + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const size_t lds = wpw * (size_t)cfg.lds_bytes_per_wave;
-    hipLaunchKernelGGL(dct32_chroma_from_tiles_kernel, dim3((unsigned)wgs), dim3(tpb), lds, stream, d_cur, d_pred, d_out_u, d_out_v, block_pitch,
-                       ctus_x, width / 16, n_ctus, d_fwd_ops);
+    // a wave lives for two blocks here: 12 KiB charged per wave (13 resident per CU) instead of the forward kernel's 8 -- paired on a 32768^2 frame
+    // 0.332 against 0.340 ms, 0.97 of the box's copy of the same bytes (tools/probes/gpu_chroma_shapes.py, profiles/r06_chroma_shapes.txt)
+    const unsigned per_wave = (unsigned)cfg.lds_bytes_per_wave < 12288u ? 12288u : (unsigned)cfg.lds_bytes_per_wave;
+    hipLaunchKernelGGL(dct32_chroma_from_tiles_kernel, dim3((unsigned)wgs), dim3(tpb), wpw * (size_t)per_wave, stream, d_cur, d_pred, d_out_u, d_out_v, block_pitch,
+                       ctus_x, width / 16, n_ctus, d_fwd_ops, per_wave);
     return hipGetLastError();
 }
 

@@ -675,6 +675,8 @@ hipError_t launch_satd8x8_chroma_from_tiles(const x266_ref_block_t *d_cur, const
     if (n_tiles == 0) return hipSuccess;
     const size_t groups = (n_tiles + 15) / 16;                          // one wave per 16 tiles, one-wave workgroups (the luma kernel's shape)
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    // 6 KiB charged per one-wave workgroup (4 KiB used): the best of the 3 x 6 shapes of tools/probes/gpu_chroma_shapes.py, 0.81 of the box's DENSE read
+    // probe of the same bytes -- the luma kernel's rate per byte less 6 % (a quarter-dense stream: one line of every four)
     hipLaunchKernelGGL(satd8x8_chroma_from_tiles_kernel, dim3((unsigned)groups), dim3(64), (size_t)6144, stream, d_cur, d_pred, d_out_u, d_out_v, pitch, n_tiles);
     return hipGetLastError();
 }

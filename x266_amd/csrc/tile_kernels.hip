@@ -185,27 +185,31 @@ __global__ __launch_bounds__(256) void residual_luma_kernel(const x266_ref_block
 // ---- chroma residual --------------------------------------------------------------------------------------------------
 // A tile's chroma is ONE 128-byte line (m_C, src/x266.cpp:60: 8 rows of 8 interleaved U,V pairs, packed at :441-449).  One lane
 // takes one 16-byte row of it from both frames and emits 8 U and 8 V residuals (16 bytes each) -- the de-interleave is two
-// masks and two packed 16-bit subtractions per dword pair.  A wave takes eight horizontally adjacent tiles x eight rows:
-//   LOGB = 3 (one 8x8 U and one 8x8 V block per tile): lane = 8 * tile + row, a tile's eight lanes read its line and write its
-//            two blocks' 128 bytes each -- with block_pitch 1 the wave's U (and V) store is 1 KiB linear;
-//   LOGB = 5 (one 32x32 U and V block per 64x64 CTU = 4 x 4 tiles): lane = 32 * block + 4 * row + tile-in-block, so the eight
-//            rows x 64 bytes a tile row contributes to a block are one 512-byte run -- two runs per store instruction.
-// No LDS, no second pass: both forms read whole lines and write whole lines.
+// masks and two packed 16-bit subtractions per dword.  A wave takes eight tiles x eight rows, lane = 8 * tile + row, so that a
+// tile's eight lanes read its whole line:
+//   LOGB = 3 (one 8x8 U and one 8x8 V block per tile): eight horizontally adjacent tiles; a tile's lanes write its two blocks'
+//            128 bytes each -- with block_pitch 1 the wave's U (and V) store is 1 KiB linear;
+//   LOGB = 5 (one 32x32 U and V block per 64x64 CTU = 4 x 4 tiles): 4 tiles x 2 tile rows = 16 rows of ONE block, re-ordered
+//            through a wave-private LDS slot into that block's row order -- again one 1 KiB-linear store per plane.
+// Both forms read whole lines and write whole lines, 1 KiB per instruction.
 typedef short v2s __attribute__((ext_vector_type(2)));
 
 template <int LOGB>
-__global__ __launch_bounds__(128) void residual_chroma_kernel(const x266_ref_block_t *__restrict__ cur,
+__global__ __launch_bounds__(256) void residual_chroma_kernel(const x266_ref_block_t *__restrict__ cur,
                                                               const x266_ref_block_t *__restrict__ pred,
                                                               int16_t *__restrict__ res_u, int16_t *__restrict__ res_v,
                                                               size_t block_pitch, int tiles_x, int groups_x, size_t n_units)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];  // LOGB = 5: 2 KiB per wave; the rest of the charge caps the resident waves
     const size_t unit = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (unit >= n_units) return;
     const int lane = threadIdx.x & 63;
-    const size_t ty = unit / (size_t)groups_x, g = unit - ty * (size_t)groups_x;
-    const int t = LOGB == 3 ? lane >> 3 : (lane >> 5) * 4 + (lane & 3);
-    const int row = LOGB == 3 ? lane & 7 : (lane >> 2) & 7;
-    size_t tx = g * 8 + (size_t)t;
+    const size_t uy = unit / (size_t)groups_x, g = unit - uy * (size_t)groups_x;
+    const int t = lane >> 3, row = lane & 7;                              // lane = 8 * tile + row: a tile's eight lanes read its whole line
+    // LOGB = 3: the unit is 8 tiles of one tile row.  LOGB = 5: 4 tiles of two tile rows = a quarter-height slab of ONE block
+    // (tiles_x and the tile row count are multiples of 4 there: no ragged units)
+    const size_t ty = LOGB == 3 ? uy : uy * 2 + (size_t)(t >> 2);
+    size_t tx = LOGB == 3 ? g * 8 + (size_t)t : g * 4 + (size_t)(t & 3);
     const bool live = tx < (size_t)tiles_x;
     if (!live) tx = (size_t)tiles_x - 1;                                 // lanes past the frame edge re-read its last tile, store nothing
     const size_t tile = ty * (size_t)tiles_x + tx;
@@ -221,16 +225,25 @@ __global__ __launch_bounds__(128) void residual_chroma_kernel(const x266_ref_blo
         du[q] = __builtin_bit_cast(int, eu);
         dv[q] = __builtin_bit_cast(int, ev);
     }
-    if (!live) return;
-    size_t blk, inside;                                                   // block in the chroma plane's raster, element offset inside it
-    if (LOGB == 3) {
-        blk = tile;
-        inside = (size_t)row * 8;
-    } else {
-        blk = (ty >> 2) * (size_t)(tiles_x >> 2) + (tx >> 2);
-        inside = ((ty & 3) * 8 + (size_t)row) * 32 + (tx & 3) * 8;
+    if (LOGB == 5) {
+        // The loads want a tile's rows in adjacent lanes, the stores a block row's four tiles: the 2 x 1 KiB change hands through a wave-private
+        // LDS slot.  16-byte chunk (tile row j, row, tile) sits at j*32 + row*4 + (tile ^ ((row >> 1) & 3)): both sides conflict-free, and the
+        // slab leaves as ONE 1 KiB-linear store per plane (16 block rows of 64 bytes).
+        unsigned char *slot = stage + (threadIdx.x >> 6) * 2048;
+        const unsigned wr = (unsigned)((t >> 2) * 32 + row * 4 + ((t & 3) ^ ((row >> 1) & 3)));
+        *reinterpret_cast<v4i *>(slot + wr * 16) = du;
+        *reinterpret_cast<v4i *>(slot + 1024 + wr * 16) = dv;
+        __builtin_amdgcn_wave_barrier();
+        const unsigned rd = (unsigned)((lane & ~3) + ((lane & 3) ^ ((lane >> 3) & 3)));
+        const v4i su = *reinterpret_cast<const v4i *>(slot + rd * 16), sv = *reinterpret_cast<const v4i *>(slot + 1024 + rd * 16);
+        const size_t blk = (uy >> 1) * (size_t)(tiles_x >> 2) + g;
+        const size_t off = blk * block_pitch * 1024 + (uy & 1) * 512 + (size_t)lane * 8;
+        store16_sc1nt(res_u + off, su);
+        store16_sc1nt(res_v + off, sv);
+        return;
     }
-    const size_t off = blk * block_pitch * (size_t)(1 << (2 * LOGB)) + inside;
+    if (!live) return;
+    const size_t off = tile * block_pitch * 64 + (size_t)row * 8;         // tiles and 8x8 chroma blocks share their raster
     store16_sc1nt(res_u + off, du);
     store16_sc1nt(res_v + off, dv);
 }
@@ -278,14 +291,15 @@ hipError_t launch_residual_luma(int block_edge, const x266_ref_block_t *d_cur, c
 hipError_t launch_residual_chroma(int block_edge, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_res_u, int16_t *d_res_v,
                                   size_t block_pitch, int width, int height, hipStream_t stream)
 {
-    const int tiles_x = width / 16, groups_x = (tiles_x + 7) / 8;
-    const size_t n_units = (size_t)groups_x * (size_t)(height / 16);      // unit = (tile row, 8 tiles): all eight chroma rows
+    const int tiles_x = width / 16, tiles_y = height / 16;
+    const int groups_x = block_edge == 32 ? tiles_x / 4 : (tiles_x + 7) / 8;
+    const size_t n_units = (size_t)groups_x * (size_t)(block_edge == 32 ? tiles_y / 2 : tiles_y);     // one wave each: 8 tiles' chroma lines
     if (n_units == 0) return hipSuccess;
-    // the luma kernel's shape: two-wave workgroups, LDS charged (not used) so that 16 waves are resident per CU
-    constexpr unsigned kThreads = 128, kLdsPerWorkgroup = 20480;
-    const size_t wgs = (n_units + 1) / 2;
-    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    dim3 grid((unsigned)wgs), block(kThreads);
+    // one-wave workgroups, 12 KiB of LDS charged = 13 resident waves per CU: paired in one process on a 32768^2 frame (tools/probes/gpu_chroma_shapes.py,
+    // profiles/r06_chroma_shapes.txt) the 8x8 order runs at 0.977 of the box's copy of the same bytes (two-wave workgroups with 20 KiB, the luma shape: 0.96)
+    constexpr unsigned kThreads = 64, kLdsPerWorkgroup = 12288;
+    if (n_units > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)n_units), block(kThreads);
     if (block_edge == 32) hipLaunchKernelGGL(residual_chroma_kernel<5>, grid, block, kLdsPerWorkgroup, stream, d_cur, d_pred, d_res_u, d_res_v, block_pitch, tiles_x, groups_x, n_units);
     else                  hipLaunchKernelGGL(residual_chroma_kernel<3>, grid, block, kLdsPerWorkgroup, stream, d_cur, d_pred, d_res_u, d_res_v, block_pitch, tiles_x, groups_x, n_units);
     return hipGetLastError();
