@@ -457,6 +457,19 @@ def smooth_frame_pair(w, h, pad, seed, mv=(5, -3)):
 # ------------------------------------------------------------------------------------------------
 # the run: device, ranks, timing helpers
 # ------------------------------------------------------------------------------------------------
+def pick_device(local_rank, n_dev, share, env):
+    """HIP device ordinal of the rank torchrun calls LOCAL_RANK: one process per GPU, rank i on device i.  A launcher that instead narrows
+    every rank to ONE visible device (HIP_/ROCR_/CUDA_VISIBLE_DEVICES set per process) leaves ordinal 0 as the rank's own.  Anything
+    else with fewer devices than ranks is a launch error, said here rather than as a failed hipSetDevice."""
+    if share:
+        return local_rank % n_dev
+    if local_rank < n_dev:
+        return local_rank
+    if n_dev == 1 and any(env.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        return 0
+    raise SystemExit("LOCAL_RANK %d but only %d HIP device(s) visible: bench.py runs one rank per GPU" % (local_rank, n_dev))
+
+
 class Bench:
     def __init__(self, args):
         import x266_amd                                                 # the library first: ITS HIP runtime is the process's
@@ -473,7 +486,7 @@ class Bench:
         # path -- shard offsets, max-over-ranks timing, checksum reduction -- can be exercised on a one-GPU box.  RCCL refuses two ranks
         # on one device, so the node-layer legs run there only when X266HIP_RCCL_LIB names the tests' RCCL model.
         self.share = os.environ.get("X266_BENCH_SHARE_GPU") == "1"
-        self.local_rank = local_rank % n_dev if self.share else local_rank
+        self.local_rank = pick_device(local_rank, n_dev, self.share, os.environ)
         self.codec = x266_amd.Codec(self.local_rank)
         self.hip = HipRuntime()
         self.hip.check(self.hip.lib.hipSetDevice(self.local_rank), "hipSetDevice")
@@ -1018,6 +1031,8 @@ def leg_node_batch_and_search(b, node, also, x, z, me):
 def node_legs(b, also, x, z, me):
     """The node layer of the C ABI: BASELINE configs[4] and the other end-to-end scatter / gather figures -- the only legs that talk RCCL."""
     from x266_amd.node import Node
+    if os.environ.get("X266_BENCH_TEST_STALL_RANK") == str(b.rank):         # test hook (never set by the driver): this rank never joins the node layer
+        time.sleep(1e6)
     uid = [Node.unique_id() if b.rank == 0 else None]
     if b.dist is not None:
         b.dist.broadcast_object_list(uid, src=0)

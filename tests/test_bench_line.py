@@ -82,3 +82,17 @@ def test_compact_survives_a_headline_only_and_a_multi_rank_record():
     d = json.loads(_line(full))
     assert d["cpu_baseline"] is None and "also" not in d and len(d["roofline"]["frac_by_rank"]) == 8
     assert len(_line(full)) < 2048
+
+
+def test_rank_to_device_mapping_for_eight_ranks():
+    """torchrun's LOCAL_RANK i -> HIP ordinal i on an 8-GPU node; a launcher that narrows each rank to one visible device -> ordinal 0;
+    fewer devices than ranks without such narrowing is refused with a message (not a failed hipSetDevice deep in the library)."""
+    import pytest
+    assert [bench.pick_device(r, 8, False, {}) for r in range(8)] == list(range(8))
+    assert [bench.pick_device(r, 1, False, {"HIP_VISIBLE_DEVICES": str(r)}) for r in range(8)] == [0] * 8
+    assert [bench.pick_device(r, 1, False, {"ROCR_VISIBLE_DEVICES": str(r)}) for r in range(8)] == [0] * 8
+    assert [bench.pick_device(r, 2, True, {}) for r in range(8)] == [0, 1] * 4         # the one-GPU test hook
+    with pytest.raises(SystemExit, match="LOCAL_RANK 5 but only 4"):
+        bench.pick_device(5, 4, False, {})
+    with pytest.raises(SystemExit):
+        bench.pick_device(1, 1, False, {})

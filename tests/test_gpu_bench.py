@@ -139,3 +139,22 @@ def test_bench_node_legs_with_one_process_per_rank_under_the_rccl_model(ranks, t
     assert also["dct32_scatter_gather"]["link_bound_blocks_per_s"] == pytest.approx(ranks * 153e9 / 2048)
     assert also["stream8k"]["link_bound_frames_per_s"] == pytest.approx(153e9 / ((32400 * 2048 + 518400 * 128) / ranks))
     assert also["satd8x8_me_search_sharded"]["identical_to_single_device"] is True and also["satd8x8_me_search_sharded"]["stripes"] == ranks
+
+
+def test_bench_prints_its_line_when_a_peer_never_joins(tmp_path):
+    """A rank that never reaches the node layer (RCCL hang, dead peer): the other rank's communicator setup blocks; past --node-timeout
+    every rank's watchdog fires, rank 0 prints the compact line WITHOUT the node legs (error named) and the job ends -- no hang, exit 0."""
+    import time
+    model = os.path.join(ROOT, "tests", "rccl_model", "librccl_model.so")
+    tmp = str(tmp_path)
+    env = dict(os.environ, X266_BENCH_SHARE_GPU="1", X266HIP_RCCL_LIB=model, HSA_ENABLE_IPC_MODE_LEGACY="0", X266_BENCH_TEST_STALL_RANK="1")
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dct-blocks", "16384",
+                          "--satd-blocks", "65536", "--stream8k", "6", "--no-transform-set", "--no-me", "--no-cpu-baseline", "--node-timeout", "10"],
+                         cwd=tmp, env=env, capture_output=True, text=True, timeout=300)
+    took = time.time() - t0
+    line, full = _line_and_full(out, tmp)
+    assert took < 120, took
+    assert "did not finish within 10 s" in line["node_layer_error"] and "stream8k" not in line["also"]
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["also"]["dct32_inv"] > 0       # the legs before the node layer are all there

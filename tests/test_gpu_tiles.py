@@ -300,3 +300,44 @@ def test_tile_frames_beyond_4_gib(codec, oracle):
             first = (4 * by + j) * (w // 8) + 4 * bx                   # four consecutive 8x8 blocks of block row 4 by + j
             assert np.array_equal(fetch(d_res8, first * 128, 256, np.int16), r8[j].ravel()), (by, bx, j)
             assert np.array_equal(fetch(d_cost, first * 4, 4, np.uint32), want_cost[j]), (by, bx, j)
+
+
+def test_chroma_of_tile_frames_beyond_4_gib(codec, oracle):
+    """The chroma kernels on a 65600 x 32768 frame (8 396 800 tiles = 4.3 GB per tile array): CTUs at the start, around the tile whose byte
+    offset is 2^32 and at the frame's far corners -- residual in both orders, fused transform, fused cost, planar outputs."""
+    w, h = 65536 + 64, 32768
+    tiles_x, nt = w // 16, (w // 16) * (h // 16)
+    assert nt * 512 > (1 << 32)
+    d_cur, d_pred = codec.alloc(nt * 512), codec.alloc(nt * 512)
+    codec.fill_residual_dev(d_cur.ptr, nt * 256, 0xC2)
+    codec.fill_residual_dev(d_pred.ptr, nt * 256, 0xC3)
+    npl = w * h // 4
+    d_r32, d_r8, d_coef, d_cost = codec.alloc(npl * 4), codec.alloc(npl * 4), codec.alloc(npl * 4), codec.alloc(nt * 8)
+    codec.residual_chroma_dev(d_cur.ptr, d_pred.ptr, w, h, 32, d_r32.ptr, d_r32.ptr + npl * 2)
+    codec.residual_chroma_dev(d_cur.ptr, d_pred.ptr, w, h, 8, d_r8.ptr, d_r8.ptr + npl * 2)
+    codec.dct32_fwd_chroma_from_tiles_dev(d_cur.ptr, d_pred.ptr, w, h, d_coef.ptr, d_coef.ptr + npl * 2)
+    codec.satd8x8_chroma_from_tiles_dev(d_cur.ptr, d_pred.ptr, w, h, d_cost.ptr, d_cost.ptr + nt * 4)
+    codec.stream_sync()
+
+    def fetch(buf, byte_off, count, dtype):
+        out = np.empty(count, dtype)
+        codec._check(codec.L.xHipMemcpyD2H(codec.ctx, out.ctypes.data, buf.ptr + byte_off, out.nbytes), "D2H")
+        return out
+
+    t_edge = (1 << 32) // 512
+    ctus_x = w // 64
+    for cy, cx in [(0, 0), (t_edge // tiles_x // 4, (t_edge % tiles_x) // 4), (h // 64 - 1, ctus_x - 1), (h // 64 - 1, 0), (h // 128, ctus_x - 1)]:
+        sixteen = lambda buf: np.concatenate([fetch(buf, ((4 * cy + j) * tiles_x + 4 * cx) * 512, 2048, np.uint8) for j in range(4)])   # the CTU's 4 x 4 tiles
+        tc, tp = sixteen(d_cur), sixteen(d_pred)
+        u32, v32 = oracle.residual_chroma(tc, tp, 64, 64, 32)
+        u8, v8 = oracle.residual_chroma(tc, tp, 64, 64, 8)
+        ctu = cy * ctus_x + cx
+        for plane, (r32, r8) in enumerate(((u32, u8), (v32, v8))):
+            base = plane * npl * 2
+            assert np.array_equal(fetch(d_r32, base + ctu * 2048, 1024, np.int16), r32), (cy, cx, plane)
+            assert np.array_equal(fetch(d_coef, base + ctu * 2048, 1024, np.int16), oracle.dct32_fwd(r32).ravel()), (cy, cx, plane)
+            want_cost = oracle.satd8x8(r8.reshape(16, 64)).reshape(4, 4)
+            for j in range(4):
+                first = (4 * cy + j) * tiles_x + 4 * cx                  # four consecutive tiles = 8x8 chroma blocks of tile row 4 cy + j
+                assert np.array_equal(fetch(d_r8, base + first * 128, 256, np.int16), r8.reshape(4, 4, 64)[j].ravel()), (cy, cx, plane, j)
+                assert np.array_equal(fetch(d_cost, plane * nt * 4 + first * 4, 4, np.uint32), want_cost[j]), (cy, cx, plane, j)

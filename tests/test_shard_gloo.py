@@ -174,20 +174,34 @@ def test_two_rank_sharded_run_matches_single(oracle, tmp_path):
     assert int(res[0]) == want and int(res[1]) == n and int(res[2]) == 2
 
 
-def test_python_fallback_of_the_plan_functions_equals_the_c_functions():
-    """x266_amd/shard.py falls back to a Python restatement of xShardRange / xMeStripePlan when libx266hip.so cannot be
-    loaded (a host without libamdhip64): same numbers as the C functions the node layer itself uses."""
+def _shard_range_py(n_units, rank, world):
+    """xShardRange restated (the cross-check; the package itself has only the C functions): contiguous shards, the first n % world ranks one unit longer."""
+    q, r = divmod(n_units, world)
+    b = rank * q + min(rank, r)
+    return b, b + q + (1 if rank < r else 0)
+
+
+def _me_stripe_py(height, rng, stripe, n_stripes):
+    """xMeStripePlan restated: block rows dealt like shard_range, reference rows = the stripe's pixel rows +- rng."""
+    b, e = _shard_range_py(height // 8, stripe, n_stripes)
+    return (b, e), (b * 8 - rng, e * 8 + rng)
+
+
+def test_the_c_plan_functions_equal_a_python_restatement():
+    """xShardRange / xMeStripePlan (x266hip_node.cpp), which the node layer, bench.py and x266_amd.shard all use, against the arithmetic
+    written out here; and x266_amd.shard is the C binding (no second implementation in the package)."""
     from x266_amd import shard
-    from x266_amd.node import me_stripe_plan, shard_range
+    from x266_amd.node import me_stripe_plan
+    assert not hasattr(shard, "shard_range_py") and not hasattr(shard, "me_stripe_py")
     for n in (0, 1, 7, 8, 9, 1000, 32400, 518400, (1 << 20) + 3):
         for world in (1, 2, 3, 5, 8):
             for rank in range(world):
-                assert shard.shard_range_py(n, rank, world) == tuple(shard_range(n, rank, world))
+                assert _shard_range_py(n, rank, world) == tuple(shard_range(n, rank, world))
     for height in (8, 64, 544, 1080 - 1080 % 8, 2160):
         for rng in (0, 1, 16, 64):
             for n_stripes in (1, 2, 3, 8, 300):
                 for stripe in range(min(n_stripes, 9)):
-                    assert shard.me_stripe_py(height, rng, stripe, n_stripes) == me_stripe_plan(height, rng, stripe, n_stripes)
+                    assert _me_stripe_py(height, rng, stripe, n_stripes) == me_stripe_plan(height, rng, stripe, n_stripes) == me_stripe(height, rng, stripe, n_stripes)
 
 
 def test_bench_spawns_its_own_ranks_when_run_plainly():
