@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--no-me", action="store_true", help="skip the motion-search legs")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-pointer leg")
     ap.add_argument("--no-transform-set", action="store_true", help="skip the transform-set / front-end / intra legs")
+    ap.add_argument("--no-autotune", action="store_true", help="skip the default-vs-autotuned leg (profiled runs: its candidate launches would mix shapes into the per-kernel averages)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic (replay profiles/traffic.json instead)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # the profiled child of the live traffic passes
@@ -685,6 +686,38 @@ def leg_dct32_inverse_and_fused(b, x, z, pmc, pmc_src):
     return out
 
 
+def leg_autotuned(b, x, z):
+    """The opt-in "autotune" option (include/x266hip.h): the families whose fastest launch shape differs from box to box, default shape and the shape
+    this box's first large call kept, alternating on the same buffers.  The headline and every other leg of the line run the DEFAULTS."""
+    codec, n = b.codec, b.n_dct
+    r, z2 = b.dev(n * 2048), b.dev(n * 2048)
+    ns = b.n_satd
+    d, s = b.dev(ns * 128), b.dev(ns * 4)
+    codec.fill_residual_dev(d.ptr, ns * 64, SATD_SEED, 0, b.stream)
+    nsad = ns * 128 // 2 // 64
+    legs = (("dct32_fwd_inv_fused", 6144.0 * n, lambda: codec.dct32_fwd_inv_dev(x.ptr, z2.ptr, r.ptr, n, b.stream)),
+            ("dct32_reconstruction_only", 4096.0 * n, lambda: codec.dct32_fwd_inv_dev(x.ptr, 0, r.ptr, n, b.stream)),
+            ("satd8x8", float(SATD_BYTES_PER_BLOCK) * ns, lambda: codec.satd8x8_dev(d.ptr, s.ptr, ns, b.stream)),
+            ("sad_8x8", 132.0 * nsad, lambda: codec.sad_dev(8, d.ptr, d.ptr + ns * 64, s.ptr, nsad, b.stream)))
+    out, short = {}, max(4, b.K // 4)
+    for name, nbytes, fn in legs:
+        fr = {}
+        for mode in (0, 1, 0, 1):                                        # default, tuned, default, tuned: the better of two per mode
+            codec.set_option("autotune", mode)
+            leg = b.timed_leg(fn, steps=short, warmup=3)
+            f = nbytes / (leg["kernel_ms"] * 1e-3) / HBM_PEAK_BYTES_PER_S
+            fr[mode] = max(fr.get(mode, 0.0), f)
+        out[name] = {"default_hbm_frac": fr[0], "autotuned_hbm_frac": fr[1]}
+    codec.set_option("autotune", 0)
+    rep = codec.autotune_report()
+    names = {"dct32_fwd_inv_fused": "dct32_fwd_inv", "dct32_reconstruction_only": "dct32_recon_only", "satd8x8": "satd8x8", "sad_8x8": "sad8"}
+    for name, fam in names.items():
+        out[name].update(choice=rep.get(fam, {}).get("choice"), candidate_ms=rep.get(fam, {}).get("ms"))
+    out["same_bytes_default_and_tuned"] = b.same_on_device(z2, z, n * 2048)
+    out["note"] = "candidate 0 = the default shape; candidates in x266hip_abi.hip (kFwdInvCands, kReconCands, kSatdCands, kSadCands)"
+    return out
+
+
 def leg_satd(b, pmc, pmc_src):
     """the 8x8 SATD residual batch (the secondary metric), with the port timed on the host cores at N = 1"""
     n, codec = b.n_satd, b.codec
@@ -1074,7 +1107,7 @@ def run_node_legs_under_watchdog(b, result, also, x, z, me, json_fd):
 # ------------------------------------------------------------------------------------------------
 COMPACT_LIMIT_BYTES = 4096             # target; tests/test_bench_line.py fails the build at 8192
 FULL_RECORD = "bench_full.json"
-_FRAC_KEYS = ("frac", "hbm_frac", "written_hbm_frac", "frac_of_v_sad_u16_floor", "frac_of_v_sad_u8_floor")
+_FRAC_KEYS = ("frac", "hbm_frac", "written_hbm_frac", "frac_of_v_sad_u16_floor", "frac_of_v_sad_u8_floor", "autotuned_hbm_frac")
 _RATE_KEYS = ("value", "frames_per_s", "blocks_per_s", "ms_per_frame")
 _GROUPS = ("transform_set", "classes", "per_ctu_mixed", "fused_from_tiles", "front_end_and_sad")   # containers, not legs: children keep their own names
 
@@ -1237,6 +1270,8 @@ def main():
             also["fused_from_tiles"] = leg_fused_from_tiles(b)
             also["front_end_and_sad"] = leg_front_end_and_sad(b)
             also["intra32"] = leg_intra(b)
+            if not args.no_autotune:
+                also["autotune"] = leg_autotuned(b, x, z)
         if rank == 0 and world == 1 and not args.no_host_api:
             also["host_api"] = leg_host_api(b, min(b.n_dct, 1 << 17))
         result["also"] = also

@@ -85,10 +85,19 @@ int  xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap,
  *   "tile_tiles_per_wave"    xTransformTilesDev: consecutive tiles per wave (0 = 2)
  *   "adaptive_per_wave"      shrink the per-wave run on small batches (default 1)
  *   "me_tile_rows"           motion-search tile height in block rows (0, the default: chosen from the frame size and the CU count)
+ *   "autotune"               0 (default) / 1: boxes differ in which launch shape a few kernels run fastest in (by up to 5 %).  With 1, the FIRST
+ *                            large call of a family -- xDct32FwdInvBatchDev with and without d_coef (>= 2^18 blocks), xSatd8x8BatchDev
+ *                            (>= 2^23 blocks), xSadBatchDev edge >= 8 (>= 128 MiB per input) -- times the family's candidate shapes on the
+ *                            caller's own buffers and stream (that one call is synchronous and launches the kernel ~20 times; every
+ *                            launch writes the same bytes) and the context keeps the fastest; xHipAutotuneReport shows what was
+ *                            measured.  Skipped under stream capture, for overlapping buffers and when the family's own knobs are set.
  * Rounds 1-3 had sixteen more (cache-policy bits, LDS staging on / off, padding, per-kernel LDS charges, ...): the forms they
  * selected lost their A/Bs (profiles/r01_*.txt) and are gone. */
 int  xHipSetOption(x266hip_ctx *ctx, const char *key, int value);
 int  xHipGetOption(const x266hip_ctx *ctx, const char *key, int *value);
+/* "autotune": one text line per tuned family -- "<family> choice <index> ms <per-candidate milliseconds, -1 = not launchable>" --
+ * candidate 0 being the default shape (x266_amd/csrc/x266hip_abi.hip, k*Cands). */
+int  xHipAutotuneReport(const x266hip_ctx *ctx, char *buf, size_t cap);
 
 /* ------------------------------------------------------------------------ */
 /* batch API, device pointers (inputs already resident in HBM)               */

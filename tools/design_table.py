@@ -57,6 +57,12 @@ def table(path):
     add("`dct32_from_tiles_kernel` / `satd8x8_from_tiles_kernel`", f(km(dt)) + " / " + f(km(st)) + " ms",
         e(dt["value"]) + " / " + e(st["value"]) + " blocks (two-kernel paths: " + e(ft["dct32_residual_then_transform"]["value"]) + " / " + e(ft["satd8x8_residual_then_cost"]["value"]) + ")",
         f(dt["hbm_frac"]) + " / " + f(st["hbm_frac"]), f(dt["frac_of_same_box_copy"]) + " copy / " + f(st["frac_of_same_box_read"]) + " read")
+    if "chroma_dct32_from_tiles" in ft:                                  # round 6: the chroma half of the tile stage
+        cd, cs, c32, c8 = ft["chroma_dct32_from_tiles"], ft["chroma_satd8x8_from_tiles"], ft["residual_chroma_32"], ft["residual_chroma_8"]
+        add("`dct32_chroma_from_tiles_kernel` / `satd8x8_chroma_from_tiles_kernel`", f(km(cd)) + " / " + f(km(cs)) + " ms", e(cd["value"]) + " / " + e(cs["value"]) + " blocks",
+            f(cd["hbm_frac"]) + " / " + f(cs["hbm_frac"]), f(cd["frac_of_same_box_copy"]) + " copy / " + f(cs["frac_of_same_box_read"]) + " read")
+        add("`residual_chroma_kernel` 32×32 / 8×8 order", f(km(c32)) + " / " + f(km(c8)) + " ms", e(c32["value"]) + " / " + e(c8["value"]) + " blocks",
+            f(c32["hbm_frac"]) + " / " + f(c8["hbm_frac"]), f(c32["frac_of_same_box_copy"]) + " / " + f(c8["frac_of_same_box_copy"]) + " copy")
     cv = [fe[k] for k in ("conv_input_fmt", "conv_output_420", "residual_luma_32")]
     add("`tile_convert_kernel` in / out, `residual_luma_kernel`", " / ".join(f(km(x)) for x in cv) + " ms", " / ".join(f(x["GBps"] / 1e3, 2) for x in cv) + " TB/s",
         " / ".join(f(x["hbm_frac"], 2) for x in cv), " / ".join(f(x["frac_of_same_box_copy"], 2) for x in cv) + " copy")
@@ -83,6 +89,11 @@ def table(path):
         "PCIe: %.1f / %.1f GB/s each way" % (ha["pageable"]["GBps_each_way"], ha["pinned"]["GBps_each_way"]),
         "%.2f / %.2f of the link with both directions running (%.1f GB/s each way; %.1f / %.1f alone)" % (ha["pageable"]["frac_of_link_both_directions"], ha["pinned"]["frac_of_link_both_directions"],
                                                                                                   lk["each_way_both_directions_at_once"], lk["h2d_alone"], lk["d2h_alone"]))
+    if "autotune" in a:                                                  # round 6: default shape / the shape this box's first large call kept
+        at = a["autotune"]
+        ks = [k for k in ("dct32_fwd_inv_fused", "dct32_reconstruction_only", "satd8x8", "sad_8x8") if k in at]
+        add("`\"autotune\"` option: " + " / ".join(k.replace("dct32_", "") for k in ks), "candidate kept: " + " / ".join(str(at[k]["choice"]) for k in ks), "–",
+            "default " + " / ".join(f(at[k]["default_hbm_frac"]) for k in ks), "autotuned " + " / ".join(f(at[k]["autotuned_hbm_frac"]) for k in ks) + " (of 8 TB/s)")
     head = ("  This box's streams (`roofline.same_box`): copy %.2f, read %.2f, read-no-store %.2f, write %.2f TB/s.  CPU baseline in the same line: %s blocks/s on %d threads (`%s`).\n"
             % (sb["copy_TBps"], sb["read_TBps"], sb["read_no_store_TBps"], sb["write_TBps"], e(d["cpu_baseline"]["value"]), d["cpu_baseline"]["cores"], d["cpu_baseline"]["kind"]))
     return head + "\n" + "\n".join(rows)
@@ -94,6 +105,7 @@ SQ_ROWS = [  # (label, kernels of the derived section of <round>_pmc_sq_counters
     ("`dct32_fwdinv_kernel` with / without the coefficient output", ["dct32_fwdinv_kernel<2, true>", "dct32_fwdinv_kernel<2, false>"]),
     ("`satd8x8_dma_kernel` (round 3's staged kernel: 17.7 / 57 / 14 / 66)", ["satd8x8_dma_kernel"]),
     ("`dct32_from_tiles_kernel` / `satd8x8_from_tiles_dma_kernel`", ["dct32_from_tiles_kernel", "satd8x8_from_tiles_dma_kernel"]),
+    ("`dct32_chroma_from_tiles_kernel` / `satd8x8_chroma_from_tiles_kernel` / `residual_chroma_kernel` 32 / 8", ["dct32_chroma_from_tiles_kernel", "satd8x8_chroma_from_tiles_kernel", "residual_chroma_kernel<5>", "residual_chroma_kernel<3>"]),
     ("`tr_fwd_small_lds_kernel` 4×4 / 8×8 / 16×16", ["tr_fwd_small_lds_kernel<2>", "tr_fwd_small_lds_kernel<3>", "tr_fwd_small_lds_kernel<4>"]),
     ("`tr_inv_small_lds_kernel` 4×4 / 8×8 / 16×16", ["tr_inv_small_lds_kernel<2>", "tr_inv_small_lds_kernel<3>", "tr_inv_small_lds_kernel<4>"]),
     ("`tr_tiles_kernel` forward / inverse", ["tr_tiles_kernel<false>", "tr_tiles_kernel<true>"]),
@@ -119,6 +131,8 @@ def sq_table(path):
         return "–" if all(v == 0 for v in vals) else " / ".join("–" if v == 0 else "%.0f" % (100 * v) if i != 1 else "%.1f" % (100 * v) for v in vals) + " %"
     out = ["  | kernel | MFMA busy | VALU busy | LDS busy | wave time waiting |", "  | --- | --- | --- | --- | --- |"]
     for label, ks in SQ_ROWS:
+        if "chroma" in label and not all(k in rows for k in ks):       # rounds before 6 have no chroma kernels
+            continue
         if not all(k in rows for k in ks):
             raise SystemExit("kernel missing from %s: %s" % (path, [k for k in ks if k not in rows]))
         out.append("  | %s | %s | %s | %s | %s |" % (label, col(ks, 1), col(ks, 2), col(ks, 3), col(ks, 5)))

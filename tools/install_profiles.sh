@@ -9,7 +9,9 @@ python tools/collect_profiles.py $T gpurun_out/prof_$S gpurun_out/pmc_fetch_$S g
 cp gpurun_out/bench_${T}_$S.json profiles/${T}_bench.json
 cp gpurun_out/bench_${T}_${S}_driver_args.json profiles/${T}_bench_driver_args.json
 cp gpurun_out/stream8k_${T}_$S.json profiles/${T}_stream8k.json
-grep '^{"metric"' gpurun_out/prof_$S.log | tail -1 > profiles/${T}_bench_profiled_run.json
+cp gpurun_out/bench_${T}_${S}_line.json profiles/${T}_bench_line.json                      # the compact line, as the driver sees it
+cp gpurun_out/bench_${T}_${S}_driver_args_line.json profiles/${T}_bench_driver_args_line.json
+cp gpurun_out/bench_${T}_${S}_profiled_run.json profiles/${T}_bench_profiled_run.json
 python tools/design_table.py profiles/${T}_bench.json --write
 python - "$T" <<'PY'
 import csv, json, re, sys

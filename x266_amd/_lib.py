@@ -55,6 +55,7 @@ def load_library():
                                  ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_SZ)]
     L.xHipSetOption.argtypes = [_P, ctypes.c_char_p, ctypes.c_int]
     L.xHipGetOption.argtypes = [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    L.xHipAutotuneReport.argtypes = [_P, ctypes.c_char_p, _SZ]
     for name in ("xDct32FwdBatchDev", "xDct32InvBatchDev", "xSatd8x8BatchDev"):
         getattr(L, name).argtypes = [_P, _P, _P, _SZ, _P]
     L.xDct32FwdInvBatchDev.argtypes = [_P, _P, _P, _P, _SZ, _P]
@@ -222,6 +223,16 @@ class Codec:
         v = ctypes.c_int()
         self._check(self.L.xHipGetOption(self.ctx, key.encode(), ctypes.byref(v)), "xHipGetOption(%s)" % key)
         return v.value
+
+    def autotune_report(self):
+        """{family: {"choice": index, "ms": [per-candidate ms]}} of the families the "autotune" option has tuned so far"""
+        buf = ctypes.create_string_buffer(4096)
+        self._check(self.L.xHipAutotuneReport(self.ctx, buf, len(buf)), "xHipAutotuneReport")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            w = line.split()
+            out[w[0]] = {"choice": int(w[2]), "ms": [float(x) for x in w[4:]]}
+        return out
 
     # -- host-pointer batch API (numpy in, numpy out) -------------------------
     def dct32_fwd(self, x):

@@ -480,21 +480,30 @@ hipError_t launch_dct32_pass(const int16_t *d_in, int16_t *d_out, size_t n_block
     return hipGetLastError();
 }
 
-hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,
-                               const DctOps *d_fwd_ops, const DctOps *d_inv_acc_ops, const LaunchCfg &cfg, hipStream_t stream)
+template <int DEPTH>
+static hipError_t launch_dct32_fwdinv_depth(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,
+                                            const DctOps *d_fwd_ops, const DctOps *d_inv_acc_ops, const LaunchCfg &cfg, hipStream_t stream)
 {
-    if (n_blocks == 0) return hipSuccess;
-    constexpr int kDepth = 2;
     const unsigned tpb = (unsigned)cfg.wg_threads;
     const unsigned bpw = units_per_wave_for(cfg, n_blocks);
     const size_t wpw = tpb / 64, waves = (n_blocks + bpw - 1) / bpw, wgs = (waves + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const unsigned need = (kDepth + 1) * 2048u;                                // input slots + the converter
+    const unsigned need = (DEPTH + 1) * 2048u;                                 // input slots + the converter
     const unsigned per_wave = (unsigned)cfg.lds_bytes_per_wave < need ? need : (unsigned)cfg.lds_bytes_per_wave;
     const size_t lds = wpw * (size_t)per_wave;
-    if (d_coef) hipLaunchKernelGGL((dct32_fwdinv_kernel<kDepth, true>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_acc_ops, bpw, per_wave);
-    else        hipLaunchKernelGGL((dct32_fwdinv_kernel<kDepth, false>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_acc_ops, bpw, per_wave);
+    if (lds > 65536) return hipErrorInvalidValue;
+    if (d_coef) hipLaunchKernelGGL((dct32_fwdinv_kernel<DEPTH, true>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_acc_ops, bpw, per_wave);
+    else        hipLaunchKernelGGL((dct32_fwdinv_kernel<DEPTH, false>), dim3((unsigned)wgs), dim3(tpb), lds, stream, d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_acc_ops, bpw, per_wave);
     return hipGetLastError();
+}
+
+// cfg.shape = input slots per wave (DMA depth): 0 or 2 = the default, 3 = the deeper pipeline of the long-lived shapes ("autotune", x266hip_abi.hip)
+hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,
+                               const DctOps *d_fwd_ops, const DctOps *d_inv_acc_ops, const LaunchCfg &cfg, hipStream_t stream)
+{
+    if (n_blocks == 0) return hipSuccess;
+    if (cfg.shape == 3) return launch_dct32_fwdinv_depth<3>(d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_acc_ops, cfg, stream);
+    return launch_dct32_fwdinv_depth<2>(d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_acc_ops, cfg, stream);
 }
 
 hipError_t launch_dct32_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_out,

@@ -98,14 +98,17 @@ __global__ __launch_bounds__(256) void sad_kernel(const uint8_t *__restrict__ a,
 
 }  // namespace
 
-hipError_t launch_sad(int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out, size_t n_blocks, hipStream_t stream)
+// waves_per_wg / lds_per_wg: 0 = the defaults below; other values are the autotuner's candidates (x266hip_abi.hip)
+hipError_t launch_sad(int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out, size_t n_blocks, int waves_per_wg, int lds_per_wg, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
     if (edge != 4 && edge != 8 && edge != 16 && edge != 32 && edge != 64) return hipErrorInvalidValue;
     const size_t chunks = n_blocks * (size_t)(edge * edge / 16);
     // 4x4 (an eighth of its traffic is results): one-wave workgroups of 1 KiB per input, 8 KiB charged; the rest: the read stream's shape
-    const int steps = edge == 4 ? 1 : 4, wpw = edge == 4 ? 1 : 4;
-    const size_t lds = edge == 4 ? 8192 : 32768;
+    const int steps = edge == 4 ? 1 : 4;
+    const int wpw = edge == 4 ? 1 : (waves_per_wg > 0 ? waves_per_wg : 4);
+    const size_t lds = edge == 4 ? 8192 : (lds_per_wg > 0 ? (size_t)lds_per_wg : 32768);
+    if (wpw > 4 || lds > 65536) return hipErrorInvalidValue;
     const size_t waves = (chunks + 64 * steps - 1) / (64 * steps);
     const size_t wgs = (waves + wpw - 1) / wpw;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;

@@ -92,7 +92,7 @@ struct LaunchCfg {
     int units_per_wave;       // streaming launch: consecutive units (DCT blocks / 32-block SATD groups / tiles) per wave; SATD batch: 0 = the kernel's own default
     int wg_threads;           // workgroup size, multiple of 64; SATD batch: 0 = the kernel's own default
     int lds_bytes_per_wave;   // LDS charged per wave (what the kernel uses + padding): 160 KiB / this = cap on resident waves per CU; SATD batch: 0 = default
-    int shape;                // SATD batch only: 0 kernel by batch size, 1 staged kernel, 3 LDS-DMA kernel
+    int shape;                // SATD batch: 0 kernel by batch size, 1 staged kernel, 3 LDS-DMA kernel; fused forward + inverse: input slots per wave (0 = 2, or 3)
 };
 
 // SATD batch: from this many blocks on the LDS-DMA kernel runs (satd_kernels.hip, launch_satd8x8)
@@ -147,7 +147,7 @@ hipError_t launch_satd_search(const uint8_t *d_cur, long long cur_stride, const 
 hipError_t launch_sad_search(const uint8_t *d_cur, long long cur_stride, const uint8_t *d_ref, long long ref_stride,
                               int width, int height, int range, x266_me_result_t *d_best, uint32_t *d_costs,
                               int tile_rows, hipStream_t stream);
-hipError_t launch_sad(int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out, size_t n_blocks, hipStream_t stream);
+hipError_t launch_sad(int edge, const uint8_t *d_a, const uint8_t *d_b, uint32_t *d_out, size_t n_blocks, int waves_per_wg, int lds_per_wg, hipStream_t stream);
 hipError_t launch_tile_convert(bool pack, x266_ref_block_t *d_tiles, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
                                long long strd_y, long long strd_c, int width, int height, hipStream_t stream);
 hipError_t launch_residual_luma(int block_edge, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_res,

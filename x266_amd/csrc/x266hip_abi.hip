@@ -48,6 +48,7 @@ struct x266hip_ctx {
     int adaptive_per_wave = 1;                      // shrink the per-wave run on small batches
     int dct_wg_threads = 0;                         // workgroup size of the DCT32 / transform-set kernels; 0 = the measured best: one-wave workgroups (profiles/r01_wg_occupancy.txt), four-wave ones for the fused forward + inverse kernel (profiles/r05_fused_variants.txt)
     int tile_tiles_per_wave = 0;                    // mixed-class tile kernel: consecutive tiles per wave (0 = 2: the wave's table copy serves two tiles)
+    int autotune = 0;                               // 1: the first large batch of a kernel family times its box-dependent launch shapes on the caller's buffers and keeps the fastest (tune_family below)
     int me_tile_rows = 0;                           // block rows per ME tile: 0 = by frame size (SATD search: 8, 4 or 2; SAD search: 2), else 2, 4, 8 (8: SATD search only; 1 is served by 2)
     // fixed launch shapes (options in rounds 1-3; their sweeps are frozen in profiles/r01_*.txt, r03_tiles_one_launch.txt)
     static constexpr int kDctLdsPerWave = 8192;     // 2 KiB used: at most 20 resident waves per CU
@@ -68,6 +69,12 @@ struct x266hip_ctx {
         bool pinned;
         bool capturing_now;
     };
+    // "autotune": per kernel family the chosen candidate (-1 = not tuned yet) and what every candidate measured
+    enum { kTuneFwdInv, kTuneRecon, kTuneSatd, kTuneSad8, kTuneSad16, kTuneSad32, kTuneSad64, kTuneFamilies };
+    static constexpr int kTuneMaxCands = 6;
+    struct Tuned { int choice = -1; int n = 0; float ms[kTuneMaxCands] = {}; };
+    Tuned tuned[kTuneFamilies];
+    hipEvent_t tune_ev[2] = {};
     static constexpr size_t kMeScratchMax = 8;
     static constexpr int kScratchKinds = 1;
     std::vector<MeScratch> scratch[kScratchKinds];
@@ -169,6 +176,62 @@ int launch_op(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n,
     }
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "kernel launch", e);
     return X266HIP_OK;
+}
+
+// ---- opt-in launch-shape autotuning ("autotune" = 1; off by default; results never depend on it) ---------------------------
+// Boxes of the pool differ in which launch shape a few kernels run fastest in (profiles/r05_fused_variants.txt: the fused forward +
+// inverse kernel's best shape is a different one on four of six boxes, up to 5 % apart).  With the option on, the FIRST call of a
+// family whose batch is large enough to time (the caller says so by `big`) runs every candidate on the caller's own buffers and
+// stream -- one warm-up and three timed launches each, HIP events on that stream, so this one call is synchronous -- and the
+// context keeps the fastest; the default shape (candidate 0) stays unless another one beats it by more than 1 %.  Every candidate
+// writes the same bytes (the parity tests run with the option on as well), so the extra launches only rewrite the outputs.
+// Not while the stream is being captured, and not for calls whose buffers overlap (the caller checks): those use the default.
+template <class Launch>
+int tune_family(x266hip_ctx *ctx, int family, int n_cands, bool big, hipStream_t stream, Launch &&launch)
+{
+    x266hip_ctx::Tuned &t = ctx->tuned[family];
+    if (!ctx->autotune) return 0;
+    if (t.choice >= 0) return t.choice;
+    if (!big) return 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream) (void)hipStreamIsCapturing(stream, &cap);
+    (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone) return 0;
+    for (hipEvent_t &e : ctx->tune_ev)
+        if (!e && hipEventCreate(&e) != hipSuccess) { e = nullptr; (void)hipGetLastError(); return 0; }
+    if (n_cands > x266hip_ctx::kTuneMaxCands) n_cands = x266hip_ctx::kTuneMaxCands;
+    t.n = n_cands;
+    int best = 0;
+    for (int c = 0; c < n_cands; ++c) {
+        t.ms[c] = -1.f;
+        if (launch(c) != hipSuccess) { (void)hipGetLastError(); continue; }
+        bool ok = hipEventRecord(ctx->tune_ev[0], stream) == hipSuccess;
+        for (int r = 0; ok && r < 3; ++r) ok = launch(c) == hipSuccess;
+        float ms = 0.f;
+        ok = ok && hipEventRecord(ctx->tune_ev[1], stream) == hipSuccess && hipEventSynchronize(ctx->tune_ev[1]) == hipSuccess &&
+             hipEventElapsedTime(&ms, ctx->tune_ev[0], ctx->tune_ev[1]) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); continue; }
+        t.ms[c] = ms / 3.f;
+        if (c && t.ms[c] > 0.f && (t.ms[best] <= 0.f || t.ms[c] < t.ms[best])) best = c;
+    }
+    if (best && t.ms[0] > 0.f && t.ms[best] > 0.99f * t.ms[0]) best = 0;   // within 1 % of the default: keep the default
+    t.choice = best;
+    return best;
+}
+
+struct ShapeCand { int units_per_wave, wg_threads, lds_bytes_per_wave, shape; };
+// fused forward + inverse with both outputs: the default first, then the deep long-lived shapes of profiles/r05_fused_variants.txt
+const ShapeCand kFwdInvCands[] = {{2, 256, 12288, 2}, {16, 256, 16384, 3}, {24, 256, 16384, 3}, {16, 128, 20480, 3}, {12, 256, 16384, 3}, {4, 128, 12288, 2}};
+const ShapeCand kReconCands[] = {{8, 256, 12288, 2}, {4, 256, 12288, 2}, {16, 256, 16384, 3}, {8, 128, 12288, 2}, {6, 256, 12288, 2}};
+// SATD batch, LDS-DMA kernel (groups per wave, workgroup, LDS per wave)
+const ShapeCand kSatdCands[] = {{4, 256, 16384, 3}, {2, 256, 16384, 3}, {8, 256, 16384, 3}, {4, 128, 12288, 3}, {6, 256, 12288, 3}, {3, 256, 12288, 3}};
+// SAD batch: (-, waves per workgroup x 64, LDS per WORKGROUP)
+const ShapeCand kSadCands[] = {{0, 256, 32768, 0}, {0, 128, 16384, 0}, {0, 64, 8192, 0}, {0, 256, 24576, 0}, {0, 256, 40960, 0}};
+
+static bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb)
+{
+    const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+    return a && b && x < y + nb && y < x + na;
 }
 
 bool bad_ptrs(const void *a, const void *b, size_t n)
@@ -377,6 +440,7 @@ void xHipCodecFree(x266hip_ctx *ctx)
     for (auto &table : ctx->scratch)
         for (const x266hip_ctx::MeScratch &m : table) { if (m.p) (void)hipFree(m.p); if (m.last_use) (void)hipEventDestroy(m.last_use); }
     for (void *q : ctx->me_retired) (void)hipFree(q);
+    for (hipEvent_t e : ctx->tune_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->d_tile_fwd) (void)hipFree(ctx->d_tile_fwd);
     if (ctx->d_tile_inv) (void)hipFree(ctx->d_tile_inv);
     if (ctx->d_fwd) (void)hipFree(ctx->d_fwd);
@@ -454,6 +518,7 @@ static const OptionDesc kOptions[] = {
     {"satd_lds_bytes_per_wave", &x266hip_ctx::satd_lds_per_wave, 0, 16384, 16},      // whole 16-byte rows; 16 KiB x the four waves of the largest workgroup = the 64 KiB a launch may ask for
     {"tile_tiles_per_wave", &x266hip_ctx::tile_tiles_per_wave, 0, 64, 1},
     {"me_tile_rows", &x266hip_ctx::me_tile_rows, 0, 8, 1},
+    {"autotune", &x266hip_ctx::autotune, 0, 1, 1},
 };
 
 static const OptionDesc *find_option(const char *key)
@@ -479,6 +544,24 @@ int xHipGetOption(const x266hip_ctx *ctx, const char *key, int *value)
     const OptionDesc *o = find_option(key);
     if (!ctx || !o || !value) return X266HIP_EINVAL;
     *value = ctx->*(o->member);
+    return X266HIP_OK;
+}
+
+int xHipAutotuneReport(const x266hip_ctx *ctx, char *buf, size_t cap)
+{
+    if (!ctx || !buf || !cap) return X266HIP_EINVAL;
+    static const char *const names[x266hip_ctx::kTuneFamilies] = {"dct32_fwd_inv", "dct32_recon_only", "satd8x8", "sad8", "sad16", "sad32", "sad64"};
+    std::string out;
+    char line[160];
+    for (int f = 0; f < x266hip_ctx::kTuneFamilies; ++f) {
+        const x266hip_ctx::Tuned &t = ctx->tuned[f];
+        if (t.choice < 0) continue;
+        std::snprintf(line, sizeof line, "%s choice %d ms", names[f], t.choice);
+        out += line;
+        for (int c = 0; c < t.n; ++c) { std::snprintf(line, sizeof line, " %.4f", t.ms[c]); out += line; }
+        out += "\n";
+    }
+    std::snprintf(buf, cap, "%s", out.c_str());
     return X266HIP_OK;
 }
 
@@ -529,12 +612,27 @@ int xDct32FwdInvBatchDev(x266hip_ctx *ctx, const int16_t *d_in, int16_t *d_coef,
         return fail(ctx, X266HIP_EINVAL, "xDct32FwdInvBatchDev: NULL or unaligned buffer");
     X_DEV(ctx);
     LaunchCfg cfg = cfg_for(ctx, 1);
-    // 2 blocks per wave with both outputs (the shape that held on every box); without the coefficient output the wave's traffic is a third less and
-    // its arithmetic the same: 4 blocks per wave, -7 % (profiles/r05_fused_variants.txt, last section)
-    cfg.units_per_wave = ctx->dct_fwdinv_blocks_per_wave ? ctx->dct_fwdinv_blocks_per_wave : (d_coef ? 2 : 8);   // paired over four boxes x three allocations (profiles/r05_fused_variants.txt): reconstruction only 2 -> 4 blocks per wave -8 %, 4 -> 8 another -1 to -4 %; with coefficients 2 is the steady one
-    if (!ctx->dct_wg_threads) cfg.wg_threads = 256;                     // the shape that held 0.73-0.76 of 8 TB/s on every box (profiles/r05_fused_variants.txt)
+    // 2 blocks per wave with both outputs (the shape that held 0.73-0.76 of 8 TB/s on every box); without the coefficient output the wave's traffic is a
+    // third less and its arithmetic the same: 8 blocks per wave (paired over four boxes x three allocations, profiles/r05_fused_variants.txt: 2 -> 4 -8 %, 4 -> 8 another -1 to -4 %)
+    cfg.units_per_wave = ctx->dct_fwdinv_blocks_per_wave ? ctx->dct_fwdinv_blocks_per_wave : (d_coef ? 2 : 8);
+    if (!ctx->dct_wg_threads) cfg.wg_threads = 256;
     cfg.lds_bytes_per_wave = x266hip_ctx::kFwdInvLdsPerWave;
-    hipError_t e = launch_dct32_fwdinv(d_in, d_coef, d_recon, n, ctx->d_fwd, ctx->d_inv_acc, cfg, (hipStream_t)stream);
+    cfg.shape = 2;
+    hipError_t e;
+    const bool knobs_untouched = !ctx->dct_fwdinv_blocks_per_wave && !ctx->dct_wg_threads;
+    const bool disjoint = !ranges_overlap(d_in, n * 2048, d_recon, n * 2048) && !ranges_overlap(d_in, n * 2048, d_coef, n * 2048);
+    if (ctx->autotune && knobs_untouched && disjoint) {
+        const ShapeCand *cands = d_coef ? kFwdInvCands : kReconCands;
+        const int n_cands = d_coef ? (int)(sizeof kFwdInvCands / sizeof kFwdInvCands[0]) : (int)(sizeof kReconCands / sizeof kReconCands[0]);
+        auto run = [&](int c) {
+            LaunchCfg k = cfg;
+            k.units_per_wave = cands[c].units_per_wave; k.wg_threads = cands[c].wg_threads; k.lds_bytes_per_wave = cands[c].lds_bytes_per_wave; k.shape = cands[c].shape;
+            return launch_dct32_fwdinv(d_in, d_coef, d_recon, n, ctx->d_fwd, ctx->d_inv_acc, k, (hipStream_t)stream);
+        };
+        e = run(tune_family(ctx, d_coef ? x266hip_ctx::kTuneFwdInv : x266hip_ctx::kTuneRecon, n_cands, n >= ((size_t)1 << 18), (hipStream_t)stream, run));
+    } else {
+        e = launch_dct32_fwdinv(d_in, d_coef, d_recon, n, ctx->d_fwd, ctx->d_inv_acc, cfg, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fwd+inv launch", e);
     return X266HIP_OK;
 }
@@ -545,6 +643,17 @@ int xSatd8x8BatchDev(x266hip_ctx *ctx, const int16_t *d_diff, uint32_t *d_out, s
     if (n && (!d_diff || !d_out || ((uintptr_t)d_diff & 15u) || ((uintptr_t)d_out & 3u)))
         return fail(ctx, X266HIP_EINVAL, "xSatd8x8BatchDev: NULL or unaligned buffer");
     X_DEV(ctx);
+    const bool knobs_untouched = !ctx->satd_variant && !ctx->satd_groups_per_wave && !ctx->satd_wg_threads && !ctx->satd_lds_per_wave;
+    if (ctx->autotune && knobs_untouched && n >= kSatdDmaMinBlocks && !ranges_overlap(d_diff, n * 128, d_out, n * 4)) {
+        auto run = [&](int c) {
+            LaunchCfg k = cfg_for(ctx, 2);
+            k.units_per_wave = kSatdCands[c].units_per_wave; k.wg_threads = kSatdCands[c].wg_threads; k.lds_bytes_per_wave = kSatdCands[c].lds_bytes_per_wave; k.shape = kSatdCands[c].shape;
+            return launch_satd8x8(d_diff, d_out, n, k, (hipStream_t)stream);
+        };
+        const hipError_t e = run(tune_family(ctx, x266hip_ctx::kTuneSatd, (int)(sizeof kSatdCands / sizeof kSatdCands[0]), n >= ((size_t)1 << 23), (hipStream_t)stream, run));
+        if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "kernel launch", e);
+        return X266HIP_OK;
+    }
     return launch_op(ctx, 2, d_diff, d_out, n, (hipStream_t)stream);
 }
 
@@ -855,7 +964,15 @@ int xSadBatchDev(x266hip_ctx *ctx, int edge, const uint8_t *d_a, const uint8_t *
     if (n && (!d_a || !d_b || !d_out || (((uintptr_t)d_a | (uintptr_t)d_b) & 15u) || ((uintptr_t)d_out & 3u)))
         return fail(ctx, X266HIP_EINVAL, "xSadBatchDev: NULL or unaligned buffer");
     X_DEV(ctx);
-    hipError_t e = launch_sad(edge, d_a, d_b, d_out, n, (hipStream_t)stream);
+    hipError_t e;
+    const size_t in_bytes = n * (size_t)(edge * edge);
+    if (ctx->autotune && edge >= 8 && !ranges_overlap(d_a, in_bytes, d_out, n * 4) && !ranges_overlap(d_b, in_bytes, d_out, n * 4)) {
+        auto run = [&](int c) { return launch_sad(edge, d_a, d_b, d_out, n, kSadCands[c].wg_threads / 64, kSadCands[c].lds_bytes_per_wave, (hipStream_t)stream); };
+        const int family = edge == 8 ? x266hip_ctx::kTuneSad8 : edge == 16 ? x266hip_ctx::kTuneSad16 : edge == 32 ? x266hip_ctx::kTuneSad32 : x266hip_ctx::kTuneSad64;
+        e = run(tune_family(ctx, family, (int)(sizeof kSadCands / sizeof kSadCands[0]), in_bytes >= ((size_t)128 << 20), (hipStream_t)stream, run));
+    } else {
+        e = launch_sad(edge, d_a, d_b, d_out, n, 0, 0, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "sad launch", e);
     return X266HIP_OK;
 }
