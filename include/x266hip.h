@@ -81,7 +81,9 @@ int  xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap,
  *                            best: 64, and 256 for the fused forward + inverse kernel)
  *   "satd_groups_per_wave", "satd_wg_threads", "satd_lds_bytes_per_wave"
  *                            SATD batch: 32-block groups per wave, workgroup size, LDS charged per wave (= cap on resident
- *                            waves per CU); 0 (default) = the chosen kernel's own: 2 / 128 / 6144 staged, 4 / 256 / 16384 LDS-DMA
+ *                            waves per CU); 0 (default) = the chosen kernel's own: 2 / 128 / 6144 staged, 4 / 256 / 16384 LDS-DMA.
+ *                            "satd_lds_bytes_per_wave" takes 0 .. 16384 in multiples of 16 (whole 16-byte rows; 16 KiB x the four waves of
+ *                            the largest workgroup = the 64 KiB a launch may ask for; values below the kernel's own need are raised to it)
  *   "tile_tiles_per_wave"    xTransformTilesDev: consecutive tiles per wave (0 = 2)
  *   "adaptive_per_wave"      shrink the per-wave run on small batches (default 1)
  *   "me_tile_rows"           motion-search tile height in block rows (0, the default: chosen from the frame size and the CU count)

@@ -80,6 +80,27 @@ def child(world, rank, id_file):
             assert np.array_equal(o0.download(np.int16, caps[0] * 1024)[: a * 1024], codec.dct32_inv(zin[: a * 1024]).ravel()), units
             assert np.array_equal(o1.download(np.uint32, caps[1])[:b], codec.satd8x8(din[: b * 64])), units
         print("ok ragged unit counts", flush=True)
+    # an argument error EVERY rank sees identically and that posts nothing (more units than the stream was created for) is refused on
+    # every rank and costs nothing: the stream and the node go on (the root-only refusals -- NULL / unaligned / output in
+    # flight -- do cost the node with one process per GPU, the peers having posted their side)
+    too_many = [caps[0] + 1, caps[1]]
+    try:
+        if root:
+            st.push([dz.ptr, dd.ptr], [outs[0][0].ptr, outs[0][1].ptr], too_many)
+        else:
+            st.push(None, None, too_many)
+        raise AssertionError("units beyond max_units were accepted")
+    except x266_amd.X266Error as e:
+        assert "exceed" in str(e), e
+    if root:
+        st.push([dz.ptr, dd.ptr], [outs[1][0].ptr, outs[1][1].ptr], [3, 9])
+    else:
+        st.push(None, None, [3, 9])
+    st.flush()
+    if root:
+        assert np.array_equal(outs[1][0].download(np.int16, 3 * 1024), codec.dct32_inv(zin[: 3 * 1024]).ravel())
+        assert np.array_equal(outs[1][1].download(np.uint32, 9), codec.satd8x8(din[: 9 * 64]))
+        print("ok a rank-symmetric argument error leaves the node usable", flush=True)
     st.close()
 
     n = 5003

@@ -98,6 +98,27 @@ def test_headline_kernels_against_this_box(bench):
     for name, (fn, units, unit_bytes, stream) in legs.items():
         rel[name], ms = _best_fraction(cd, fn, units * unit_bytes, stream, x, z, nbytes)
         got[name] = (units / ms * 1e3, units * unit_bytes / (ms * 1e-3))
+    # Two more allocation SETS (keep round 4's floors and average the placement out instead of lowering them): where a process's buffers
+    # land moves a kernel by 2-9 % against the stream on the same buffers (profiles/r05_placement.txt), and attempts on the SAME buffers do not
+    # average that out -- fresh buffers are another draw, the best draw is what the kernel can do, a regression is below the floor on every one.
+    D = Dev(cd)
+    for _ in range(2):
+        x2 = D.empty(n * 1024, np.int16)
+        z2, r2 = D.empty_like(x2), D.empty_like(x2)
+        out2 = D.empty(ns, np.int32)
+        cd.fill_residual_dev(x2.data_ptr(), x2.numel(), 0x266)
+        legs2 = {"fwd": (lambda: cd.dct32_fwd_dev(x2.data_ptr(), z2.data_ptr(), n), n, 4096, "copy"),
+                 "inv": (lambda: cd.dct32_inv_dev(z2.data_ptr(), r2.data_ptr(), n), n, 4096, "copy"),
+                 "satd": (lambda: cd.satd8x8_dev(x2.data_ptr(), out2.data_ptr(), ns), ns, 132, "read"),
+                 "fused": (lambda: cd.dct32_fwd_inv_dev(x2.data_ptr(), z2.data_ptr(), r2.data_ptr(), n), n, 6144, "copy")}
+        for name, (fn, units, unit_bytes, stream) in legs2.items():
+            if rel[name] >= FLOORS[name] + 0.02:
+                continue                                               # comfortably above already
+            frac, ms = _best_fraction(cd, fn, units * unit_bytes, stream, x2, z2, nbytes, attempts=2)
+            if frac > rel[name]:
+                rel[name] = frac
+                got[name] = max(got[name], (units / ms * 1e3, units * unit_bytes / (ms * 1e-3)))
+        del x2, z2, r2, out2
     print("\nfractions of this box's streams: " + ", ".join("%s %.3f" % kv for kv in rel.items()) +
           " | of 8 TB/s: " + ", ".join("%s %.3f" % (k, v[1] / HBM_PEAK) for k, v in got.items()))
     assert got["fwd"][0] >= 1e8 and got["fwd"][1] / HBM_PEAK >= 0.70, got       # the north star itself
@@ -108,8 +129,8 @@ def test_headline_kernels_against_this_box(bench):
 
 # fractions of the box's own copy / read / write stream; measured values and boxes in profiles/r04_perf_floor_calibration.txt.  Round 5: where a process's buffers
 # land moves a kernel by 2-9 % against the stream on the same buffers (profiles/r05_placement.txt) and three attempts on the SAME buffers do not average that out:
-# the floors sit under the worst landing seen (forward 0.97-0.99, inverse 0.93-0.96, fused 0.86-0.90, SATD batch 0.87-0.94), a regression is still far below them
-FLOORS = {"fwd": 0.95, "inv": 0.90, "fused": 0.82, "satd": 0.85, "tiles_fwd": 0.91, "tiles_inv": 0.90, "intra_write": 0.64}
+# the headline kernels therefore take the best of up to three allocation SETS against round 4's floors (forward 0.97-0.99, inverse 0.93-0.96, fused 0.86-0.90, SATD batch 0.87-0.94 seen)
+FLOORS = {"fwd": 0.96, "inv": 0.92, "fused": 0.82, "satd": 0.88, "tiles_fwd": 0.91, "tiles_inv": 0.90, "intra_write": 0.64}
 
 
 def test_other_baseline_config_legs_against_this_box(bench):

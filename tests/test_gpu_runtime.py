@@ -52,11 +52,16 @@ def test_pinned_block_outlives_the_array_it_was_handed_out_as(codec):
     assert cd._pinned_live == 1                            # two views alive: nothing freed
     out = cd.dct32_fwd(view)                               # the host-pointer call reads through a VIEW of the pinned block
     assert out.shape == (2, 1024) and np.array_equal(flat, np.arange(1024, 2048, dtype=np.int16))
-    cd.close()                                             # deferred: a block is alive
-    assert cd.ctx is not None
+    with pytest.warns(ResourceWarning, match="1 pinned host block"):
+        cd.close()                                         # deferred: a block is alive -- said aloud ...
+    assert cd.close_deferred and cd.ctx is None
+    with pytest.raises(x266_amd.X266Error, match="closed"):
+        cd.dct32_fwd(flat)                                 # ... and the codec takes no new calls meanwhile
+    assert np.array_equal(flat, np.arange(1024, 2048, dtype=np.int16))   # the pinned memory itself is still there
     del view
     gc.collect()
-    assert cd._pinned_live == 1
+    assert cd._pinned_live == 1 and cd.close_deferred
     del flat
     gc.collect()
-    assert cd._pinned_live == 0 and cd.ctx is None         # last view gone: block freed, then the context
+    assert cd._pinned_live == 0 and cd.ctx is None and not cd.close_deferred   # last view gone: block freed, then the context
+    cd.close()                                             # idempotent

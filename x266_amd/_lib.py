@@ -35,14 +35,16 @@ def build_library(force=False):
 _lib = None
 
 
-def load_library():
+def load_library(path=None):
+    """The product library (cached), or -- path given -- another build of the same ABI, bound afresh."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    path = lib_path()
+    default = path is None
+    path = path or lib_path()
     if not os.path.exists(path):
-        raise X266Error("libx266hip.so is not built (run `make -C x266_amd/csrc`); "
-                        "there is no Python/CPU fallback for the kernels")
+        raise X266Error("%s is not built (run `make -C x266_amd/csrc`); "
+                        "there is no Python/CPU fallback for the kernels" % os.path.basename(path))
     L = ctypes.CDLL(path)
     L.xHipVersion.restype = ctypes.c_char_p
     L.xHipLastError.restype = ctypes.c_char_p
@@ -115,7 +117,8 @@ def load_library():
     L.xDct32PackDctWord.restype = ctypes.c_uint64
     L.dct32_getDct.restype = ctypes.c_ulonglong
     L.satd8x8_getSatd.restype = ctypes.c_uint
-    _lib = L
+    if default:
+        _lib = L
     return L
 
 
@@ -170,8 +173,9 @@ class DeviceBuffer:
 class Codec:
     """Context object mirroring x266hip_ctx (xHipCodecInit / xHipCodecFree)."""
 
-    def __init__(self, device=0):
-        self.L = load_library()
+    def __init__(self, device=0, library=None):
+        """library: another build of the same ABI (tests: libx266hip_waits0.so) instead of the product x266_amd/libx266hip.so"""
+        self.L = load_library(library)
         ctx = _P()
         rc = self.L.xHipCodecInit(ctypes.byref(ctx), int(device))
         if rc != 0 or not ctx.value:
@@ -189,13 +193,34 @@ class Codec:
         return self
 
     def close(self):
-        if getattr(self, "ctx", None):
-            if getattr(self, "_pinned_live", 0) > 0:       # pinned blocks of host_alloc are still referenced: the context goes with the last one
-                self._close_pending = True
+        """Frees the context.  While pinned blocks of host_alloc are still referenced the context cannot go yet (xHipHostFree needs it): the
+        codec is then CLOSED FOR NEW CALLS at once -- they raise -- a ResourceWarning says so, and the context itself is freed with the
+        last block (`close_deferred` is True in between)."""
+        with self._lock():
+            ctx = getattr(self, "ctx", None) or getattr(self, "_ctx_for_free", None)
+            if not ctx:
+                return
+            if getattr(self, "_pinned_live", 0) > 0:
+                if getattr(self, "ctx", None):
+                    import warnings
+                    warnings.warn("Codec.close(): %d pinned host block(s) still referenced; the codec refuses new calls now, its context is "
+                                  "freed with the last block" % self._pinned_live, ResourceWarning, stacklevel=2)
+                self._ctx_for_free, self.ctx = ctx, None
                 return
             if not getattr(self, "_borrowed", False):
-                self.L.xHipCodecFree(self.ctx)
-            self.ctx = None
+                self.L.xHipCodecFree(ctx)
+            self.ctx = self._ctx_for_free = None
+
+    @property
+    def close_deferred(self):
+        return bool(getattr(self, "_ctx_for_free", None))
+
+    def _lock(self):
+        lk = self.__dict__.get("_lk")
+        if lk is None:
+            import threading
+            lk = self.__dict__.setdefault("_lk", threading.RLock())
+        return lk
 
     def __del__(self):
         try:
@@ -205,6 +230,8 @@ class Codec:
 
     def _check(self, rc, what):
         if rc != 0:
+            if not getattr(self, "ctx", None):
+                raise X266Error("%s: the codec is closed" % what)
             raise X266Error("%s failed (%d): %s" % (what, rc, self.L.xHipLastError(self.ctx).decode()))
 
     # -- info / options ----------------------------------------------------
@@ -552,7 +579,8 @@ class _PinnedBlock:
 
     def __init__(self, codec, ptr, nbytes):
         self.codec, self.ptr, self.nbytes = codec, ptr, nbytes
-        codec._pinned_live = getattr(codec, "_pinned_live", 0) + 1
+        with codec._lock():                                             # __del__ below may run on any thread (GC)
+            codec._pinned_live = getattr(codec, "_pinned_live", 0) + 1
         self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
 
     def __del__(self):
@@ -561,10 +589,12 @@ class _PinnedBlock:
         if not ptr or codec is None:
             return
         try:
-            if getattr(codec, "ctx", None):
-                codec.L.xHipHostFree(codec.ctx, ptr)
-            codec._pinned_live -= 1
-            if codec._pinned_live == 0 and getattr(codec, "_close_pending", False):
-                codec.close()
+            with codec._lock():
+                ctx = getattr(codec, "ctx", None) or getattr(codec, "_ctx_for_free", None)
+                if ctx:
+                    codec.L.xHipHostFree(ctx, ptr)
+                codec._pinned_live -= 1
+                if codec._pinned_live == 0 and codec.close_deferred:
+                    codec.close()
         except Exception:
             pass

@@ -177,18 +177,9 @@ __global__ __launch_bounds__(256) void dct32_lds_kernel(const int16_t *__restric
 //    waves per CU.  Deeper pipelines with long-lived waves (3 slots, 16 blocks per wave, 8 waves per CU) are 3-5 % faster on
 //    some boxes and 5-8 % slower on others; this shape gave 0.73-0.76 of 8 TB/s on every one of eight boxes (round 4's
 //    kernel: 0.66-0.77 on the same boxes).
-__device__ __forceinline__ void wait_vmcnt_even(unsigned n)
-{
-    switch (n) {
-#define X266_WAIT(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    X266_WAIT(2) X266_WAIT(4) X266_WAIT(6) X266_WAIT(8) X266_WAIT(10) X266_WAIT(12) X266_WAIT(14) X266_WAIT(16) X266_WAIT(18) X266_WAIT(20)
-    X266_WAIT(22) X266_WAIT(24) X266_WAIT(26) X266_WAIT(28) X266_WAIT(30) X266_WAIT(32) X266_WAIT(34) X266_WAIT(36) X266_WAIT(38) X266_WAIT(40)
-#undef X266_WAIT
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-}
-
 // two 1 KiB-linear stores of one tile: scalar base + the lane's 32-bit offset, "sc1 nt" (x266_device.hpp, store16_sc1nt)
+constexpr unsigned kStoresPerTile = 2;       // global_store instructions store_tile_sc1nt issues (counted by the kernel's waits)
+constexpr unsigned kDmaPerBlock = 2;         // global_load_lds instructions one fetch of a 2 KiB block issues
 __device__ __forceinline__ void store_tile_sc1nt(char *base, unsigned lane_off, const v4i &s0, const v4i &s1)
 {
     asm volatile("global_store_dwordx4 %0, %1, %3 sc1 nt\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024 sc1 nt\n\ts_nop 1"
@@ -248,17 +239,17 @@ __global__ __launch_bounds__(256) void dct32_fwdinv_kernel(const int16_t *__rest
     asm volatile("" : "+v"(kf.p1), "+v"(kf.p2), "+v"(kf.c1), "+v"(kf.c2), "+v"(ki.p1), "+v"(ki.p2), "+v"(ki.c1), "+v"(c2r));
     const int c2s0 = (1 << 10) + (h ? 0 : 128 * 2048);            // swapped pass 2: row v = acc_row(0, 0) = 0 carries the offset fix
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    constexpr unsigned kStoresPerBlock = COEF ? 4u : 2u;
+    constexpr unsigned kStoresPerBlock = (COEF ? 2u : 1u) * kStoresPerTile;          // coefficient tile + reconstruction tile
     unsigned si = 0;                                               // i mod DEPTH
     for (unsigned i = 0; i < cnt; ++i) {
         const unsigned younger_loads = cnt - 1 - i < (unsigned)(DEPTH - 1) ? cnt - 1 - i : (unsigned)(DEPTH - 1);
         const unsigned stores_since = i < (unsigned)DEPTH ? i : (unsigned)DEPTH;
         if (i >= (unsigned)DEPTH && i + DEPTH <= cnt) {             // steady state: DEPTH - 1 younger blocks in flight, DEPTH blocks' stores since
-            constexpr unsigned kSteady = 2u * (DEPTH - 1) + kStoresPerBlock * DEPTH;
-            static_assert(kSteady <= 40, "wait_vmcnt_even");
-            wait_vmcnt_even(kSteady);
+            constexpr unsigned kSteady = kDmaPerBlock * (DEPTH - 1) + kStoresPerBlock * DEPTH;
+            static_assert(kSteady <= kWaitVmcntMax, "steady-state wait beyond wait_vmcnt's range");
+            wait_vmcnt(kSteady);
         } else {
-            wait_vmcnt_even(2u * younger_loads + kStoresPerBlock * stores_since);
+            wait_vmcnt(kDmaPerBlock * younger_loads + kStoresPerBlock * stores_since);
         }
         unsigned char *slot = slots + si * 2048u;
         v4i ylo, yhi;

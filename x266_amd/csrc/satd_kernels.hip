@@ -160,6 +160,7 @@ __device__ __forceinline__ void satd8x8_lds_wave(const int16_t *__restrict__ dif
 // line, n = (l + 64 i) >> 3, j = l & 7: the same whole lines per instruction, permuted inside each line.
 // `group` = the group's first byte, wave-uniform: the address is an SGPR pair + the lane's constant 32-bit offset, no vector
 // address arithmetic per group.  CLAMP: the batch's last, partly filled group -- lanes past the end re-read its last 16 bytes.
+constexpr unsigned kDmaPerGroup = 4;         // global_load_lds instructions one group fetch issues -- satd8x8_dma_issue and tiles_dma_issue alike (counted by the kernels' waits)
 template <bool CLAMP>
 __device__ __forceinline__ void satd8x8_dma_issue(const char *__restrict__ group, size_t bytes_left, const unsigned (&goff)[4], unsigned char *slot)
 {
@@ -225,8 +226,8 @@ __device__ __forceinline__ void satd8x8_dma_wave(const int16_t *__restrict__ dif
     const SatdOperands H = make_satd_operands(lane);
     for (unsigned i = 0; g < end; ++g, ++i) {
         unsigned char *slot = slots + (i & 1) * 4096;
-        if (g + 1 < end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // group g has landed, group g+1 stays in flight
-        else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // group g has landed when only group g+1's DMA may still be out (the cost stores issued in between make the count conservative, never short)
+        wait_vmcnt(g + 1 < end ? kDmaPerGroup : 0u);
         __builtin_amdgcn_wave_barrier();
         const v4i w0 = *reinterpret_cast<const v4i *>(slot + frag[0]), w1 = *reinterpret_cast<const v4i *>(slot + frag[1]);
         const v4i w2 = *reinterpret_cast<const v4i *>(slot + frag[2]), w3 = *reinterpret_cast<const v4i *>(slot + frag[3]);
@@ -457,8 +458,8 @@ __global__ __launch_bounds__(256) void satd8x8_from_tiles_dma_kernel(const x266_
     for (unsigned i = 0; i < cnt; ++i) {
         unsigned char *slot = slots + (i & 1) * 4096;
         // younger than group i's DMA: the 4 DMA of group i + 1 (when there is one) and the cost store of group i - 1 (issued after them)
-        if (i + 1 < cnt) { if (i) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else             { if (i) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        constexpr unsigned kStoresPerGroup = 1;                          // the ONE global_store_dword at the end of the loop body
+        wait_vmcnt((i + 1 < cnt ? kDmaPerGroup : 0u) + (i ? kStoresPerGroup : 0u));
         __builtin_amdgcn_wave_barrier();
         uint2 a[4], b[4];
 #pragma unroll

@@ -49,6 +49,33 @@ __device__ __forceinline__ void store16_sc1(void *p, const v4i &v)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v));
 }
 
+// ---- hand-counted waits ---------------------------------------------------------------------------------------------------
+// The LDS-DMA kernels (dct32_fwdinv_kernel, satd8x8_dma_kernel, satd8x8_from_tiles_dma_kernel) issue their loads and streaming stores as
+// inline asm, invisible to the compiler's vmcnt bookkeeping, and wait by COUNT: a wave's vector memory operations retire in issue
+// order, so "fetch f has landed" = at most {the operations issued after f} outstanding.  Every such count is written as a sum of
+// the per-call instruction counts below (kDmaPer*, kStoresPer*), which the issuing helpers static_assert against what they emit.
+// The check that the sums are right is by execution: `make -C x266_amd/csrc waits0` builds libx266hip_waits0.so with X266_WAIT_ALL,
+// where every counted wait waits for EVERYTHING, and tests/test_gpu_waits.py compares the two libraries byte for byte on ragged,
+// steady-state and single-block runs -- a count that is too high reads an LDS slot before its DMA landed and shows there.
+__device__ __forceinline__ void wait_vmcnt(unsigned n)
+{
+#ifdef X266_WAIT_ALL
+    (void)n;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    switch (n) {
+#define X266_WAIT(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    X266_WAIT(1) X266_WAIT(2) X266_WAIT(3) X266_WAIT(4) X266_WAIT(5) X266_WAIT(6) X266_WAIT(7) X266_WAIT(8) X266_WAIT(9) X266_WAIT(10)
+    X266_WAIT(11) X266_WAIT(12) X266_WAIT(13) X266_WAIT(14) X266_WAIT(15) X266_WAIT(16) X266_WAIT(17) X266_WAIT(18) X266_WAIT(19) X266_WAIT(20)
+    X266_WAIT(21) X266_WAIT(22) X266_WAIT(23) X266_WAIT(24) X266_WAIT(25) X266_WAIT(26) X266_WAIT(27) X266_WAIT(28) X266_WAIT(29) X266_WAIT(30)
+    X266_WAIT(31) X266_WAIT(32) X266_WAIT(33) X266_WAIT(34) X266_WAIT(35) X266_WAIT(36) X266_WAIT(37) X266_WAIT(38) X266_WAIT(39) X266_WAIT(40)
+#undef X266_WAIT
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // 0, and anything beyond the counter's range
+    }
+#endif
+}
+constexpr unsigned kWaitVmcntMax = 40;
+
 // ---- cross-lane sums without LDS traffic (a __shfl_xor is a ds_bpermute: address arithmetic, an LDS instruction and its latency) ----
 // x + (lane ^ 32's x): gfx950's v_permlane32_swap exchanges the upper half of one register with the lower half of another
 __device__ __forceinline__ uint32_t sum_with_other_half(uint32_t x)

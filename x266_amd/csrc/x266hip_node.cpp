@@ -656,7 +656,8 @@ int xNodeFrameStreamCreate(x266hip_node *node, int width, int height, x266hip_ns
 namespace {
 
 // Step t: transfers {inputs of frame t, results of frame t-2}, then kernels of frame t.
-int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units, void *producer_stream, bool has_frame, bool *posted)
+int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units, void *producer_stream, bool has_frame, bool *posted,
+                     bool *root_only_refusal)
 {
     x266hip_node *node = s->node;
     if (node->failed) return nfail(node, X266HIP_ECOMM, "an earlier step of this node failed and its communicators were aborted");
@@ -672,8 +673,10 @@ int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d
             cur.units[l] = units ? units[l] : s->max_units[l];
             if (cur.units[l] > s->max_units[l]) return nfail(node, X266HIP_EINVAL, "xNodeStreamPush: units exceed the stream's max_units");
             if (drives_root && cur.units[l]) {
-                if (!d_in || !d_out || !d_in[l] || !d_out[l] || (((uintptr_t)d_in[l] | (uintptr_t)d_out[l]) & 15u))
+                if (!d_in || !d_out || !d_in[l] || !d_out[l] || (((uintptr_t)d_in[l] | (uintptr_t)d_out[l]) & 15u)) {
+                    *root_only_refusal = true;                         // the peers cannot see this check: they post step t regardless
                     return nfail(node, X266HIP_EINVAL, "xNodeStreamPush: NULL or unaligned frame buffer on the root");
+                }
                 cur.d_in[l] = (const char *)d_in[l];
                 cur.d_out[l] = (char *)d_out[l];
             }
@@ -689,8 +692,10 @@ int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d
                         if (!cur.units[l] || !prev.units[m]) continue;
                         const char *a0 = cur.d_out[l], *a1 = a0 + cur.units[l] * kOutUnit[s->op[l]];
                         const char *b0 = prev.d_out[m], *b1 = b0 + prev.units[m] * kOutUnit[s->op[m]];
-                        if (a0 < b1 && b0 < a1)
+                        if (a0 < b1 && b0 < a1) {
+                            *root_only_refusal = true;
                             return nfail(node, X266HIP_EINVAL, "xNodeStreamPush: an output buffer overlaps the output of a frame still in flight (output rings need X266_STREAM_OUT_RING buffers)");
+                        }
                     }
             }
         }
@@ -808,16 +813,17 @@ int stream_step_impl(x266hip_nstream *s, const void *const *d_in, void *const *d
 
 int stream_step(x266hip_nstream *s, const void *const *d_in, void *const *d_out, const size_t *units, void *producer_stream, bool has_frame)
 {
-    bool posted = false;
-    const int rc = stream_step_impl(s, d_in, d_out, units, producer_stream, has_frame, &posted);
-    // a failure after the step's group was posted -- whatever its code: a per-rank launch can still refuse an argument there --
-    // or any non-argument failure before it: the other ranks will post a group this rank never joins.  With one process per GPU that
-    // holds for ARGUMENT errors too: the checks that involve the root's buffers (NULL / unaligned / an output still in flight) run on
-    // the root only, the peers cannot see them and post step t regardless -- this rank's communicators are aborted and the
-    // node marked failed, so that every later call here says ECOMM instead of pairing step t+1 with the peers' step t; the peers learn
-    // of it the way they learn of any lost rank (their group never completes: the host tears the node down, include/x266hip.h).
+    bool posted = false, root_only_refusal = false;
+    const int rc = stream_step_impl(s, d_in, d_out, units, producer_stream, has_frame, &posted, &root_only_refusal);
+    // When does a failed step cost the node?  (a) after the step's group was posted, whatever the code (a per-rank launch can still refuse
+    // an argument there), and (b) on any non-argument failure before it: the other ranks will post a group this rank never joins.
+    // (c) With one process per GPU also on the argument checks that only the ROOT can make (NULL / unaligned frame buffer, an output
+    // still in flight): the peers post step t regardless, so this rank's communicators are aborted and the node marked
+    // failed -- every later call says ECOMM instead of pairing step t+1 with the peers' step t, and the peers learn of it the way
+    // they learn of any lost rank.  Argument errors EVERY rank sees identically and that post nothing ("units exceed max_units":
+    // all ranks pass the same counts) stay harmless: the call returns EINVAL and the stream is as it was.
     const bool peers_elsewhere = !s->node->single_process && s->node->world > 1;
-    if (rc != X266HIP_OK && (posted || rc != X266HIP_EINVAL || peers_elsewhere)) abort_comms(s->node);
+    if (rc != X266HIP_OK && (posted || rc != X266HIP_EINVAL || (peers_elsewhere && root_only_refusal))) abort_comms(s->node);
     return rc;
 }
 
