@@ -1,6 +1,6 @@
 """The documents' numbers and lists are generated from (or checked against) the code and the committed measurements, so that
-they cannot drift: DESIGN.md section 5's table = tools/design_table.py over profiles/r04_bench.json; the option keys the
-header documents = the keys the library accepts; the kernel count DESIGN states = the kernels in the built library."""
+they cannot drift: DESIGN.md section 0 and profiles/MEASURED.md = tools/design_table.py over the committed bench record; the option
+keys the header documents = the keys the library accepts; the kernel count DESIGN states = the kernels in the built library."""
 import os
 import re
 import subprocess
@@ -12,22 +12,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def test_design_measured_table_is_the_generated_one():
+MEASURED = os.path.join(ROOT, "profiles", "MEASURED.md")
+
+
+def test_measured_table_is_the_generated_one():
     import design_table
-    s = open(os.path.join(ROOT, "DESIGN.md")).read()
+    s = open(MEASURED).read()
     region = s[s.index(design_table.BEGIN) + len(design_table.BEGIN):s.index(design_table.END)]
     src = re.search(r"generated from `([^`]+)`", region).group(1)
     assert region.split("\n\n", 1)[1].strip() == design_table.table(os.path.join(ROOT, src)).strip(), \
-        "DESIGN.md section 5 is stale: python tools/design_table.py %s --write" % src
+        "profiles/MEASURED.md is stale: python tools/design_table.py %s --write" % src
 
 
-def test_design_sq_counter_table_is_the_generated_one():
+def test_sq_counter_table_is_the_generated_one():
     import design_table
-    s = open(os.path.join(ROOT, "DESIGN.md")).read()
+    s = open(MEASURED).read()
     region = s[s.index(design_table.SQ_BEGIN) + len(design_table.SQ_BEGIN):s.index(design_table.SQ_END)]
     src = re.search(r"generated from `([^`]+)`", region).group(1)
     assert region.split("\n\n", 1)[1].strip() == design_table.sq_table(os.path.join(ROOT, src)).strip(), \
-        "DESIGN.md's SQ table is stale: python tools/design_table.py profiles/<round>_bench.json --write"
+        "profiles/MEASURED.md's SQ table is stale: python tools/design_table.py profiles/<round>_bench.json --write"
+
+
+def test_design_summary_is_generated_and_design_stays_short():
+    """DESIGN.md section 0 = the ten-row summary generated from the committed bench record; the whole document stays readable:
+    at most 25 KB and 120 columns (52 KB of 200-400-character lines had become a functional risk)"""
+    import design_table
+    s = open(os.path.join(ROOT, "DESIGN.md")).read()
+    region = s[s.index(design_table.SUM_BEGIN) + len(design_table.SUM_BEGIN):s.index(design_table.SUM_END)]
+    src = re.search(r"generated from `([^`]+)`", region).group(1)
+    assert region.split("\n\n", 1)[1].strip() == design_table.summary(os.path.join(ROOT, src)).strip(), \
+        "DESIGN.md section 0 is stale: python tools/design_table.py %s --write" % src
+    assert len(s.encode()) <= 25 * 1024, len(s.encode())
+    long_lines = [i + 1 for i, l in enumerate(s.splitlines()) if len(l) > 120]
+    assert not long_lines, long_lines[:10]
 
 
 def _abi_option_keys():

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""DESIGN.md section 5's measured table, generated from a committed bench line so that the prose cannot drift from it:
-    python tools/design_table.py profiles/r04_bench.json            # print the table
-    python tools/design_table.py profiles/r04_bench.json --write    # replace the region between the bench-table markers in DESIGN.md
+"""The measured tables, generated from a committed bench record so that the prose cannot drift from it:
+    python tools/design_table.py profiles/r06_bench.json            # print them
+    python tools/design_table.py profiles/r06_bench.json --write    # profiles/MEASURED.md: the per-kernel table and the SQ-counter table (between
+                                                                    # their markers); DESIGN.md: the ten-row summary of section 0
 """
 import json, os, sys
 
@@ -99,6 +100,41 @@ def table(path):
     return head + "\n" + "\n".join(rows)
 
 
+SUM_BEGIN, SUM_END = "<!-- summary:begin (tools/design_table.py) -->", "<!-- summary:end -->"
+
+
+def summary(path):
+    """ten rows of numbers, every line under 120 columns"""
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    a, r = d["also"], d["roofline"]
+    ft, it, s8, mix = a["fused_from_tiles"], a["intra32"], a["stream8k"], a["transform_set"]["per_ctu_mixed"]
+    u, sat, m = a["dct32_fwd_inv_fused"], a["satd8x8"], a["satd8x8_me_search"]
+    rows = ["| leg (BASELINE config) | rate | of 8 TB/s | of this box's stream |", "|---|---|---|---|"]
+    add = lambda *c: rows.append("| " + " | ".join(c) + " |")
+    add("forward DCT32, 2^20 blocks [1] (headline)", e(d["value"]) + " blocks/s", "**" + f(r["frac"]) + "**", f(r["frac_of_same_box_copy"]) + " copy")
+    add("inverse DCT32 [1]", e(a["dct32_inv"]["value"]), f(a["dct32_inv"]["roofline"]["frac"]), f(a["dct32_inv"]["roofline"]["frac_of_same_box_copy"]) + " copy")
+    add("fused forward + inverse [1], 6144 B/block", e(u["value"]), f(u["hbm_frac"]), f(u["frac_of_same_box_copy"]) + " copy")
+    add("8x8 SATD batch, 2^24 blocks (secondary)", e(sat["value"]) + " blocks/s", "**" + f(sat["roofline"]["frac"]) + "**", f(sat["roofline"]["frac_of_same_box_read"]) + " read")
+    add("full-search SATD ME, 4K frame, +-64 [2]", "%.2f ms, %s SATD/s" % (km(m), e(m["value"])), f(m["frac_of_v_sad_u16_floor"]) + " of the VALU floor", "-")
+    o = mix["per_ctu_one_launch"]
+    add("mixed transform set, CTU order, one launch [3]", e(o["value"]) + " CTUs/s", f(o["hbm_frac"]), f(o["frac_of_same_box_copy"]) + " copy")
+    add("7680x4320 stream, node layer, ONE rank [4]", e(s8["frames_per_s"]) + " frames/s", "-", "-")
+    dt, st = ft["dct32_from_tiles"], ft["satd8x8_from_tiles"]
+    add("tiles -> DCT32 / SATD, luma (f2)", e(dt["value"]) + " / " + e(st["value"]), f(dt["hbm_frac"]) + " / " + f(st["hbm_frac"]),
+        f(dt["frac_of_same_box_copy"]) + " copy / " + f(st["frac_of_same_box_read"]) + " read")
+    if "chroma_dct32_from_tiles" in ft:
+        cd, cs = ft["chroma_dct32_from_tiles"], ft["chroma_satd8x8_from_tiles"]
+        add("tiles -> DCT32 / SATD, chroma (f2)", e(cd["value"]) + " / " + e(cs["value"]), f(cd["hbm_frac"]) + " / " + f(cs["hbm_frac"]),
+            f(cd["frac_of_same_box_copy"]) + " copy / " + f(cs["frac_of_same_box_read"]) + " read")
+    pr = it["predict_residual_dct32"]
+    add("intra predict -> residual -> DCT32, one kernel (f4)", e(pr["value"]), f(pr["hbm_frac"]), f(pr["frac_of_same_box_copy"]) + " copy")
+    c = d["cpu_baseline"]
+    add("reference C (`src_tb/dct32.c`) on %d host threads" % c["cores"], e(c["value"]) + " blocks/s", "-", "bit-exact with the GPU batch")
+    out = "\n".join(rows)
+    assert max(len(l) for l in rows) <= 120, max(len(l) for l in rows)
+    return out
+
+
 SQ_BEGIN, SQ_END = "<!-- sq-table:begin (tools/design_table.py) -->", "<!-- sq-table:end -->"
 SQ_ROWS = [  # (label, kernels of the derived section of <round>_pmc_sq_counters.csv)
     ("`dct32_lds_kernel` fwd / inv", ["dct32_lds_kernel<false>", "dct32_lds_kernel<true>"]),
@@ -155,13 +191,18 @@ def main():
             print()
             print(sq)
         return
-    p = os.path.join(ROOT, "DESIGN.md")
+    p = os.path.join(ROOT, "profiles", "MEASURED.md")
     s = open(p).read()
     s = replace_region(s, BEGIN, END, t, os.path.relpath(os.path.abspath(path), ROOT))
     if sq and SQ_BEGIN in s:
         s = replace_region(s, SQ_BEGIN, SQ_END, sq, os.path.relpath(sq_path, ROOT))
     open(p, "w").write(s)
-    print("DESIGN.md: tables regenerated from", path)
+    p = os.path.join(ROOT, "DESIGN.md")
+    s = open(p).read()
+    b, en = s.index(SUM_BEGIN), s.index(SUM_END)
+    s = s[:b] + SUM_BEGIN + "\n(generated from `%s`)\n\n" % os.path.relpath(os.path.abspath(path), ROOT) + summary(path) + "\n\n" + s[en:]
+    open(p, "w").write(s)
+    print("profiles/MEASURED.md and DESIGN.md section 0 regenerated from", path)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 #!/bin/bash
-# After tools/run_profiles.sh <round> <suffix> has come back through gpurun: copy its outputs into profiles/ and regenerate DESIGN.md's tables.
+# After tools/run_profiles.sh <round> <suffix> has come back through gpurun: copy its outputs into profiles/ and regenerate profiles/MEASURED.md and DESIGN.md section 0.
 #   tools/install_profiles.sh <round-tag, e.g. r04> <suffix>
 set -e
 T=${1:?round tag}; S=${2:?suffix}
@@ -20,10 +20,10 @@ d = json.loads(open("profiles/%s_bench_profiled_run.json" % t).read())
 rows = list(csv.reader(open("profiles/%s_bench_kernel_stats.csv" % t)))
 f = [r for r in rows if "dct32_lds_kernel<false>" in r[0]][0]
 s = [r for r in rows if "satd8x8_dma" in r[0]][0]
-new = "within 1–2 %%: forward %.4f ms over %s\n  launches against %.4f, SATD %.4f over %s against %.4f" % (
+new = "within 1–2 %%: forward %.4f ms over %s launches against %.4f, SATD %.4f over %s against\n%.4f" % (
     float(f[3]) / 1e6, f[1], d["roofline"]["kernel_ms_per_launch"], float(s[3]) / 1e6, s[1], d["also"]["satd8x8"]["kernel_ms"])
-D = open("DESIGN.md").read()
-m = re.search(r"within 1–2 %: forward [0-9.]+ ms over \d+\n?\s*launches against [0-9.]+, SATD [0-9.]+ over \d+ against [0-9.]+", D)
-open("DESIGN.md", "w").write(D.replace(m.group(0), new))
+D = open("profiles/MEASURED.md").read()
+m = re.search(r"within 1–2 %: forward [0-9.]+ ms over \d+\s+launches against [0-9.]+, SATD [0-9.]+ over \d+\s+against\s+[0-9.]+", D)
+open("profiles/MEASURED.md", "w").write(D.replace(m.group(0), new))
 print(new)
 PY
