@@ -5,7 +5,7 @@ import ctypes, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import bench
+import bench_cpu as bench
 from _util import Oracle, Reference, ref_path
 
 print("os.cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
