@@ -489,6 +489,7 @@ def compact_record(full):
     r = full.get("roofline") or {}
     line["roofline"] = {k: _sig(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_launch",
                                                      "kernel_ms_mean", "algorithmic_bytes_per_launch", "frac_of_same_box_copy", "frac_at_mean")}
+    line["roofline"]["traffic_measured_live"] = "measured in this run" in str(r.get("traffic_source"))   # else replayed from profiles/traffic.json, or null
     if r.get("frac_by_rank"):
         line["roofline"]["frac_by_rank"] = [_sig(v, 4) for v in r["frac_by_rank"]]
     c = full.get("cpu_baseline")

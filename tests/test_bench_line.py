@@ -39,7 +39,7 @@ def test_compact_line_is_small_and_round_trips():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert abs(r["frac"] - full["roofline"]["frac"]) < 1e-4
     assert r["algorithmic_bytes_per_launch"] == 4096 * full["config"]["blocks_per_gpu"]
-    assert r["traffic"] is not None and r["kernel_ms_per_launch"] <= d["ms_per_step"] * 1.0001
+    assert r["traffic"] is not None and r["traffic_measured_live"] is True and r["kernel_ms_per_launch"] <= d["ms_per_step"] * 1.0001
     c = d["cpu_baseline"]
     assert c["kind"] == "reference" and c["cores"] == 16 and c["unit"] == "blocks/s" and c["gpu_output_bit_exact_vs_cpu"] is True
     assert "BASELINE configs[1]" in d["config"]["workload"] and str(full["config"]["blocks_per_gpu"]) in d["config"]["workload"]
