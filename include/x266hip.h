@@ -272,6 +272,13 @@ int xResidualChromaDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x2
 int xDct32FwdChromaFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred,
                                 int width, int height, int16_t *d_coef_u, int16_t *d_coef_v, size_t block_pitch,
                                 void *stream);
+/* A whole 4:2:0 CTU per unit of output, one launch: for every 64x64 CTU (raster order) 12 KiB of coefficients
+ * d_coef[ctu * 6144 + q * 1024 ..]: q = 0..3 the forward DCT32 of its four 32x32 luma residual quadrants (top-left, top-right,
+ * bottom-left, bottom-right), q = 4 of its 32x32 U residual, q = 5 of V -- bit-identical to xDct32FwdFromTilesDev and
+ * xDct32FwdChromaFromTilesDev, whose frame-raster luma and separate chroma streams it re-orders into the order a per-CTU
+ * encoder loop consumes (BASELINE configs[3]: "batched per-CTU").  width, height multiples of 64. */
+int xDct32FwdCtuFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred,
+                             int width, int height, int16_t *d_coef, void *stream);
 /* Fused chroma residual + SATD: d_out_u[t * pitch] = satd8x8 of tile t's U residual, d_out_v[t * pitch] of its V residual
  * (tiles in raster order) -- bit-identical to xResidualChromaDev(.., 8, ..) followed by xSatd8x8BatchDev.  pitch 2 with
  * d_out_v = d_out_u + 1 interleaves the two costs.  width, height multiples of 16. */

@@ -161,6 +161,37 @@ def test_chroma_residual_then_transform_and_cost(codec, oracle, w, h):
             assert np.array_equal(sb[:, 0], want_u) and np.array_equal(sb[:, 1], want_v)
 
 
+@pytest.mark.parametrize("w,h", [(64, 64), (192, 128), (448, 832), (1920, 1088 - 1088 % 64), (3136, 1792)])
+def test_whole_ctu_in_one_launch(codec, oracle, w, h):
+    """xDct32FwdCtuFromTilesDev: per 64x64 CTU the six coefficient blocks Y0 Y1 Y2 Y3 U V (12 KiB, CTU raster order) from ONE launch --
+    against the oracle on the planes the tiles were packed from, and against the frame-raster luma / planar chroma calls it re-orders."""
+    yc, uc, vc = _yuv(w, h, 41 + w)
+    yp, up, vp = _yuv(w, h, 42 + w)
+    dc, nt = _pack(codec, yc, uc, vc, w, h)
+    dp, _ = _pack(codec, yp, up, vp, w, h)
+    n_ctu = (w // 64) * (h // 64)
+    dz = codec.alloc(n_ctu * 6 * 2048)
+    dz.upload(np.full(n_ctu * 6 * 1024, 0x5555, np.int16))
+    codec.dct32_fwd_ctu_from_tiles_dev(dc.ptr, dp.ptr, w, h, dz.ptr)
+    codec.stream_sync()
+    got = dz.download(np.int16, n_ctu * 6 * 1024).reshape(n_ctu, 6, 1024)
+    dy = (yc.astype(np.int16) - yp.astype(np.int16)).reshape(h // 64, 2, 32, w // 64, 2, 32).transpose(0, 3, 1, 4, 2, 5).reshape(n_ctu, 4, 1024)
+    du = (uc.astype(np.int16) - up.astype(np.int16)).reshape(h // 64, 32, w // 64, 32).transpose(0, 2, 1, 3).reshape(n_ctu, 1024)
+    dv = (vc.astype(np.int16) - vp.astype(np.int16)).reshape(h // 64, 32, w // 64, 32).transpose(0, 2, 1, 3).reshape(n_ctu, 1024)
+    want = oracle.dct32_fwd(np.concatenate([dy, du[:, None], dv[:, None]], axis=1).reshape(-1, 1024), threads=8).reshape(n_ctu, 6, 1024)
+    assert np.array_equal(got, want)
+    # the two calls it stands for: luma in frame raster order of 32x32 blocks, chroma per CTU
+    dl, dcu, dcv = codec.alloc(w * h * 2), codec.alloc(n_ctu * 2048), codec.alloc(n_ctu * 2048)
+    codec.dct32_fwd_from_tiles_dev(dc.ptr, dp.ptr, w, h, dl.ptr)
+    codec.dct32_fwd_chroma_from_tiles_dev(dc.ptr, dp.ptr, w, h, dcu.ptr, dcv.ptr)
+    codec.stream_sync()
+    luma = dl.download(np.int16, w * h).reshape(h // 64, 2, w // 64, 2, 1024).transpose(0, 2, 1, 3, 4).reshape(n_ctu, 4, 1024)
+    assert np.array_equal(got[:, :4], luma)
+    assert np.array_equal(got[:, 4], dcu.download(np.int16, n_ctu * 1024).reshape(n_ctu, 1024))
+    assert np.array_equal(got[:, 5], dcv.download(np.int16, n_ctu * 1024).reshape(n_ctu, 1024))
+    assert codec.L.xDct32FwdCtuFromTilesDev(codec.ctx, dc.ptr, dp.ptr, w + 32, h, dz.ptr, None) < 0      # not whole CTUs
+
+
 def test_chroma_extreme_pixels(codec, oracle):
     """0 / 255 chroma samples: differences of +-255 through the single-byte-plane fused paths"""
     w, h = 128, 64

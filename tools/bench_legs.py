@@ -227,10 +227,13 @@ def leg_fused_from_tiles(b):
     # the chroma half (m_C of the same tiles, src/x266.cpp:60): per 64x64 CTU one 32x32 U and one 32x32 V block -> 2^19 DCT32 blocks; per tile
     # one 8x8 U and V block -> 2^23 SATD blocks.  Planar U / V output streams.  The read side touches ONE 128-byte line of every 512-byte tile.
     nc32, nc8 = fw * fh // 4096 * 2, ntile * 2
+    fctu = b.dev(fw * fh * 3)
     legs += (("chroma_dct32_from_tiles", nc32, 4096,
               lambda: codec.dct32_fwd_chroma_from_tiles_dev(tcur.ptr, tpred.ptr, fw, fh, fcoef.ptr, fcoef.ptr + nc32 * 1024, 1, b.stream)),
              ("chroma_satd8x8_from_tiles", nc8, 132,
               lambda: codec.satd8x8_chroma_from_tiles_dev(tcur.ptr, tpred.ptr, fw, fh, fcost.ptr, fcost.ptr + ntile * 4, 1, b.stream)),
+             ("ctu_dct32_from_tiles", fw * fh // 4096 * 6, 4096,      # a whole 4:2:0 CTU per 12 KiB of output: Y0 Y1 Y2 Y3 U V, one launch
+              lambda: codec.dct32_fwd_ctu_from_tiles_dev(tcur.ptr, tpred.ptr, fw, fh, fctu.ptr, b.stream)),
              ("residual_chroma_32", nc32, 4096,
               lambda: codec.residual_chroma_dev(tcur.ptr, tpred.ptr, fw, fh, 32, fres.ptr, fres.ptr + nc32 * 1024, 1, b.stream)),
              ("residual_chroma_8", nc8, 256,

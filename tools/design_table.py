@@ -62,6 +62,9 @@ def table(path):
         cd, cs, c32, c8 = ft["chroma_dct32_from_tiles"], ft["chroma_satd8x8_from_tiles"], ft["residual_chroma_32"], ft["residual_chroma_8"]
         add("`dct32_chroma_from_tiles_kernel` / `satd8x8_chroma_from_tiles_kernel`", f(km(cd)) + " / " + f(km(cs)) + " ms", e(cd["value"]) + " / " + e(cs["value"]) + " blocks",
             f(cd["hbm_frac"]) + " / " + f(cs["hbm_frac"]), f(cd["frac_of_same_box_copy"]) + " copy / " + f(cs["frac_of_same_box_read"]) + " read")
+        if "ctu_dct32_from_tiles" in ft:
+            cu = ft["ctu_dct32_from_tiles"]
+            add("`dct32_ctu_from_tiles_kernel` (a 4:2:0 CTU's six blocks, CTU order, one launch)", f(km(cu)) + " ms", e(cu["value"]) + " blocks", f(cu["hbm_frac"]), f(cu["frac_of_same_box_copy"]) + " copy")
         add("`residual_chroma_kernel` 32×32 / 8×8 order", f(km(c32)) + " / " + f(km(c8)) + " ms", e(c32["value"]) + " / " + e(c8["value"]) + " blocks",
             f(c32["hbm_frac"]) + " / " + f(c8["hbm_frac"]), f(c32["frac_of_same_box_copy"]) + " / " + f(c8["frac_of_same_box_copy"]) + " copy")
     cv = [fe[k] for k in ("conv_input_fmt", "conv_output_420", "residual_luma_32")]

@@ -80,6 +80,7 @@ def load_library(path=None):
     L.xSatd8x8FromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
     L.xResidualChromaDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_size_t, _P]
     L.xDct32FwdChromaFromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_size_t, _P]
+    L.xDct32FwdCtuFromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
     L.xSatd8x8ChromaFromTilesDev.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_size_t, _P]
     L.xSadBatchDev.argtypes = [_P, ctypes.c_int, _P, _P, _P, _SZ, _P]
     L.xTransformInvBatchDev.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, _P, _SZ, _P, _P]
@@ -404,6 +405,9 @@ class Codec:
     def dct32_fwd_chroma_from_tiles_dev(self, d_cur, d_pred, w, h, d_coef_u, d_coef_v, block_pitch=1, stream=0):
         self._check(self.L.xDct32FwdChromaFromTilesDev(self.ctx, d_cur, d_pred, w, h, d_coef_u, d_coef_v, block_pitch, stream),
                     "xDct32FwdChromaFromTilesDev")
+
+    def dct32_fwd_ctu_from_tiles_dev(self, d_cur, d_pred, w, h, d_coef, stream=0):
+        self._check(self.L.xDct32FwdCtuFromTilesDev(self.ctx, d_cur, d_pred, w, h, d_coef, stream), "xDct32FwdCtuFromTilesDev")
 
     def satd8x8_chroma_from_tiles_dev(self, d_cur, d_pred, w, h, d_out_u, d_out_v, pitch=1, stream=0):
         self._check(self.L.xSatd8x8ChromaFromTilesDev(self.ctx, d_cur, d_pred, w, h, d_out_u, d_out_v, pitch, stream),

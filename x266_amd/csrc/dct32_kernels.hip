@@ -411,6 +411,78 @@ __global__ __launch_bounds__(256) void dct32_chroma_from_tiles_kernel(const x266
     }
 }
 
+// ---- a whole 4:2:0 CTU in one launch ----------------------------------------------------------------------------------------
+// coef[ctu][0..3] = DCT32 of the CTU's four 32x32 luma residual quadrants (raster order inside the CTU), coef[ctu][4] = U,
+// coef[ctu][5] = V: 12 KiB per 64x64 CTU, CTUs in raster order -- the order a per-CTU encoder loop consumes, from ONE grid
+// instead of xDct32FwdFromTilesDev + xDct32FwdChromaFromTilesDev (frame-raster luma, separate chroma streams).  Five waves per
+// CTU: four take one luma quadrant each (dct32_from_tiles_kernel's body), the fifth both chroma planes
+// (dct32_chroma_from_tiles_kernel's body: their fragments come from the same loads).  The part index is wave-uniform.
+__global__ __launch_bounds__(256) void dct32_ctu_from_tiles_kernel(const x266_ref_block_t *__restrict__ cur,
+                                                                   const x266_ref_block_t *__restrict__ pred,
+                                                                   int16_t *__restrict__ out, int ctus_x, int tiles_x, size_t n_ctus,
+                                                                   const DctOps *__restrict__ ops, unsigned lds_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
+    const int lane = threadIdx.x & 63;
+    const unsigned wave_in_wg = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned char *slot = stage + wave_in_wg * lds_per_wave;
+    const size_t unit = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+    const size_t ctu = unit / 5;
+    const unsigned part = (unsigned)(unit - ctu * 5);
+    if (ctu >= n_ctus) return;
+    const unsigned c = lane & 31, h = lane >> 5;
+    const size_t cy = ctu / ctus_x, cx = ctu - cy * ctus_x;
+    const LaneConsts k = load_consts(ops, lane);
+    const uint32_t S = 0x80808080u;
+    const v16i round1 = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};
+    const unsigned lin0 = lds_slot(lane >> 2, lane & 3), lin1 = lds_slot(16 + (lane >> 2), lane & 3);
+    const unsigned frag0 = lds_slot(c, 2 * h), frag1 = lds_slot(c, 2 * h + 1);
+    char *dst = reinterpret_cast<char *>(out + ctu * 6144) + lane * 16;
+    if (part < 4) {
+        // luma quadrant (part >> 1, part & 1): row c of the quadrant, columns 16h .. 16h+15 = one 16-byte luma row of one tile
+        const size_t tile = (cy * 4 + (part >> 1) * 2 + (c >> 4)) * (size_t)tiles_x + cx * 4 + (part & 1) * 2 + h;
+        const v4i a = load16<true>(reinterpret_cast<const unsigned char *>(cur + tile) + (c & 15) * 16);
+        const v4i b = load16<true>(reinterpret_cast<const unsigned char *>(pred + tile) + (c & 15) * 16);
+        const v4i bias = {(int)S, (int)S, (int)S, (int)S};
+        v16i acc = mfma(a ^ bias, k.p1, round1);
+        acc = mfma(b ^ bias, k.tr, acc);
+        v4i o0, o1;
+        fwd_finish<4, 11>(acc, k, o0, o1);
+        *reinterpret_cast<v4i *>(slot + frag0) = o0;
+        *reinterpret_cast<v4i *>(slot + frag1) = o1;
+        __builtin_amdgcn_wave_barrier();
+        const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
+        const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
+        store16_sc1nt(dst + part * 2048, s0);
+        store16_sc1nt(dst + part * 2048 + 1024, s1);
+        return;
+    }
+    const size_t tile = (cy * 4 + (c >> 3)) * (size_t)tiles_x + cx * 4 + 2 * h;
+    const unsigned char *pc = reinterpret_cast<const unsigned char *>(cur + tile) + 256 + (c & 7) * 16;
+    const unsigned char *pp = reinterpret_cast<const unsigned char *>(pred + tile) + 256 + (c & 7) * 16;
+    const v4i a0 = load16<true>(pc), a1 = load16<true>(pc + 512), b0 = load16<true>(pp), b1 = load16<true>(pp + 512);
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane) {
+        const uint32_t sel = plane ? 0x07050301u : 0x06040200u;
+        const v4i a = {(int)(bperm((uint32_t)a0[1], (uint32_t)a0[0], sel) ^ S), (int)(bperm((uint32_t)a0[3], (uint32_t)a0[2], sel) ^ S),
+                       (int)(bperm((uint32_t)a1[1], (uint32_t)a1[0], sel) ^ S), (int)(bperm((uint32_t)a1[3], (uint32_t)a1[2], sel) ^ S)};
+        const v4i b = {(int)(bperm((uint32_t)b0[1], (uint32_t)b0[0], sel) ^ S), (int)(bperm((uint32_t)b0[3], (uint32_t)b0[2], sel) ^ S),
+                       (int)(bperm((uint32_t)b1[1], (uint32_t)b1[0], sel) ^ S), (int)(bperm((uint32_t)b1[3], (uint32_t)b1[2], sel) ^ S)};
+        v16i acc = mfma(a, k.p1, round1);
+        acc = mfma(b, k.tr, acc);
+        v4i o0, o1;
+        fwd_finish<4, 11>(acc, k, o0, o1);
+        if (plane) __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<v4i *>(slot + frag0) = o0;
+        *reinterpret_cast<v4i *>(slot + frag1) = o1;
+        __builtin_amdgcn_wave_barrier();
+        const v4i s0 = *reinterpret_cast<const v4i *>(slot + lin0);
+        const v4i s1 = *reinterpret_cast<const v4i *>(slot + lin1);
+        store16_sc1nt(dst + (4 + plane) * 2048, s0);
+        store16_sc1nt(dst + (4 + plane) * 2048 + 1024, s1);
+    }
+}
+
 // ---- the 1-D pass on its own (partialButterfly32, src_tb/dct32.c:66-170; RTL stage src/mkDct32.bsv:213-284) --------
 // dst[k*32 + j] = (int16)((sum_n g[k][n] * src[j*32 + n] + (1 << (shift-1))) >> shift): one MFMA pass of the forward
 // kernel with the accumulators stored TRANSPOSED, as the reference does.  Lane (c, h) holds frequency kappa(c) for the 16
@@ -524,6 +596,21 @@ hipError_t launch_dct32_chroma_from_tiles(const x266_ref_block_t *d_cur, const x
     // 0.332 against 0.340 ms, 0.97 of the box's copy of the same bytes (tools/probes/gpu_chroma_shapes.py, profiles/r06_chroma_shapes.txt)
     const unsigned per_wave = (unsigned)cfg.lds_bytes_per_wave < 12288u ? 12288u : (unsigned)cfg.lds_bytes_per_wave;
     hipLaunchKernelGGL(dct32_chroma_from_tiles_kernel, dim3((unsigned)wgs), dim3(tpb), wpw * (size_t)per_wave, stream, d_cur, d_pred, d_out_u, d_out_v, block_pitch,
+                       ctus_x, width / 16, n_ctus, d_fwd_ops, per_wave);
+    return hipGetLastError();
+}
+
+hipError_t launch_dct32_ctu_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_out,
+                                       int width, int height, const DctOps *d_fwd_ops, const LaunchCfg &cfg, hipStream_t stream)
+{
+    const int ctus_x = width / 64;
+    const size_t n_ctus = (size_t)ctus_x * (size_t)(height / 64);
+    if (n_ctus == 0) return hipSuccess;
+    const unsigned tpb = (unsigned)cfg.wg_threads;
+    const size_t wpw = tpb / 64, units = n_ctus * 5, wgs = (units + wpw - 1) / wpw;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const unsigned per_wave = (unsigned)cfg.lds_bytes_per_wave;
+    hipLaunchKernelGGL(dct32_ctu_from_tiles_kernel, dim3((unsigned)wgs), dim3(tpb), wpw * (size_t)per_wave, stream, d_cur, d_pred, d_out,
                        ctus_x, width / 16, n_ctus, d_fwd_ops, per_wave);
     return hipGetLastError();
 }

@@ -183,6 +183,8 @@ hipError_t launch_residual_chroma(int block_edge, const x266_ref_block_t *d_cur,
                                   size_t block_pitch, int width, int height, hipStream_t stream);
 hipError_t launch_dct32_chroma_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_out_u, int16_t *d_out_v,
                                           size_t block_pitch, int width, int height, const DctOps *d_fwd_ops, const LaunchCfg &cfg, hipStream_t stream);
+hipError_t launch_dct32_ctu_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int16_t *d_out,
+                                       int width, int height, const DctOps *d_fwd_ops, const LaunchCfg &cfg, hipStream_t stream);
 hipError_t launch_satd8x8_chroma_from_tiles(const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, uint32_t *d_out_u, uint32_t *d_out_v,
                                             size_t pitch, int width, int height, hipStream_t stream);
 hipError_t launch_mem_ceiling(int kind, const void *d_src, void *d_dst, size_t bytes, hipStream_t stream);

@@ -942,6 +942,19 @@ int xDct32FwdChromaFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur,
     return X266HIP_OK;
 }
 
+int xDct32FwdCtuFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int width, int height,
+                             int16_t *d_coef, void *stream)
+{
+    if (!ctx) return X266HIP_EINVAL;
+    if (width <= 0 || height <= 0 || (width & 63) || (height & 63)) return fail(ctx, X266HIP_EINVAL, "xDct32FwdCtuFromTilesDev: width/height must be multiples of 64");
+    if (!d_cur || !d_pred || !d_coef || ((((uintptr_t)d_cur | (uintptr_t)d_pred | (uintptr_t)d_coef)) & 15u))
+        return fail(ctx, X266HIP_EINVAL, "xDct32FwdCtuFromTilesDev: NULL or unaligned buffer");
+    X_DEV(ctx);
+    hipError_t e = launch_dct32_ctu_from_tiles(d_cur, d_pred, d_coef, width, height, ctx->d_fwd, cfg_for(ctx, 0), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "fused CTU transform launch", e);
+    return X266HIP_OK;
+}
+
 int xSatd8x8ChromaFromTilesDev(x266hip_ctx *ctx, const x266_ref_block_t *d_cur, const x266_ref_block_t *d_pred, int width, int height,
                                uint32_t *d_out_u, uint32_t *d_out_v, size_t pitch, void *stream)
 {
