@@ -184,7 +184,8 @@ int launch_op(x266hip_ctx *ctx, int op, const void *d_in, void *d_out, size_t n,
 // family whose batch is large enough to time (the caller says so by `big`) runs every candidate on the caller's own buffers and
 // stream -- one warm-up and three timed launches each, HIP events on that stream, so this one call is synchronous -- and the
 // context keeps the fastest; the default shape (candidate 0) stays unless another one beats it by more than 1 %.  Every candidate
-// writes the same bytes (the parity tests run with the option on as well), so the extra launches only rewrite the outputs.
+// writes the same bytes (tests/test_gpu_autotune.py compares option off / on per family; tests/test_gpu_waits.py every fused candidate against the
+// wait-for-everything build), so the extra launches only rewrite the outputs.
 // Not while the stream is being captured, and not for calls whose buffers overlap (the caller checks): those use the default.
 template <class Launch>
 int tune_family(x266hip_ctx *ctx, int family, int n_cands, bool big, hipStream_t stream, Launch &&launch)
