@@ -91,7 +91,7 @@ int  xHipDeviceInfo(const x266hip_ctx *ctx, char *name, size_t name_cap,
  *                            large call of a family -- xDct32FwdInvBatchDev with and without d_coef (>= 2^18 blocks), xSatd8x8BatchDev
  *                            (>= 2^23 blocks), xSadBatchDev edge >= 8 (>= 128 MiB per input) -- times the family's candidate shapes on the
  *                            caller's own buffers and stream (that one call is synchronous and launches the kernel ~20 times; every
- *                            launch writes the same bytes) and the context keeps the fastest; xHipAutotuneReport shows what was
+ *                            launch writes the same bytes) and the context keeps the fastest (the default unless beaten by > 2 %); xHipAutotuneReport shows what was
  *                            measured.  Skipped under stream capture, for overlapping buffers and when the family's own knobs are set.
  * Rounds 1-3 had sixteen more (cache-policy bits, LDS staging on / off, padding, per-kernel LDS charges, ...): the forms they
  * selected lost their A/Bs (profiles/r01_*.txt) and are gone. */

@@ -57,9 +57,9 @@ def test_fused_depth_three_shapes_of_the_autotuner(waits0):
     n = (1 << 18) + 3
     tuned = x266_amd.Codec(0)
     try:
-        tuned.set_option("autotune", 1)                                  # the tuning call itself launches all six candidates over the outputs
+        tuned.set_option("autotune", 1)                                  # the tuning call itself launches all eight candidates over the outputs
         a = _fused(tuned, n, True, 0x71, {})
-        assert len(tuned.autotune_report()["dct32_fwd_inv"]["ms"]) == 6
+        assert len(tuned.autotune_report()["dct32_fwd_inv"]["ms"]) == 8
     finally:
         tuned.close()
     b = _fused(waits0, n, True, 0x71, {})

@@ -560,12 +560,13 @@ static hipError_t launch_dct32_fwdinv_depth(const int16_t *d_in, int16_t *d_coef
     return hipGetLastError();
 }
 
-// cfg.shape = input slots per wave (DMA depth): 0 or 2 = the default, 3 = the deeper pipeline of the long-lived shapes ("autotune", x266hip_abi.hip)
+// cfg.shape = input slots per wave (DMA depth): 0 or 2 = the default, 3 / 4 = the deeper pipelines of the long-lived shapes ("autotune", x266hip_abi.hip)
 hipError_t launch_dct32_fwdinv(const int16_t *d_in, int16_t *d_coef, int16_t *d_recon, size_t n_blocks,
                                const DctOps *d_fwd_ops, const DctOps *d_inv_acc_ops, const LaunchCfg &cfg, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
     if (cfg.shape == 3) return launch_dct32_fwdinv_depth<3>(d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_acc_ops, cfg, stream);
+    if (cfg.shape == 4) return launch_dct32_fwdinv_depth<4>(d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_acc_ops, cfg, stream);
     return launch_dct32_fwdinv_depth<2>(d_in, d_coef, d_recon, n_blocks, d_fwd_ops, d_inv_acc_ops, cfg, stream);
 }
 
