@@ -519,3 +519,18 @@ def test_two_host_threads_two_contexts(oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("n_dct,n_satd", [(1, 1), (31, 511), (32, 512), (33, 513), (70, 1100)])
+def test_small_host_pointer_calls_on_both_sides_of_the_64_kib_path(codec, oracle, n_dct, n_satd):
+    """Host-pointer calls of up to 64 KiB each way (the BDPI shims: one block per call) run the kernel directly on page-locked host memory
+    (x266hip_abi.hip, host_batch); larger ones go through the staged three-slot pipeline.  Same bytes either side of the switch."""
+    x = fullrange_np(n_dct * 1024, 900 + n_dct).reshape(n_dct, 1024)
+    assert np.array_equal(codec.dct32_fwd(x), oracle.dct32_fwd(x))
+    z = residual_np(n_dct * 1024, 901 + n_dct).reshape(n_dct, 1024)
+    assert np.array_equal(codec.dct32_inv(z), oracle.dct32_inv(z))
+    d = fullrange_np(n_satd * 64, 902 + n_satd).reshape(n_satd, 64)
+    assert np.array_equal(codec.satd8x8(d), oracle.satd8x8(d))
+    for _ in range(3):                                                   # the two pinned buffers are reused call after call
+        x1 = residual_np(1024, 903).reshape(1, 1024)
+        assert np.array_equal(codec.dct32_fwd(x1), oracle.dct32_fwd(x1))

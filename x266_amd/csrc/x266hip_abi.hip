@@ -89,6 +89,10 @@ struct x266hip_ctx {
     // slots' events.  With a stream per slot (rounds 1-3) uploads and downloads of different chunks did not overlap on this
     // runtime: 28-30 GB/s each way from pinned memory against 43 this way (profiles/r04_hostpipe.txt; the link gives 48.5 both ways)
     hipStream_t stage_stream[3] = {};
+    // small host-pointer calls (the BDPI shims: one block per call): two page-locked, device-visible 64 KiB buffers the kernel reads and writes in place
+    static constexpr size_t kSmallCallBytes = (size_t)64 << 10;
+    void *h_small_in = nullptr, *h_small_out = nullptr;
+    hipStream_t small_stream = nullptr;
     hipEvent_t stage_up[kSlots] = {}, stage_done[kSlots] = {}, stage_down[kSlots] = {};
     std::string err;
 };
@@ -434,6 +438,9 @@ void xHipCodecFree(x266hip_ctx *ctx)
     }
     for (hipStream_t st : ctx->stage_stream)
         if (st) (void)hipStreamDestroy(st);
+    if (ctx->h_small_in) (void)hipHostFree(ctx->h_small_in);
+    if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
+    if (ctx->small_stream) (void)hipStreamDestroy(ctx->small_stream);
     for (int type = 0; type < x266hip_ctx::kTypes; ++type)
         for (int l = 0; l < 3; ++l) {
             if (ctx->d_tr[type][l]) (void)hipFree(ctx->d_tr[type][l]);
@@ -1103,6 +1110,22 @@ static int host_batch(x266hip_ctx *ctx, int op, const void *in, void *out, size_
     if (n == 0) return X266HIP_OK;
     if (!in || !out) return fail(ctx, X266HIP_EINVAL, "NULL host buffer");
     X_DEV(ctx);
+    // A call of a block or a few (the BDPI shims hand over ONE: dct32_genNew, satd8x8_genNew) is all latency: upload, kernel and download
+    // as three stream operations cost 60-80 us per call.  Up to 64 KiB each way the kernel instead reads its input from, and writes its result
+    // to, page-locked host memory the device sees (hipHostMalloc: coherent, uncached on the device side): two memcpy on the host, ONE launch,
+    // one synchronize -- profiles/r06_bdpi_latency.txt.  Same kernels, same bytes (tests/test_gpu_parity.py runs both paths against each other).
+    if (n * in_unit <= x266hip_ctx::kSmallCallBytes && n * out_unit <= x266hip_ctx::kSmallCallBytes) {
+        if (!ctx->h_small_in) X_HIP(ctx, hipHostMalloc(&ctx->h_small_in, x266hip_ctx::kSmallCallBytes, hipHostMallocDefault));
+        if (!ctx->h_small_out) X_HIP(ctx, hipHostMalloc(&ctx->h_small_out, x266hip_ctx::kSmallCallBytes, hipHostMallocDefault));
+        if (!ctx->small_stream) X_HIP(ctx, hipStreamCreateWithFlags(&ctx->small_stream, hipStreamNonBlocking));
+        std::memcpy(ctx->h_small_in, in, n * in_unit);
+        const int rc_small = launch_op(ctx, op, ctx->h_small_in, ctx->h_small_out, n, ctx->small_stream);
+        const hipError_t es = hipStreamSynchronize(ctx->small_stream);   // also after a failed launch: nothing of this call stays in flight
+        if (rc_small != X266HIP_OK) return rc_small;
+        if (es != hipSuccess) return fail(ctx, X266HIP_EDEVICE, "hipStreamSynchronize(small call)", es);
+        std::memcpy(out, ctx->h_small_out, n * out_unit);
+        return X266HIP_OK;
+    }
     const size_t chunk_bytes = (size_t)16 << 20;                       // 16 MiB of input per chunk
     size_t chunk = chunk_bytes / in_unit;
     if (chunk > n) chunk = n;
