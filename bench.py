@@ -502,6 +502,9 @@ def compact_record(full):
     also, failed = {}, []
     for name, leg in (full.get("also") or {}).items():
         _leg_scalars(name, leg, also, failed)
+    one = ((full.get("also") or {}).get("host_api") or {}).get("one_block_call_us")
+    if one is not None:
+        also["host_api.one_block_call_us"] = _sig(float(one), 4)
     if full.get("also") is not None:
         line["also"] = also
         line["checks_failed"] = failed

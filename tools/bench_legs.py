@@ -356,6 +356,15 @@ def leg_host_api(b, n):
     out["pinned"] = {"blocks_per_s": n / dt, "GBps_each_way": nbytes / dt / 1e9, "ms": dt * 1e3, "same_result_as_pageable": bool(np.array_equal(zp, zh))}
     for k in ("pinned", "pageable"):
         out[k]["frac_of_link_both_directions"] = out[k]["GBps_each_way"] / two_way
+    # one block per call -- what the BDPI shims do (the <= 64 KiB path: the kernel runs on page-locked host memory, one launch + one synchronize)
+    x1, z1 = xh[:1].copy(), np.empty((1, 1024), np.int16)
+    for _ in range(50):
+        codec.L.xDct32FwdBatch(codec.ctx, P(x1.ctypes.data), P(z1.ctypes.data), 1)
+    t0 = time.perf_counter()
+    for _ in range(1000):
+        codec.L.xDct32FwdBatch(codec.ctx, P(x1.ctypes.data), P(z1.ctypes.data), 1)
+    out["one_block_call_us"] = (time.perf_counter() - t0) / 1000 * 1e6
+    out["one_block_call_same_result"] = bool(np.array_equal(z1[0], zh[0]))
     out["note"] = ("host pointers in and out, best of 4 calls: 16 MiB chunks over three staging slots, uploads + kernels issued by the calling thread, "
                    "downloads by a helper thread (a pageable copy blocks its issuing thread); inputs are NOT resident, so this is never `value`")
     return out
