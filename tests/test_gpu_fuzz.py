@@ -293,3 +293,64 @@ def test_sad_batches_random(codec, edge, n, seed, extreme):
         b = a.copy()
     want = np.abs(a.astype(np.int32) - b.astype(np.int32)).sum(axis=1).astype(np.uint32)
     assert np.array_equal(codec.sad(edge, a, b), want)
+
+
+@fuzz(25)
+@given(tw=st.integers(1, 21), th=st.integers(1, 9), ctu=st.integers(0, 1), pitch=st.integers(1, 3), extreme=st.integers(0, 1), seed=st.integers(1, 1 << 20),
+       wg=st.sampled_from([0, 64, 128, 256]), satd_variant=st.sampled_from([0, 1, 3]))
+def test_tile_stage_random_frames(codec, oracle, tw, th, ctu, pitch, extreme, seed, wg, satd_variant):
+    """The tile stage on random frames (any bytes are a valid tile array): luma and chroma residuals in both orders, planar and pitched chroma
+    outputs, the fused tiles -> DCT32 / SATD forms for both, and the whole-CTU launch -- against the oracle's residuals run through the pinned
+    kernels' oracles.  ctu = 1 rounds the frame to whole 64x64 CTUs (the 32x32 orders need them), else any multiple of 16."""
+    w, h = (64 * ((tw + 3) // 4), 64 * ((th + 3) // 4)) if ctu else (16 * tw, 16 * th)
+    nt = (w // 16) * (h // 16)
+    rs = np.random.RandomState(seed)
+    mk = (lambda: rs.choice(np.array([0, 255], np.uint8), nt * 512)) if extreme else (lambda: rs.randint(0, 256, nt * 512).astype(np.uint8))
+    tc, tp = mk(), mk()
+    dc, dp = codec.alloc(nt * 512), codec.alloc(nt * 512)
+    dc.upload(tc); dp.upload(tp)
+    saved = {k: codec.get_option(k) for k in ("dct32_wg_threads", "satd_variant")}
+    try:
+        codec.set_option("dct32_wg_threads", wg); codec.set_option("satd_variant", satd_variant)
+        npl = w * h // 4
+        for edge in ((8, 32) if ctu else (8,)):
+            n = npl // (edge * edge)
+            ou, ov = oracle.residual_chroma(tc, tp, w, h, edge)
+            buf = codec.alloc(npl * 2 * pitch * 2 + 64)
+            buf.upload(np.full(npl * pitch * 2 + 32, 0x1234, np.int16))
+            vp = buf.ptr + (edge * edge * 2 if pitch > 1 else n * pitch * edge * edge * 2)
+            codec.residual_chroma_dev(dc.ptr, dp.ptr, w, h, edge, buf.ptr, vp, pitch)
+            codec.stream_sync()
+            got = buf.download(np.int16, npl * pitch * 2 + 32)
+            gu = got[: n * pitch * edge * edge].reshape(n, pitch, edge * edge)[:, 0]
+            off = edge * edge if pitch > 1 else n * pitch * edge * edge
+            gv = got[off: off + n * pitch * edge * edge - (edge * edge * (pitch - 1) if pitch > 1 else 0)]
+            gv = np.concatenate([gv, np.zeros((-len(gv)) % (pitch * edge * edge), np.int16)]).reshape(n, pitch, edge * edge)[:, 0]
+            assert np.array_equal(gu, ou.reshape(n, -1)) and np.array_equal(gv, ov.reshape(n, -1)), (edge, pitch)
+            lum = oracle.residual_luma(tc, tp, w, h, edge)
+            dl = codec.alloc(w * h * 2)
+            codec.residual_luma_dev(dc.ptr, dp.ptr, w, h, edge, dl.ptr)
+            codec.stream_sync()
+            assert np.array_equal(dl.download(np.int16, w * h), lum), edge
+            if edge == 8:
+                cu, cv, cl = codec.alloc(n * 4), codec.alloc(n * 4), codec.alloc(w * h // 64 * 4)
+                codec.satd8x8_chroma_from_tiles_dev(dc.ptr, dp.ptr, w, h, cu.ptr, cv.ptr)
+                codec.satd8x8_from_tiles_dev(dc.ptr, dp.ptr, w, h, cl.ptr)
+                codec.stream_sync()
+                assert np.array_equal(cu.download(np.uint32, n), oracle.satd8x8(ou)) and np.array_equal(cv.download(np.uint32, n), oracle.satd8x8(ov))
+                assert np.array_equal(cl.download(np.uint32, w * h // 64), oracle.satd8x8(lum))
+            else:
+                zu, zv, zl, zc = codec.alloc(n * 2048), codec.alloc(n * 2048), codec.alloc(w * h * 2), codec.alloc(n * 6 * 2048)
+                codec.dct32_fwd_chroma_from_tiles_dev(dc.ptr, dp.ptr, w, h, zu.ptr, zv.ptr)
+                codec.dct32_fwd_from_tiles_dev(dc.ptr, dp.ptr, w, h, zl.ptr)
+                codec.dct32_fwd_ctu_from_tiles_dev(dc.ptr, dp.ptr, w, h, zc.ptr)
+                codec.stream_sync()
+                wu, wv, wl = oracle.dct32_fwd(ou), oracle.dct32_fwd(ov), oracle.dct32_fwd(lum)
+                assert np.array_equal(zu.download(np.int16, n * 1024).reshape(n, 1024), wu) and np.array_equal(zv.download(np.int16, n * 1024).reshape(n, 1024), wv)
+                assert np.array_equal(zl.download(np.int16, w * h).reshape(-1, 1024), wl)
+                ctus = zc.download(np.int16, n * 6 * 1024).reshape(n, 6, 1024)
+                wl_ctu = wl.reshape(h // 64, 2, w // 64, 2, 1024).transpose(0, 2, 1, 3, 4).reshape(n, 4, 1024)
+                assert np.array_equal(ctus[:, :4], wl_ctu) and np.array_equal(ctus[:, 4], wu) and np.array_equal(ctus[:, 5], wv)
+    finally:
+        for k, v in saved.items():
+            codec.set_option(k, v)
