@@ -489,6 +489,8 @@ def compact_record(full):
     r = full.get("roofline") or {}
     line["roofline"] = {k: _sig(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_launch",
                                                      "kernel_ms_mean", "algorithmic_bytes_per_launch", "frac_of_same_box_copy", "frac_at_mean")}
+    if isinstance(r.get("traffic"), (int, float)):
+        line["roofline"]["traffic"] = int(round(r["traffic"]))          # bytes per launch from the counters: whole bytes, next to the algorithmic count
     line["roofline"]["traffic_measured_live"] = "measured in this run" in str(r.get("traffic_source"))   # else replayed from profiles/traffic.json, or null
     if r.get("frac_by_rank"):
         line["roofline"]["frac_by_rank"] = [_sig(v, 4) for v in r["frac_by_rank"]]
