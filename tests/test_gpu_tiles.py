@@ -372,3 +372,22 @@ def test_chroma_of_tile_frames_beyond_4_gib(codec, oracle):
                 first = (4 * cy + j) * tiles_x + 4 * cx                  # four consecutive tiles = 8x8 chroma blocks of tile row 4 cy + j
                 assert np.array_equal(fetch(d_r8, base + first * 128, 256, np.int16), r8.reshape(4, 4, 64)[j].ravel()), (cy, cx, plane, j)
                 assert np.array_equal(fetch(d_cost, plane * nt * 4 + first * 4, 4, np.uint32), want_cost[j]), (cy, cx, plane, j)
+
+
+@pytest.mark.parametrize("size", [(), ("256", "192"), ("3840", "2176")])
+def test_plain_c_host_takes_a_420_frame_through_the_tile_stage(size):
+    """host/frame420_example.c: planar YUV -> tiles -> whole-CTU coefficients + luma / chroma SATD costs from a C host without HIP headers,
+    every fused output compared there with the two-step calls (residual in HBM, then the pinned batch kernels)."""
+    import json
+    import os
+    import subprocess
+    from _util import ROOT
+    exe = os.path.join(ROOT, "host", "frame420_example")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "--no-print-directory"])
+    out = subprocess.run([exe, *size], timeout=300, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["fused_equals_two_step"] is True and d["luma_satd_sum"] > 0 and d["chroma_satd_sum"] > 0
+    w, h = (int(size[0]), int(size[1])) if size else (1920, 1088)
+    assert d["ctus"] == (w // 64) * (h // 64) and d["coefficient_bytes"] == d["ctus"] * 12288
