@@ -503,6 +503,8 @@ def compact_record(full):
         line["secondary"] = {k: _sig(v) for k, v in full["secondary"].items()}
     also, failed = {}, []
     for name, leg in (full.get("also") or {}).items():
+        if name.endswith("_error") and name != "node_layer_error":      # a leg that threw (N = 1): named, the rest of the line stands
+            failed.append(name)
         _leg_scalars(name, leg, also, failed)
     one = ((full.get("also") or {}).get("host_api") or {}).get("one_block_call_us")
     if one is not None:
@@ -522,10 +524,21 @@ def compact_record(full):
     return line
 
 
+def _finite(o):
+    """NaN / +-Infinity are not JSON: a leg that divided by zero must cost its own scalar (null), never the line"""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
 def emit(result, json_fd):
     """rank 0: the full record to FULL_RECORD (cwd; also gpurun_out/ when it exists), the compact line -- alone -- to stdout.
     stderr only gets a pointer: a consumer that reads both streams must not find a 20 KB line after the compact one."""
-    full = json.dumps(result)
+    full = json.dumps(_finite(result))
     for path in (FULL_RECORD, os.path.join("gpurun_out", FULL_RECORD) if os.path.isdir("gpurun_out") else None):
         if path:
             try:
@@ -535,7 +548,7 @@ def emit(result, json_fd):
                 sys.stderr.write("bench.py: could not write %s: %s\n" % (path, e))
     sys.stderr.write("bench.py: full record (%d bytes) in %s\n" % (len(full), os.path.abspath(FULL_RECORD)))
     sys.stderr.flush()
-    os.write(json_fd, (json.dumps(compact_record(result), separators=(",", ":")) + "\n").encode())
+    os.write(json_fd, (json.dumps(_finite(compact_record(result)), separators=(",", ":"), allow_nan=False) + "\n").encode())
 
 
 def spawn_ranks(args):
@@ -601,34 +614,54 @@ def main():
 
     if not args.no_also:
         also, me = {}, {}
-        also.update(leg_dct32_inverse_and_fused(b, x, z, pmc, pmc_src))
-        also["satd8x8"] = leg_satd(b, pmc, pmc_src)
+
+        def leg(name, fn, merge=False):
+            """one family of `also`.  At N = 1 a leg that throws costs its own entry ("<name>_error", listed under checks_failed), not the line;
+            with several ranks the exception stands: the other ranks are inside the leg's barriers and the launcher must end the job."""
+            try:
+                r = fn()
+            except Exception as e:                                          # noqa: BLE001
+                if world > 1:
+                    raise
+                also[name + "_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+                return
+            if merge:
+                also.update(r)
+            else:
+                also[name] = r
+        leg("dct32_inverse_and_fused", lambda: leg_dct32_inverse_and_fused(b, x, z, pmc, pmc_src), merge=True)
+        leg("satd8x8", lambda: leg_satd(b, pmc, pmc_src))
         if not args.no_me:
-            also.update(leg_motion_search(b, me))
+            leg("motion_search", lambda: leg_motion_search(b, me), merge=True)
         if not args.no_transform_set:
-            also["transform_set"] = leg_transform_set(b, x)
-            also["fused_from_tiles"] = leg_fused_from_tiles(b)
-            also["front_end_and_sad"] = leg_front_end_and_sad(b)
-            also["intra32"] = leg_intra(b)
+            leg("transform_set", lambda: leg_transform_set(b, x))
+            leg("fused_from_tiles", lambda: leg_fused_from_tiles(b))
+            leg("front_end_and_sad", lambda: leg_front_end_and_sad(b))
+            leg("intra32", lambda: leg_intra(b))
             if not args.no_autotune:
-                also["autotune"] = leg_autotuned(b, x, z)
+                leg("autotune", lambda: leg_autotuned(b, x, z))
         if rank == 0 and world == 1 and not args.no_host_api:
-            also["host_api"] = leg_host_api(b, min(b.n_dct, 1 << 17))
+            leg("host_api", lambda: leg_host_api(b, min(b.n_dct, 1 << 17)))
         result["also"] = also
-        result["secondary"] = {"metric": "satd8x8_blocks_per_s", "value": also["satd8x8"]["value"], "unit": "blocks/s",
-                               "roofline_frac": also["satd8x8"]["roofline"]["frac"],
-                               "frac_of_same_box_read": also["satd8x8"]["roofline"]["frac_of_same_box_read"]}
+        if "satd8x8" in also:
+            result["secondary"] = {"metric": "satd8x8_blocks_per_s", "value": also["satd8x8"]["value"], "unit": "blocks/s",
+                                   "roofline_frac": also["satd8x8"]["roofline"]["frac"],
+                                   "frac_of_same_box_read": also["satd8x8"]["roofline"]["frac_of_same_box_read"]}
         if (not b.share or os.environ.get("X266HIP_RCCL_LIB")) and args.stream8k > 0:
             run_node_legs_under_watchdog(b, result, also, x, z, me, json_fd, emit)
         also["rccl_libraries_in_process"] = loaded_libraries("librccl")
 
     # ---- CPU baseline for the headline leg (rank 0, N = 1 only) ------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        x_host = x.download(np.int16, b.n_dct * 1024).reshape(b.n_dct, 1024)
-        base, exact = cpu_baseline_dct(x_host, z_host.reshape(b.n_dct, 1024))
-        result["cpu_baseline"] = base
-        if not exact:
-            result["error"] = "GPU output differs from the CPU reference"
+        try:
+            x_host = x.download(np.int16, b.n_dct * 1024).reshape(b.n_dct, 1024)
+            base, exact = cpu_baseline_dct(x_host, z_host.reshape(b.n_dct, 1024))
+            result["cpu_baseline"] = base
+            if not exact:
+                result["error"] = "GPU output differs from the CPU reference"
+        except Exception as e:                                              # noqa: BLE001  (e.g. the checker's .so files did not travel: say so, keep the line)
+            result["cpu_baseline"] = None
+            result["error"] = "cpu_baseline leg failed: %s: %s" % (type(e).__name__, str(e)[:200])
     elif rank == 0:
         result["cpu_baseline"] = None
 

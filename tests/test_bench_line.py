@@ -96,3 +96,23 @@ def test_rank_to_device_mapping_for_eight_ranks():
         bench.pick_device(5, 4, False, {})
     with pytest.raises(SystemExit):
         bench.pick_device(1, 1, False, {})
+
+
+def test_non_finite_numbers_never_reach_the_line():
+    """a leg that divides by zero (inf) or by nothing (nan) becomes null in the line: NaN / Infinity are not JSON and would cost the driver the whole record"""
+    full = _sample()
+    full["also"]["dct32_inv"]["roofline"]["frac"] = float("nan")
+    full["also"]["stream8k"]["frames_per_s"] = float("inf")
+    full["roofline"]["frac_at_mean"] = float("-inf")
+    line = json.dumps(bench._finite(bench.compact_record(full)), separators=(",", ":"), allow_nan=False)
+    d = json.loads(line)
+    assert d["also"]["dct32_inv"] is None and d["also"]["stream8k"] is None and d["roofline"]["frac_at_mean"] is None
+    assert d["value"] == full["value"] and "NaN" not in line and "Infinity" not in line
+
+
+def test_a_leg_that_threw_is_named_in_the_line():
+    full = _sample()
+    del full["also"]["intra32"]
+    full["also"]["intra32_error"] = "X266Error: xIntra32PredictDev failed (-3): intra launch: out of memory"
+    d = json.loads(_line(full))
+    assert d["checks_failed"] == ["intra32_error"] and "intra32.predict" not in d["also"] and d["also"]["dct32_inv"] > 0
