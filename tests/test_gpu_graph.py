@@ -34,6 +34,8 @@ class FrameJob:
         self.best = a((w // 8) * (h // 8) * 8)
         self.n_blk = w * h // 1024                        # intra: one reference set and mode per 32x32 block, the cur plane's bytes as block-major source
         self.irefs, self.imodes, self.icoef = a(self.n_blk * 144), a(self.n_blk), a(w * h * 2)
+        self.ctu = a(w * h * 3)                            # round 6: the whole-CTU launch (Y0..Y3 U V) and the chroma costs of the same tiles
+        self.cost_c = a(nt * 8)
 
     def upload(self, seed):
         w, h, pad = self.w, self.h, self.pad
@@ -58,6 +60,8 @@ class FrameJob:
         cd.residual_luma_dev(self.tiles[0].ptr, self.tiles[1].ptr, w, h, 32, self.res.ptr, st)
         cd.dct32_fwd_inv_dev(self.res.ptr, self.coef2.ptr, self.recon.ptr, w * h // 1024, st)
         cd.intra32_residual_dct32_dev(self.irefs.ptr, self.imodes.ptr, 0, self.y[0].ptr, self.icoef.ptr, self.n_blk, st)
+        cd.dct32_fwd_ctu_from_tiles_dev(self.tiles[0].ptr, self.tiles[1].ptr, w, h, self.ctu.ptr, st)
+        cd.satd8x8_chroma_from_tiles_dev(self.tiles[0].ptr, self.tiles[1].ptr, w, h, self.cost_c.ptr, self.cost_c.ptr + 4, 2, st)
         if not with_search:
             return
         stride = w + 2 * self.pad
@@ -66,7 +70,8 @@ class FrameJob:
     def results(self):
         w, h = self.w, self.h
         return [self.coef.download(np.int16, w * h), self.cost.download(np.uint32, w * h // 64), self.coef2.download(np.int16, w * h),
-                self.recon.download(np.int16, w * h), self.best.download(np.uint32, (w // 8) * (h // 8) * 2), self.icoef.download(np.int16, w * h)]
+                self.recon.download(np.int16, w * h), self.best.download(np.uint32, (w // 8) * (h // 8) * 2), self.icoef.download(np.int16, w * h),
+                self.ctu.download(np.int16, w * h * 3 // 2), self.cost_c.download(np.uint32, (w // 16) * (h // 16) * 2)]
 
 
 def test_graph_replay_equals_direct_calls(codec):
@@ -84,14 +89,14 @@ def test_graph_replay_equals_direct_calls(codec):
             job.enqueue(st)
             codec.stream_sync(st)
             direct = job.results()
-            for buf in (job.coef, job.cost, job.coef2, job.recon, job.best, job.icoef):   # wipe, then replay the graph
+            for buf in (job.coef, job.cost, job.coef2, job.recon, job.best, job.icoef, job.ctu, job.cost_c):   # wipe, then replay the graph
                 buf.upload(np.zeros(buf.nbytes, np.uint8))
             codec.graph_launch(graph, st)
             codec.stream_sync(st)
             for a, b in zip(direct, job.results()):
                 assert np.array_equal(a, b)
             assert direct[0].any() and direct[1].any()
-        # the six small kernels without the search are launch-bound: one submission instead of six
+        # the eight small kernels without the search are launch-bound: one submission instead of eight
         codec.graph_begin(st)
         job.enqueue(st, with_search=False)
         small = codec.graph_end(st)
