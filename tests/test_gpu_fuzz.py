@@ -9,7 +9,7 @@ from _util import extremes_np, fullrange_np, intra_refs_np, residual_np
 
 pytestmark = pytest.mark.gpu
 
-# X266_FUZZ_SCALE=k multiplies the example counts and turns random seeds on (campaigns run by hand: round 6, the final library -- all twelve tests incl. the tile stage with chroma and the whole-CTU launch, and the DCT / SATD batches over the 64 KiB host path -- 100x = 30 500 examples, clean; round 5, the final library -- fused DCT32 and fused intra kernels, LDS-DMA from-tiles SATD, the re-shaped residual and inverse kernels -- 1000x = 255 000 examples, clean (and 300x before the last shape changes); round 4, after the SATD LDS-DMA kernel, the kernel prune, the new SAD and intra kernels, 100x = 25 500 examples, clean; round 3, after the tile kernel rewrite and with the three round-3 tests, 100x = 23 000 examples, clean; the round-2 campaign was
+# X266_FUZZ_SCALE=k multiplies the example counts and turns random seeds on (campaigns run by hand: round 6, the final library -- all twelve tests incl. the tile stage with chroma and the whole-CTU launch, and the DCT / SATD batches over the 64 KiB host path -- 100x = 30 500 examples, clean (the tile-stage test alone also at 400x = 10 000 examples); round 5, the final library -- fused DCT32 and fused intra kernels, LDS-DMA from-tiles SATD, the re-shaped residual and inverse kernels -- 1000x = 255 000 examples, clean (and 300x before the last shape changes); round 4, after the SATD LDS-DMA kernel, the kernel prune, the new SAD and intra kernels, 100x = 25 500 examples, clean; round 3, after the tile kernel rewrite and with the three round-3 tests, 100x = 23 000 examples, clean; the round-2 campaign was
 # 200x = 33 000 examples, clean); by default the examples are derived deterministically from the test body, so that a regular run of the
 # suite does not depend on a random seed.
 import os
